@@ -1,0 +1,352 @@
+"""FeMaSRNet on MI355X: the reference's module surface over libfemasr_hip.so.
+
+Drop-in for basicsr/archs/femasr_arch.py:214-479 on the INFERENCE path:
+same class name, registered in ARCH_REGISTRY the same way, same keyword-only
+constructor (femasr_arch.py:216-228), same methods (`test`, `test_tile`,
+`forward`, `encode_and_decode`, `decode_indices`), same public attributes and
+the same state-dict keys/shapes, so `load_state_dict(torch.load(p)['params'],
+strict=False)` (inference_femasr.py:40) works on released checkpoints.
+
+The torch sub-modules below are PARAMETER HOLDERS only: they give the state
+dict its names, shapes and default initialisation.  No torch op computes
+anything on the path — every forward goes through the C ABI
+(include/femasr_hip.h) into the HIP kernels, and raises if the extension or a
+GPU is missing (no CPU / eager fallback).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+from .. import tiling
+from ..registry import ARCH_REGISTRY
+
+_CHANNELS = {8: 256, 16: 256, 32: 256, 64: 256, 128: 128, 256: 64, 512: 32}   # femasr_arch.py:244-252
+
+
+# --------------------------------------------------------------------------- parameter holders
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - never used on the product path
+        raise RuntimeError('parameter holder: computation happens in libfemasr_hip.so')
+
+
+def _seq(*mods):
+    """Numbered children like nn.Sequential, without its forward."""
+    h = _Holder()
+    for i, m in enumerate(mods):
+        if m is not None:
+            h.add_module(str(i), m)
+    return h
+
+
+def _norm(c):               # fema_utils.py:5-29 NormLayer('gn') -> .norm = GroupNorm(32, c, eps=1e-6)
+    h = _Holder()
+    h.norm = nn.GroupNorm(32, c, eps=1e-6, affine=True)
+    return h
+
+
+def _resblock(c):           # fema_utils.py:65-84: conv = Sequential(norm, act, conv, norm, act, conv)
+    h = _Holder()
+    h.conv = _seq(_norm(c), None, nn.Conv2d(c, c, 3, 1, 1), _norm(c), None, nn.Conv2d(c, c, 3, 1, 1))
+    return h
+
+
+def _swin_block(dim, heads, ws, shift, res=(32, 32)):   # network_swinir.py:164-237
+    h = _Holder()
+    h.norm1 = nn.LayerNorm(dim)
+    attn = _Holder()
+    attn.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), heads))
+    nn.init.trunc_normal_(attn.relative_position_bias_table, std=.02)
+    ys, xs = np.divmod(np.arange(ws * ws), ws)
+    rel = (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1)
+    attn.register_buffer('relative_position_index', torch.from_numpy(rel.astype(np.int64)))
+    attn.qkv = nn.Linear(dim, dim * 3)
+    attn.proj = nn.Linear(dim, dim)
+    h.attn = attn
+    h.norm2 = nn.LayerNorm(dim)
+    mlp = _Holder()
+    mlp.fc1 = nn.Linear(dim, dim * 4)
+    mlp.fc2 = nn.Linear(dim * 4, dim)
+    h.mlp = mlp
+    if shift > 0:           # persistent buffer in checkpoints (16x64x64 for the (32,32) construction size)
+        hh, ww = res
+        lab = np.zeros((hh, ww), np.float32)
+        sl = (slice(0, -ws), slice(-ws, -shift), slice(-shift, None))
+        cnt = 0
+        for a in sl:
+            for b in sl:
+                lab[a, b] = cnt
+                cnt += 1
+        win = lab.reshape(hh // ws, ws, ww // ws, ws).transpose(0, 2, 1, 3).reshape(-1, ws * ws)
+        diff = win[:, None, :] - win[:, :, None]
+        h.register_buffer('attn_mask', torch.from_numpy(np.where(diff != 0, -100.0, 0.0).astype(np.float32)))
+    else:
+        h.register_buffer('attn_mask', None)
+    return h
+
+
+def _rstb(dim=256, depth=6, heads=8, ws=8):             # network_swinir.py:419-482
+    h = _Holder()
+    grp = _Holder()
+    grp.blocks = _seq(*[_swin_block(dim, heads, ws, 0 if i % 2 == 0 else ws // 2) for i in range(depth)])
+    h.residual_group = grp
+    h.conv = nn.Conv2d(dim, dim, 3, 1, 1)
+    return h
+
+
+def _up_block(cin, cout):   # Upsample, Conv, ResBlock, ResBlock  (femasr_arch.py:171-176, 201-206)
+    return _seq(None, nn.Conv2d(cin, cout, 3, 1, 1), _resblock(cout), _resblock(cout))
+
+
+# --------------------------------------------------------------------------- the arch
+@ARCH_REGISTRY.register()
+class FeMaSRNet(nn.Module):
+    def __init__(self, *, in_channel=3, codebook_params=None, gt_resolution=256, LQ_stage=False,
+                 norm_type='gn', act_type='silu', use_quantize=True, scale_factor=4,
+                 use_semantic_loss=False, use_residual=True, **ignore_kwargs):
+        super().__init__()
+        codebook_params = np.array(codebook_params)
+        if codebook_params.ndim != 2 or codebook_params.shape[0] != 1:
+            raise NotImplementedError('MI355X path builds single-codebook configs (codebook_params=[[s,n_e,e_dim]])')
+        if norm_type != 'gn' or act_type != 'silu':
+            raise NotImplementedError("MI355X path builds norm_type='gn', act_type='silu' (the published configs)")
+        self.codebook_scale = codebook_params[:, 0]
+        n_e, e_dim = int(codebook_params[0, 1]), int(codebook_params[0, 2])
+        self.use_quantize = use_quantize
+        self.in_channel = in_channel
+        self.gt_res = gt_resolution
+        self.LQ_stage = LQ_stage
+        self.scale_factor = scale_factor if LQ_stage else 1
+        self.use_residual = use_residual
+        # accepted for signature compatibility; the VGG branch is training-only and is forced off
+        # inside test() by the reference as well (femasr_arch.py:451-452)
+        self.use_semantic_loss = False
+        self.max_depth = int(np.log2(gt_resolution // self.codebook_scale[0]))
+        encode_depth = int(np.log2(gt_resolution // self.scale_factor // self.codebook_scale[0]))
+        self._encode_depth = encode_depth
+
+        # ---- parameter tree (names == reference state-dict keys)
+        enc = _Holder()
+        res = gt_resolution // self.scale_factor
+        enc.in_conv = nn.Conv2d(in_channel, _CHANNELS[res], 4, padding=1)
+        blocks = []
+        for _ in range(encode_depth):
+            ci, co = _CHANNELS[res], _CHANNELS[res // 2]
+            blocks.append(_seq(nn.Conv2d(ci, co, 3, stride=2, padding=1), _resblock(co), _resblock(co)))
+            res //= 2
+        if LQ_stage:
+            swin = _Holder()
+            swin.swin_blks = _seq(*[_rstb() for _ in range(4)])
+            blocks.append(swin)
+            for _ in range(2):
+                blocks.append(_up_block(_CHANNELS[res], _CHANNELS[res * 2]))
+                res *= 2
+        enc.blocks = _seq(*blocks)
+        self.multiscale_encoder = enc
+
+        dec = []
+        out_ch = None
+        for i in range(self.max_depth):
+            r = gt_resolution // 2 ** self.max_depth * 2 ** i
+            blk = _Holder()
+            blk.block = _up_block(_CHANNELS[r], _CHANNELS[r * 2])
+            dec.append(blk)
+            out_ch = _CHANNELS[r * 2]
+        self.decoder_group = _seq(*dec)
+        self.out_conv = nn.Conv2d(out_ch, 3, 3, 1, 1)
+
+        q = _Holder()
+        q.embedding = nn.Embedding(n_e, e_dim)
+        q.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)       # femasr_arch.py:33
+        self.quantize_group = _seq(q)
+        qc = _CHANNELS[int(self.codebook_scale[0])]
+        self.before_quant_group = _seq(nn.Conv2d(qc, e_dim, 1))
+        aq = _Holder()
+        aq.conv = nn.Conv2d(e_dim, qc, 3, 1, 1)
+        self.after_quant_group = _seq(aq)
+        self._n_e, self._e_dim = n_e, e_dim
+
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self._handle = None
+        self._handle_device = None
+        self._pushed = {}
+        self._ws = None
+        self.max_tile_batch = 16        # tiles per batched test() call inside test_tile
+
+    # ------------------------------------------------------------------ native handle
+    def _native(self, device):
+        """Create / refresh the C handle and push any changed weights."""
+        if device.type != 'cuda':
+            raise _lib.FemasrError('FeMaSRNet (MI355X build) runs on a GPU device only; move the module and '
+                                   'inputs to cuda. There is no CPU fallback.')
+        lib = _lib.load()
+        dev_index = device.index if device.index is not None else torch.cuda.current_device()
+        if self._handle is None or self._handle_device != dev_index:
+            self._release()
+            cfg = _lib.Config(self.in_channel, self.gt_res, int(self.LQ_stage), int(self.scale_factor),
+                              int(self.use_quantize), int(self.use_residual), int(self.codebook_scale[0]),
+                              self._n_e, self._e_dim, dev_index)
+            h = ctypes.c_void_p()
+            _lib.check(lib.femasr_create(ctypes.byref(cfg), ctypes.byref(h)))
+            self._handle, self._handle_device, self._pushed = h, dev_index, {}
+        dirty = False
+        for key, t in self.state_dict().items():
+            if key.endswith('relative_position_index') or key.endswith('attn_mask'):
+                continue
+            if t.device.type != 'cuda':
+                raise _lib.FemasrError(f'parameter {key} is on {t.device}; call .to("cuda") on the module')
+            stamp = (t.data_ptr(), t._version)
+            if self._pushed.get(key) == stamp:
+                continue
+            if not dirty:
+                torch.cuda.synchronize(device)
+                dirty = True
+            src = t.detach().to(torch.float32).contiguous()
+            shape = (ctypes.c_int64 * src.dim())(*src.shape)
+            _lib.check(lib.femasr_set_weight(self._handle, key.encode(), _lib.ptr(src), shape, src.dim()))
+            self._pushed[key] = stamp
+        if dirty:
+            _lib.check(lib.femasr_finalize_weights(self._handle))
+        return lib, self._handle
+
+    def _release(self):
+        if getattr(self, '_handle', None) is not None:
+            _lib.load().femasr_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def enable_profile(self, on=True):
+        lib, h = self._native(next(self.parameters()).device)
+        _lib.check(lib.femasr_profile_enable(h, int(on)))
+        _lib.check(lib.femasr_profile_reset(h))
+
+    def profile(self):
+        """{kernel name: (ms, launches, flops, bytes)} since the last reset (HIP events on the launch stream)."""
+        lib, h = self._native(next(self.parameters()).device)
+        out = {}
+        for s in range(lib.femasr_profile_slots(h)):
+            ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            _lib.check(lib.femasr_profile_get(h, s, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
+            if n.value:
+                out[lib.femasr_profile_name(h, s).decode()] = (ms.value, n.value, fl.value, by.value)
+        return out
+
+    # ------------------------------------------------------------------ the path
+    def _run(self, x, pad_mode):
+        if x.dim() != 4 or x.shape[1] != self.in_channel:
+            raise ValueError(f'expected (B,{self.in_channel},H,W), got {tuple(x.shape)}')
+        lib, h = self._native(x.device)
+        x = x.detach().to(torch.float32).contiguous()
+        b, _, hh, ww = x.shape
+        s = self.scale_factor
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.femasr_workspace_bytes(h, b, hh, ww, pad_mode, ctypes.byref(nbytes)))
+        ws = self._workspace(nbytes.value, x.device)
+        if pad_mode:
+            ph, pw = tiling.padded_hw(hh, ww, s)
+            oh, ow = hh * s, ww * s
+        else:
+            ph, pw = hh, ww
+            oh, ow = hh * s, ww * s
+        down = 2 ** self._encode_depth
+        qh, qw = ph // down, pw // down
+        if not pad_mode and (hh % (down * (8 if self.LQ_stage else 1)) or ww % (down * (8 if self.LQ_stage else 1))):
+            raise ValueError(f'forward(): H,W must be multiples of {down * (8 if self.LQ_stage else 1)}; use test() for '
+                             'arbitrary sizes')
+        out = torch.empty((b, 3, oh, ow), dtype=torch.float32, device=x.device)
+        idx = torch.empty((b, 1, qh, qw), dtype=torch.int64, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.femasr_forward(h, ctypes.c_void_p(stream), _lib.ptr(x), b, hh, ww, pad_mode,
+                                      _lib.ptr(out), _lib.ptr(idx), _lib.ptr(ws), ws.numel()))
+        return out, idx
+
+    @torch.no_grad()
+    def encode_and_decode(self, input, gt_indices=None, current_iter=None):
+        if gt_indices is not None:
+            raise NotImplementedError('gt_indices is a training-time input (femasr_arch.py:339-340)')
+        out, idx = self._run(input, 0)
+        zero = out.new_zeros(())
+        return out, zero, zero, [idx]
+
+    @torch.no_grad()
+    def forward(self, input, gt_indices=None):
+        """(dec, codebook_loss, semantic_loss, [indices]) like femasr_arch.py:470-479 (losses are 0 in inference)."""
+        return self.encode_and_decode(input, gt_indices)
+
+    @torch.no_grad()
+    def test(self, input):
+        """femasr_arch.py:449-468: mirror-pad to (h//wsz+1)*wsz, run, crop to (h*s, w*s)."""
+        return self._run(input, 1)[0]
+
+    @torch.no_grad()
+    def test_with_indices(self, input):
+        return self._run(input, 1)
+
+    @torch.no_grad()
+    def decode_indices(self, indices):
+        assert len(indices.shape) == 4, f'shape of indices must be (b, 1, h, w), but got {indices.shape}'
+        dev = next(self.parameters()).device
+        lib, h = self._native(dev)
+        idx = indices.to(device=dev, dtype=torch.int64).contiguous()
+        b, _, qh, qw = idx.shape
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.femasr_decode_workspace_bytes(h, b, qh, qw, ctypes.byref(nbytes)))
+        ws = self._workspace(nbytes.value, dev)
+        up = 2 ** self.max_depth
+        out = torch.empty((b, 3, qh * up, qw * up), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.femasr_decode_indices(h, ctypes.c_void_p(stream), _lib.ptr(idx), b, qh, qw, _lib.ptr(out),
+                                             _lib.ptr(ws), ws.numel()))
+        return out
+
+    # ------------------------------------------------------------------ tiled inference
+    @torch.no_grad()
+    def test_tile(self, input, tile_size=240, tile_pad=16, rank=0, world_size=1, gather=None):
+        """Reference semantics of femasr_arch.py:387-447 (overlap-discard paste onto a zero canvas), but
+        tiles of one shape class run as batched `test()` calls, and with world_size > 1 each rank
+        computes a contiguous share of every class; `gather(list_of_tensors) -> list per rank` supplies
+        the collective (femasr_amd.distributed.gather_tiles, RCCL all-gather)."""
+        batch, channel, height, width = input.shape
+        s = self.scale_factor
+        tiles = tiling.enumerate_tiles(height, width, tile_size, tile_pad)
+        classes = tiling.shape_classes(tiles)
+        mine = tiling.partition(classes, rank, world_size)
+        results = {}
+        for hw, tl in mine.items():
+            outs = []
+            for i in range(0, len(tl), max(1, self.max_tile_batch // batch)):
+                chunk = tl[i:i + max(1, self.max_tile_batch // batch)]
+                crops = torch.cat([input[:, :, t.y0p:t.y1p, t.x0p:t.x1p] for t in chunk], 0)
+                outs.append(self.test(crops))
+            results[hw] = torch.cat(outs, 0) if outs else input.new_zeros((0, channel, hw[0] * s, hw[1] * s))
+        if world_size > 1:
+            if gather is None:
+                raise ValueError('world_size > 1 needs a gather callable')
+            per_rank = gather(results, classes, batch, channel, s)
+        else:
+            per_rank = [results]
+        output = input.new_zeros((batch, channel, height * s, width * s))
+        for r, res in enumerate(per_rank):
+            owned = tiling.partition(classes, r, world_size)
+            for hw, tl in owned.items():
+                block = res[hw]
+                for k, t in enumerate(tl):
+                    ys, ye, xs, xe = t.out_src(s)
+                    dy0, dy1, dx0, dx1 = t.out_dst(s)
+                    output[:, :, dy0:dy1, dx0:dx1] = block[k * batch:(k + 1) * batch, :, ys:ye, xs:xe]
+        return output

@@ -1,0 +1,49 @@
+"""Build libfemasr_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    python femasr_amd/csrc/build.py [--force]
+
+Flags that matter for the parity contract: -ffp-contract=off (the kernels place
+every fmaf explicitly) and correctly-rounded fp32 divide / sqrt.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ['kernels_conv.hip', 'kernels_misc.hip', 'model.hip']
+HEADERS = ['common.h', 'detmath.h', '../../include/femasr_hip.h']
+SO = os.path.join(HERE, 'libfemasr_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+         '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result']
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(HERE, src.replace('.hip', '.o'))
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(SO, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', SO] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,35 @@
+// common.h — internal declarations shared by the .hip translation units of libfemasr_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/femasr_hip.h"
+
+// thread-local error message plumbing (model.hip)
+int femasr_set_error(int code, const char *fmt, ...);
+#define FEMASR_CHECK_HIP(expr)                                                            \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return femasr_set_error(FEMASR_ERR_HIP, "%s failed: %s (%s:%d)", #expr,       \
+                                    hipGetErrorString(_e), __FILE__, __LINE__);           \
+    } while (0)
+#define FEMASR_REQUIRE(cond, ...)                                                         \
+    do {                                                                                  \
+        if (!(cond)) return femasr_set_error(FEMASR_ERR_INVALID, __VA_ARGS__);            \
+    } while (0)
+
+// conv launcher with the VQ-argmin epilogue option (kernels_conv.hip)
+//   vq_part != nullptr : instead of storing the tile, each block writes, per row, the
+//   first-min (distance, column) over its BN columns of d = (vq_zz[row] + vq_ee[col]) - 2*acc
+//   to vq_part[(row*vq_nblk + nblock)*2 + {0,1}] (column stored as a float-bit-cast int).
+struct conv_vq_epilogue {
+    const float *zz;
+    const float *ee;
+    float *part;
+    int nblk;
+};
+int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_epilogue *vq,
+                         int *variant_out, double *flops_out);
+int femasr_conv_variant_count();
+const char *femasr_conv_variant_name(int v);

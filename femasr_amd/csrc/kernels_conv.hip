@@ -1,0 +1,407 @@
+// kernels_conv.hip — NHWC implicit-GEMM convolution / linear on the gfx950 fp32 matrix cores.
+//
+// One kernel family covers every dense contraction of the hot path:
+//   nn.Conv2d k1/k3/k4, stride 1/2, zero padding      femasr_arch.py:150,159,173,203,273,298;
+//                                                     fema_utils.py:75,78,90; network_swinir.py:465
+//   nn.Upsample(scale_factor=2) fused into the loader femasr_arch.py:172,202
+//   nn.Linear (ksz=1 on a (1,rows,1,Cin) tensor)      network_swinir.py:19-21,105-112
+//   GroupNorm-apply + SiLU on load (PRO_GN)           fema_utils.py:72-79
+//   LayerNorm-apply on load (PRO_LN)                  network_swinir.py:243,277
+//   bias, GELU(erf), up to two residual adds on store fema_utils.py:82-83; network_swinir.py:276-277,482;
+//                                                     femasr_arch.py:361-362
+//   VQ distance + per-tile first-min argmin epilogue  femasr_arch.py:35-38,63-66
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = ksz*ksz*Cin in (ky,kx,cin) order.
+// Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32, and per output element ONE k-ascending fmaf
+// chain, which is the order the oracle specifies, so results are bit-identical to it.  That
+// fixes the schedule: no split-K, one accumulator per output, K walked in ascending order.
+//
+// Tiling: 256 threads = 4 waves (one per SIMD), block tile BM x BN, BK = 32.
+//   A tile (BM x 32) staged global -> registers -> (prologue math) -> LDS [m][33] (pad: conflict-free
+//   ds_read_b32 of the MFMA A fragment A[i=lane&31][k=lane>>5] AND conflict-free scattered stores);
+//   B tile (32 x BN) = weights [k][n], stored as loaded ([k][n], ds_write_b128), fragment reads of
+//   B[k=lane>>5][j=lane&31] hit 32 consecutive banks.
+//   Double-buffered LDS, one __syncthreads per K-chunk: loads of chunk c+1 are issued before the
+//   16 k-pair MFMA steps of chunk c and written to the other buffer after them.
+//   fp32 MFMA is 64 cycles/instruction/SIMD, so LDS and the VALU prologue run in its shadow.
+// Grid: 1-D over (m-block, n-block), n fastest, with the bijective XCD remap so that the blocks
+//   sharing an A tile / neighbouring halo rows land on the same XCD's L2.
+#include "common.h"
+#include "detmath.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct ConvParams {
+    const float *in, *w, *bias, *pro_a, *pro_b, *pro_c, *res1, *res2;
+    float *out;
+    const float *vq_zz, *vq_ee;
+    float *vq_part;
+    int vq_nblk;
+    int B, H, W, Cin, Cout, ksz, stride, pad, up2, act, Ho, Wo;
+    int M, K, nchunks, cpt, MB, NB;
+};
+
+constexpr int BK = 32;
+constexpr int ALD = BK + 1;
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
+{
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int AROWS = BM / 32;               // A float4 units per thread
+    constexpr int BUNITS = (BK * BN / 4) / 256;  // B float4 units per thread
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BUNITS >= 1, "tile config");
+    static_assert(CINVEC || PRO == FEMASR_PRO_NONE, "generic-Cin path has no prologue");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                  // [2][BM][ALD]
+    float *Bs = smem + 2 * BM * ALD;   // [2][BK][BN]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- XCD-aware, bijective block -> tile remap (block b runs on XCD b % 8)
+    int L;
+    {
+        const int nblk = p.MB * p.NB, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int nb = L % p.NB, mb = L / p.NB;
+    const int m0 = mb * BM, n0 = nb * BN;
+
+    // ---- per-thread A rows: (mrow + 32 j, k-quad kq)
+    const int kq = t & 7, mrow = t >> 3;
+    int rn[AROWS], riy[AROWS], rix[AROWS];
+    float lmean[AROWS], lrstd[AROWS];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j) {
+        const int r = m0 + mrow + 32 * j;
+        if (r < p.M) {
+            const int n = r / HoWo, rem = r - n * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            rn[j] = n;
+            riy[j] = oy * p.stride - p.pad;
+            rix[j] = ox * p.stride - p.pad;
+            if (PRO == FEMASR_PRO_LN) {
+                lmean[j] = p.pro_a[2 * (size_t)r];
+                lrstd[j] = p.pro_a[2 * (size_t)r + 1];
+            }
+        } else {
+            rn[j] = 0;
+            riy[j] = -(1 << 28);
+            rix[j] = -(1 << 28);
+            if (PRO == FEMASR_PRO_LN) { lmean[j] = 0.f; lrstd[j] = 0.f; }
+        }
+    }
+    const int Hv = p.up2 ? 2 * p.H : p.H, Wv = p.up2 ? 2 * p.W : p.W;
+    const bool wvec = (p.Cout & 3) == 0;
+
+    float4 ra[AROWS], rga[AROWS], rgb[AROWS], rb[BUNITS];
+    float4 lng, lnb;
+    unsigned amask = 0;
+
+    // ---- global -> register staging of K-chunk c
+    auto load_chunk = [&](int c) {
+        amask = 0;
+        if (CINVEC) {
+            const int tap = c / p.cpt, c0 = (c - tap * p.cpt) * BK + 4 * kq;
+            const int ky = tap / p.ksz, kx = tap - ky * p.ksz;
+#pragma unroll
+            for (int j = 0; j < AROWS; ++j) {
+                const int iy = riy[j] + ky, ix = rix[j] + kx;
+                const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
+                if (ok) {
+                    const int sy = p.up2 ? (iy >> 1) : iy, sx = p.up2 ? (ix >> 1) : ix;
+                    const size_t off = (((size_t)rn[j] * p.H + sy) * p.W + sx) * p.Cin + c0;
+                    ra[j] = ld4(p.in + off);
+                    if (PRO == FEMASR_PRO_GN_SILU) {
+                        rga[j] = ld4(p.pro_a + (size_t)rn[j] * p.Cin + c0);
+                        rgb[j] = ld4(p.pro_b + (size_t)rn[j] * p.Cin + c0);
+                    }
+                    amask |= 1u << j;
+                }
+            }
+            if (PRO == FEMASR_PRO_LN) {
+                lng = ld4(p.pro_b + c0);
+                lnb = ld4(p.pro_c + c0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < AROWS; ++j) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = c * BK + 4 * kq + e;
+                    v[e] = 0.f;
+                    if (k < p.K) {
+                        const int tap = k / p.Cin, ci = k - tap * p.Cin;
+                        const int ky = tap / p.ksz, kx = tap - ky * p.ksz;
+                        const int iy = riy[j] + ky, ix = rix[j] + kx;
+                        if ((iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv)) {
+                            const int sy = p.up2 ? (iy >> 1) : iy, sx = p.up2 ? (ix >> 1) : ix;
+                            v[e] = p.in[(((size_t)rn[j] * p.H + sy) * p.W + sx) * p.Cin + ci];
+                        }
+                    }
+                }
+                ra[j] = make_float4(v[0], v[1], v[2], v[3]);
+                amask |= 1u << j;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BUNITS; ++u) {
+            const int unit = t + 256 * u;
+            const int nq = unit % (BN / 4), kr = unit / (BN / 4);
+            const int k = c * BK + kr, n = n0 + 4 * nq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < p.K) {
+                const float *wp = p.w + (size_t)k * p.Cout + n;
+                if (wvec) {
+                    if (n < p.Cout) v = ld4(wp);
+                } else {
+                    if (n + 0 < p.Cout) v.x = wp[0];
+                    if (n + 1 < p.Cout) v.y = wp[1];
+                    if (n + 2 < p.Cout) v.z = wp[2];
+                    if (n + 3 < p.Cout) v.w = wp[3];
+                }
+            }
+            rb[u] = v;
+        }
+    };
+
+    // ---- registers -> LDS (with the fused normalisation / activation prologue)
+    auto store_chunk = [&](int buf) {
+        float *Ab = As + buf * BM * ALD;
+        float *Bb = Bs + buf * BK * BN;
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (amask & (1u << j)) {
+                v = ra[j];
+                if (PRO == FEMASR_PRO_GN_SILU) {
+                    v.x = det_silu(__builtin_fmaf(v.x, rga[j].x, rgb[j].x));
+                    v.y = det_silu(__builtin_fmaf(v.y, rga[j].y, rgb[j].y));
+                    v.z = det_silu(__builtin_fmaf(v.z, rga[j].z, rgb[j].z));
+                    v.w = det_silu(__builtin_fmaf(v.w, rga[j].w, rgb[j].w));
+                } else if (PRO == FEMASR_PRO_LN) {
+                    v.x = __builtin_fmaf((v.x - lmean[j]) * lrstd[j], lng.x, lnb.x);
+                    v.y = __builtin_fmaf((v.y - lmean[j]) * lrstd[j], lng.y, lnb.y);
+                    v.z = __builtin_fmaf((v.z - lmean[j]) * lrstd[j], lng.z, lnb.z);
+                    v.w = __builtin_fmaf((v.w - lmean[j]) * lrstd[j], lng.w, lnb.w);
+                }
+            }
+            float *dst = Ab + (mrow + 32 * j) * ALD + 4 * kq;
+            dst[0] = v.x;
+            dst[1] = v.y;
+            dst[2] = v.z;
+            dst[3] = v.w;
+        }
+#pragma unroll
+        for (int u = 0; u < BUNITS; ++u) {
+            const int unit = t + 256 * u;
+            const int nq = unit % (BN / 4), kr = unit / (BN / 4);
+            *reinterpret_cast<float4 *>(Bb + kr * BN + 4 * nq) = rb[u];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    const int arow = (wm * TM * 32 + (lane & 31)) * ALD + (lane >> 5);
+    const int bcol = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+
+    for (int c = 0; c < p.nchunks; ++c) {
+        const int buf = c & 1;
+        const bool more = (c + 1) < p.nchunks;
+        if (more) load_chunk(c + 1);
+        const float *Ab = As + buf * BM * ALD + arow;
+        const float *Bb = Bs + buf * BK * BN + bcol;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[i * 32 * ALD + 2 * kk];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bb[2 * kk * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (!VQ) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+                const float bv = col < p.Cout ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < p.M && col < p.Cout) {
+                        float v = acc[i][j][r] + bv;
+                        if (p.act == FEMASR_ACT_GELU) v = det_gelu(v);
+                        const size_t o = (size_t)row * p.Cout + col;
+                        if (p.res1) v = v + p.res1[o];
+                        if (p.res2) v = v + p.res2[o];
+                        p.out[o] = v;
+                    }
+                }
+            }
+    } else {
+        // d = (|z|^2 + |e|^2) - 2 z.e ; first-min over this block's BN columns, per row.
+        float *red = smem;   // [WN][BM][2]  (A/B buffers are dead after the loop's last barrier)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowl = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = m0 + rowl;
+                const float zz = row < p.M ? p.vq_zz[row] : 0.f;
+                float bd = INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+                    if (col < p.Cout) {
+                        const float d = (zz + p.vq_ee[col]) - 2.0f * acc[i][j][r];
+                        if (d < bd || (d == bd && col < bi)) { bd = d; bi = col; }
+                    }
+                }
+#pragma unroll
+                for (int s = 16; s >= 1; s >>= 1) {
+                    const float od = __shfl_xor(bd, s, 64);
+                    const int oi = __shfl_xor(bi, s, 64);
+                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                }
+                if ((lane & 31) == 0) {
+                    red[(wn * BM + rowl) * 2] = bd;
+                    red[(wn * BM + rowl) * 2 + 1] = __int_as_float(bi);
+                }
+            }
+        __syncthreads();
+        if (t < BM && m0 + t < p.M) {
+            float bd = red[t * 2];
+            int bi = __float_as_int(red[t * 2 + 1]);
+#pragma unroll
+            for (int w2 = 1; w2 < WN; ++w2) {
+                const float od = red[(w2 * BM + t) * 2];
+                const int oi = __float_as_int(red[(w2 * BM + t) * 2 + 1]);
+                if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+            }
+            float *dst = p.vq_part + ((size_t)(m0 + t) * p.vq_nblk + nb) * 2;
+            dst[0] = bd;
+            dst[1] = __int_as_float(bi);
+        }
+    }
+}
+
+template <int BM, int BN>
+constexpr size_t conv_lds_bytes() { return (size_t)(2 * BM * ALD + 2 * BK * BN) * sizeof(float); }
+
+struct Variant {
+    const char *name;
+    int bm, bn;
+    void (*kern)(const ConvParams);
+    size_t lds;
+    bool attr_set;
+};
+
+#define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ)                                                   \
+    { "conv_igemm<" #BM "x" #BN "," #PRO "," #VEC "," #VQ ">", BM, BN,                                 \
+      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ>, conv_lds_bytes<BM, BN>(), false }
+
+Variant g_variants[] = {
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, false),     // 0
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_GN_SILU, true, false),  // 1
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_LN, true, false),       // 2
+    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, true, false),      // 3
+    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_GN_SILU, true, false),   // 4
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false),      // 5
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_GN_SILU, true, false),   // 6
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, false, false),    // 7  generic Cin (in_conv)
+    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, false, false),     // 8
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, true),      // 9  VQ distance + argmin
+    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_LN, true, false),        // 10
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false),        // 11
+};
+constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
+
+int pick_variant(const femasr_conv_args *a, bool vq)
+{
+    const bool vec = (a->Cin % BK) == 0;
+    if (vq) return 9;
+    if (!vec) return a->Cout > 64 ? 7 : 8;
+    const int cls = a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2);
+    static const int table[3][3] = {{0, 1, 2}, {3, 4, 10}, {5, 6, 11}};
+    return table[cls][a->prologue];
+}
+
+}  // namespace
+
+int femasr_conv_variant_count() { return kNumVariants; }
+const char *femasr_conv_variant_name(int v) { return (v >= 0 && v < kNumVariants) ? g_variants[v].name : "?"; }
+
+int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_epilogue *vq,
+                         int *variant_out, double *flops_out)
+{
+    FEMASR_REQUIRE(a && a->in && a->w && a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0,
+                   "conv2d: null pointer or empty shape");
+    FEMASR_REQUIRE(vq || (a->bias && a->out), "conv2d: bias/out must be set");
+    FEMASR_REQUIRE(a->ksz >= 1 && a->ksz <= 7 && (a->stride == 1 || a->stride == 2) && a->pad >= 0,
+                   "conv2d: unsupported ksz=%d stride=%d pad=%d", a->ksz, a->stride, a->pad);
+    FEMASR_REQUIRE(a->prologue >= 0 && a->prologue <= 2, "conv2d: bad prologue %d", a->prologue);
+    const int Hv = a->up2 ? 2 * a->H : a->H, Wv = a->up2 ? 2 * a->W : a->W;
+    const int Ho = (Hv + 2 * a->pad - a->ksz) / a->stride + 1, Wo = (Wv + 2 * a->pad - a->ksz) / a->stride + 1;
+    FEMASR_REQUIRE(Ho == a->Ho && Wo == a->Wo, "conv2d: Ho/Wo mismatch (%d,%d) vs expected (%d,%d)", a->Ho, a->Wo, Ho, Wo);
+    const bool vec = (a->Cin % BK) == 0;
+    FEMASR_REQUIRE(vec || a->prologue == FEMASR_PRO_NONE, "conv2d: prologue needs Cin %% 32 == 0 (Cin=%d)", a->Cin);
+    if (a->prologue == FEMASR_PRO_GN_SILU) FEMASR_REQUIRE(a->pro_a && a->pro_b, "conv2d: GN prologue needs a,b");
+    if (a->prologue == FEMASR_PRO_LN) FEMASR_REQUIRE(a->pro_a && a->pro_b && a->pro_c, "conv2d: LN prologue needs stats,gamma,beta");
+    const long long M = (long long)a->B * Ho * Wo;
+    FEMASR_REQUIRE(M < (1ll << 31) - 256, "conv2d: too many output pixels");
+
+    ConvParams p{};
+    p.in = a->in; p.w = a->w; p.bias = a->bias; p.pro_a = a->pro_a; p.pro_b = a->pro_b; p.pro_c = a->pro_c;
+    p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.ksz = a->ksz; p.stride = a->stride;
+    p.pad = a->pad; p.up2 = a->up2; p.act = a->act; p.Ho = Ho; p.Wo = Wo;
+    p.M = (int)M; p.K = a->ksz * a->ksz * a->Cin; p.nchunks = (p.K + BK - 1) / BK; p.cpt = vec ? a->Cin / BK : 1;
+    const int vi = pick_variant(a, vq != nullptr);
+    Variant &v = g_variants[vi];
+    p.MB = (p.M + v.bm - 1) / v.bm;
+    p.NB = (p.Cout + v.bn - 1) / v.bn;
+    if (vq) {
+        FEMASR_REQUIRE(vq->zz && vq->ee && vq->part && vq->nblk == p.NB && (a->Cout % 32) == 0, "vq epilogue: bad args");
+        p.vq_zz = vq->zz; p.vq_ee = vq->ee; p.vq_part = vq->part; p.vq_nblk = vq->nblk;
+    }
+    if (!v.attr_set) {
+        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+        v.attr_set = true;
+    }
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(256), v.lds, s, p);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    if (variant_out) *variant_out = vi;
+    if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K;
+    return FEMASR_OK;
+}

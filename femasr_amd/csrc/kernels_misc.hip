@@ -1,0 +1,492 @@
+// kernels_misc.hip — the HBM-bound / small kernels of the hot path (everything that is not a
+// dense contraction): layout+pad, crop, GroupNorm moments, LayerNorm moments, 8x8 window
+// attention, VQ row norms / argmin finalize / gather, weight repack.
+// Reduction orders follow DESIGN.md "Arithmetic specification" (== the oracle's), so every
+// kernel here is bit-reproducible and bit-identical to the CPU restatement.
+#include "common.h"
+#include "detmath.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// ------------------------------------------------------------------------------------------
+// pad / crop (femasr_arch.py:454-465)
+// ------------------------------------------------------------------------------------------
+// one thread per output element of NHWC (B,Hp,Wp,C); mirror: padded row H+i <- row H-1-i.
+__global__ void pad_nchw_to_nhwc_kernel(const float *__restrict__ in, int B, int C, int H, int W, int Hp, int Wp,
+                                        float *__restrict__ out, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % Wp);
+        r /= Wp;
+        const int y = (int)(r % Hp);
+        const int n = (int)(r / Hp);
+        const int sy = y < H ? y : 2 * H - 1 - y, sx = x < W ? x : 2 * W - 1 - x;
+        out[i] = in[(((size_t)n * C + c) * H + sy) * W + sx];
+    }
+}
+
+// one thread per output element of NCHW (B,C,Hc,Wc)
+__global__ void crop_nhwc_to_nchw_kernel(const float *__restrict__ in, int B, int Hs, int Ws, int C, int Hc, int Wc,
+                                         float *__restrict__ out, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wc);
+        size_t r = i / Wc;
+        const int y = (int)(r % Hc);
+        r /= Hc;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        out[i] = in[(((size_t)n * Hs + y) * Ws + x) * C + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm moments (fema_utils.py:22), two fixed-order fp64 levels
+// ------------------------------------------------------------------------------------------
+// level 1: thread (n, y, g) sums row y of group g: x ascending, channel-in-group ascending.
+template <int CG>
+__global__ void gn_rows_kernel(const float *__restrict__ x, int B, int H, int W, int C, int G, double *__restrict__ part)
+{
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * H * G;
+    if (tid >= total) return;
+    const int g = (int)(tid % G);
+    const size_t ny = tid / G;   // n*H + y
+    const float *row = x + ny * (size_t)W * C + g * CG;
+    double s = 0.0, ss = 0.0;
+    for (int xx = 0; xx < W; ++xx) {
+        float v[CG];
+        if constexpr (CG == 8) {
+            const float4 a = ld4(row + (size_t)xx * C), b = ld4(row + (size_t)xx * C + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else if constexpr (CG == 4) {
+            const float4 a = ld4(row + (size_t)xx * C);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < CG; ++j) v[j] = row[(size_t)xx * C + j];
+        }
+#pragma unroll
+        for (int j = 0; j < CG; ++j) {
+            const double d = (double)v[j];
+            s = s + d;
+            ss = ss + d * d;
+        }
+    }
+    part[tid * 2] = s;
+    part[tid * 2 + 1] = ss;
+}
+
+// generic channel-per-group fallback (runtime cg)
+__global__ void gn_rows_generic_kernel(const float *__restrict__ x, int B, int H, int W, int C, int G, int cg,
+                                       double *__restrict__ part)
+{
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * H * G;
+    if (tid >= total) return;
+    const int g = (int)(tid % G);
+    const size_t ny = tid / G;
+    const float *row = x + ny * (size_t)W * C + g * cg;
+    double s = 0.0, ss = 0.0;
+    for (int xx = 0; xx < W; ++xx)
+        for (int j = 0; j < cg; ++j) {
+            const double d = (double)row[(size_t)xx * C + j];
+            s = s + d;
+            ss = ss + d * d;
+        }
+    part[tid * 2] = s;
+    part[tid * 2 + 1] = ss;
+}
+
+// level 2: thread (n, g) sums rows y ascending, then folds into a[n,c], b[n,c].
+__global__ void gn_finalize_kernel(const double *__restrict__ part, int B, int H, int W, int C, int G,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                   float *__restrict__ a, float *__restrict__ b)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= B * G) return;
+    const int n = tid / G, g = tid % G, cg = C / G;
+    double S = 0.0, SS = 0.0;
+    for (int y = 0; y < H; ++y) {
+        const size_t o = (((size_t)n * H + y) * G + g) * 2;
+        S = S + part[o];
+        SS = SS + part[o + 1];
+    }
+    const double N = (double)H * (double)W * (double)cg;
+    const double mean = S / N;
+    double var = SS / N - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = 1.0f / sqrtf((float)var + eps);
+    const float meanf = (float)mean;
+    for (int j = 0; j < cg; ++j) {
+        const int c = g * cg + j;
+        const float ac = rstd * gamma[c];
+        a[n * C + c] = ac;
+        b[n * C + c] = __builtin_fmaf(-meanf, ac, beta[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm moments (network_swinir.py:199,205): one wave per row of C = 64*PER floats
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_tree_sum(float p)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) p = p + __shfl_xor(p, s, 64);
+    return p;
+}
+
+__global__ void ln_stats_kernel(const float *__restrict__ x, long long rows, float eps, float *__restrict__ stats)
+{
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4 v = ld4(x + row * 256 + lane * 4);
+    float s = v.x;
+    s = s + v.y;
+    s = s + v.z;
+    s = s + v.w;
+    const float mean = wave_tree_sum(s) * (1.0f / 256.0f);
+    float d = v.x - mean;
+    float q = d * d;
+    d = v.y - mean;
+    q = __builtin_fmaf(d, d, q);
+    d = v.z - mean;
+    q = __builtin_fmaf(d, d, q);
+    d = v.w - mean;
+    q = __builtin_fmaf(d, d, q);
+    const float var = wave_tree_sum(q) * (1.0f / 256.0f);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = 1.0f / sqrtf(var + eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 8x8 (shifted-)window attention (network_swinir.py:114-145,216-237,249-272)
+// ------------------------------------------------------------------------------------------
+// One wave per (batch, window, head); lane i owns query row i.  K and V of the head (64 x 32
+// each) are staged in LDS with a 36-float row pitch (conflict-free b128 stores, broadcast b128
+// reads).  Roll / window partition / reverse are index math; the shift mask is the analytic
+// label test; softmax and both products follow the oracle's sequential orders.
+constexpr int ATT_HD = 32, ATT_N = 64, ATT_LD = 36;
+
+__global__ __launch_bounds__(64) void window_attention_kernel(const float *__restrict__ qkv, int B, int H, int W, int C,
+                                                              int heads, int shift, const float *__restrict__ table,
+                                                              float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_N * ATT_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_N * ATT_LD];
+    __shared__ float Ts[225];
+    __shared__ int Ls[ATT_N];
+
+    const int lane = threadIdx.x;
+    const int nwx = W >> 3, nwy = H >> 3;
+    int bid = blockIdx.x;
+    const int h = bid % heads;
+    bid /= heads;
+    const int wx = bid % nwx;
+    bid /= nwx;
+    const int wy = bid % nwy;
+    const int n = bid / nwy;
+
+    const int iy = lane >> 3, ix = lane & 7;
+    const int ys = wy * 8 + iy, xs = wx * 8 + ix;
+    int y = ys + shift, x = xs + shift;
+    if (y >= H) y -= H;
+    if (x >= W) x -= W;
+    const size_t tok = (size_t)n * H * W + (size_t)y * W + x;
+    const int ry = ys < H - 8 ? 0 : (ys < H - shift ? 1 : 2);
+    const int rx = xs < W - 8 ? 0 : (xs < W - shift ? 1 : 2);
+    const int mylab = 3 * ry + rx;
+    Ls[lane] = mylab;
+    for (int i = lane; i < 225; i += 64) Ts[i] = table[i * heads + h];
+
+    const float *base = qkv + tok * 3 * C + h * ATT_HD;
+    const float scale = 0.17677669529663687f;   // (float)(32 ** -0.5)
+    float q[ATT_HD];
+#pragma unroll
+    for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
+        const float4 qv = ld4(base + 4 * d4);
+        q[4 * d4 + 0] = qv.x * scale;
+        q[4 * d4 + 1] = qv.y * scale;
+        q[4 * d4 + 2] = qv.z * scale;
+        q[4 * d4 + 3] = qv.w * scale;
+        *reinterpret_cast<float4 *>(Ks + lane * ATT_LD + 4 * d4) = ld4(base + C + 4 * d4);
+        *reinterpret_cast<float4 *>(Vs + lane * ATT_LD + 4 * d4) = ld4(base + 2 * C + 4 * d4);
+    }
+    __syncthreads();
+
+    float s[ATT_N];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < ATT_N; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
+            const float4 kv = *reinterpret_cast<const float4 *>(Ks + j * ATT_LD + 4 * d4);
+            acc = __builtin_fmaf(q[4 * d4 + 0], kv.x, acc);
+            acc = __builtin_fmaf(q[4 * d4 + 1], kv.y, acc);
+            acc = __builtin_fmaf(q[4 * d4 + 2], kv.z, acc);
+            acc = __builtin_fmaf(q[4 * d4 + 3], kv.w, acc);
+        }
+        const int dy = iy - (j >> 3) + 7, dx = ix - (j & 7) + 7;
+        acc = acc + Ts[dy * 15 + dx];
+        if (shift > 0) acc = acc + (Ls[j] != mylab ? -100.0f : 0.0f);
+        s[j] = acc;
+        m = acc > m ? acc : m;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < ATT_N; ++j) {
+        s[j] = det_expf(s[j] - m);
+        sum = sum + s[j];
+    }
+    float o[ATT_HD];
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < ATT_N; ++j) {
+        const float pj = s[j] / sum;
+#pragma unroll
+        for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
+            const float4 vv = *reinterpret_cast<const float4 *>(Vs + j * ATT_LD + 4 * d4);
+            o[4 * d4 + 0] = __builtin_fmaf(pj, vv.x, o[4 * d4 + 0]);
+            o[4 * d4 + 1] = __builtin_fmaf(pj, vv.y, o[4 * d4 + 1]);
+            o[4 * d4 + 2] = __builtin_fmaf(pj, vv.z, o[4 * d4 + 2]);
+            o[4 * d4 + 3] = __builtin_fmaf(pj, vv.w, o[4 * d4 + 3]);
+        }
+    }
+    float *op = out + tok * C + h * ATT_HD;
+#pragma unroll
+    for (int d4 = 0; d4 < ATT_HD / 4; ++d4)
+        *reinterpret_cast<float4 *>(op + 4 * d4) = make_float4(o[4 * d4], o[4 * d4 + 1], o[4 * d4 + 2], o[4 * d4 + 3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// VQ helpers (femasr_arch.py:35-38,63-66,81-82,95,100,102-112)
+// ------------------------------------------------------------------------------------------
+// |row|^2 as ONE fmaf chain, c ascending; thread per row, float4 loads.
+__global__ void row_sqsum_kernel(const float *__restrict__ x, long long rows, int D, float *__restrict__ out)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float *p = x + r * D;
+    float acc = 0.f;
+    for (int c = 0; c < D; c += 4) {
+        const float4 v = ld4(p + c);
+        acc = __builtin_fmaf(v.x, v.x, acc);
+        acc = __builtin_fmaf(v.y, v.y, acc);
+        acc = __builtin_fmaf(v.z, v.z, acc);
+        acc = __builtin_fmaf(v.w, v.w, acc);
+    }
+    out[r] = acc;
+}
+
+// one wave per row: pick the first-min over the n-block partials (ascending block order),
+// write idx (int64) and z_q = z + (e[idx] - z).
+__global__ void vq_finalize_kernel(const float *__restrict__ z, long long M, int D, const float *__restrict__ cb,
+                                   const float *__restrict__ part, int nblk, long long *__restrict__ idx,
+                                   float *__restrict__ zq)
+{
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float *pp = part + (size_t)row * nblk * 2;
+    float bd = pp[0];
+    int bi = __float_as_int(pp[1]);
+    for (int b = 1; b < nblk; ++b) {
+        const float d = pp[2 * b];
+        const int i = __float_as_int(pp[2 * b + 1]);
+        if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+    }
+    if (lane == 0) idx[row] = (long long)bi;
+    const float *e = cb + (size_t)bi * D;
+    const float *zr = z + (size_t)row * D;
+    float *o = zq + (size_t)row * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 zv = ld4(zr + c), ev = ld4(e + c);
+        float4 r;
+        r.x = zv.x + (ev.x - zv.x);
+        r.y = zv.y + (ev.y - zv.y);
+        r.z = zv.z + (ev.z - zv.z);
+        r.w = zv.w + (ev.w - zv.w);
+        *reinterpret_cast<float4 *>(o + c) = r;
+    }
+}
+
+__global__ void codebook_gather_kernel(const long long *__restrict__ idx, long long M, int D, const float *__restrict__ cb,
+                                       int n_e, float *__restrict__ zq)
+{
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    long long i = idx[row];
+    i = i < 0 ? 0 : (i >= n_e ? n_e - 1 : i);
+    for (int c = lane * 4; c < D; c += 256)
+        *reinterpret_cast<float4 *>(zq + (size_t)row * D + c) = ld4(cb + (size_t)i * D + c);
+}
+
+// OIHW -> [kh][kw][I][O]; thread per OUTPUT element (coalesced stores)
+__global__ void repack_oihw_kernel(const float *__restrict__ in, int O, int I, int kh, int kw, float *__restrict__ out,
+                                   size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i % O);
+        size_t r = i / O;
+        const int ci = (int)(r % I);
+        r /= I;
+        const int x = (int)(r % kw);
+        const int y = (int)(r / kw);
+        out[i] = in[(((size_t)o * I + ci) * kh + y) * kw + x];
+    }
+}
+
+inline unsigned grid_for(size_t total, int block = 256)
+{
+    size_t g = (total + block - 1) / block;
+    const size_t cap = 256 * 16;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI (include/femasr_hip.h)
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int femasr_pad_nchw_to_nhwc(void *stream, const float *in, int B, int C, int H, int W, int Hp, int Wp, float *out)
+{
+    FEMASR_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0, "pad: bad args");
+    FEMASR_REQUIRE(Hp >= H && Wp >= W && Hp - H <= H && Wp - W <= W, "pad: mirror pad larger than the image (%d,%d)->(%d,%d)", H, W, Hp, Wp);
+    const size_t total = (size_t)B * Hp * Wp * C;
+    hipLaunchKernelGGL(pad_nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, B, C, H, W,
+                       Hp, Wp, out, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_crop_nhwc_to_nchw(void *stream, const float *in, int B, int Hs, int Ws, int C, int Hc, int Wc, float *out)
+{
+    FEMASR_REQUIRE(in && out && B > 0 && C > 0 && Hc > 0 && Wc > 0 && Hc <= Hs && Wc <= Ws, "crop: bad args");
+    const size_t total = (size_t)B * C * Hc * Wc;
+    hipLaunchKernelGGL(crop_nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, B, Hs, Ws,
+                       C, Hc, Wc, out, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_gn_coeffs(void *stream, const float *x, int B, int H, int W, int C, int G, const float *gamma,
+                     const float *beta, float eps, float *a, float *b, void *scratch)
+{
+    FEMASR_REQUIRE(x && gamma && beta && a && b && scratch, "gn_coeffs: null pointer");
+    FEMASR_REQUIRE(B > 0 && H > 0 && W > 0 && G > 0 && C % G == 0, "gn_coeffs: bad shape C=%d G=%d", C, G);
+    const int cg = C / G;
+    hipStream_t s = (hipStream_t)stream;
+    double *part = (double *)scratch;
+    const size_t total = (size_t)B * H * G;
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    if (cg == 8 && C % 4 == 0)
+        hipLaunchKernelGGL(gn_rows_kernel<8>, grid, blk, 0, s, x, B, H, W, C, G, part);
+    else if (cg == 4 && C % 4 == 0)
+        hipLaunchKernelGGL(gn_rows_kernel<4>, grid, blk, 0, s, x, B, H, W, C, G, part);
+    else if (cg == 2)
+        hipLaunchKernelGGL(gn_rows_kernel<2>, grid, blk, 0, s, x, B, H, W, C, G, part);
+    else
+        hipLaunchKernelGGL(gn_rows_generic_kernel, grid, blk, 0, s, x, B, H, W, C, G, cg, part);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((B * G + 63) / 64)), dim3(64), 0, s, part, B, H, W, C, G, gamma,
+                       beta, eps, a, b);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_ln_stats(void *stream, const float *x, int64_t rows, int C, float eps, float *stats)
+{
+    FEMASR_REQUIRE(x && stats && rows > 0, "ln_stats: bad args");
+    FEMASR_REQUIRE(C == 256, "ln_stats: only C == 256 (Swin embed_dim, femasr_arch.py:115) is built, got %d", C);
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)rows, eps, stats);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W, int C, int heads, int shift,
+                            const float *table, float *out)
+{
+    FEMASR_REQUIRE(qkv && table && out && B > 0, "window_attention: bad args");
+    FEMASR_REQUIRE(H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8, "window_attention: H,W must be multiples of 8 (%d,%d)", H, W);
+    FEMASR_REQUIRE(heads > 0 && C == heads * ATT_HD, "window_attention: head_dim must be 32 (C=%d heads=%d)", C, heads);
+    FEMASR_REQUIRE(shift >= 0 && shift < 8, "window_attention: bad shift %d", shift);
+    const unsigned grid = (unsigned)((size_t)B * (H / 8) * (W / 8) * heads);
+    hipLaunchKernelGGL(window_attention_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads, shift,
+                       table, out);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_row_sqsum(void *stream, const float *x, int64_t rows, int D, float *out)
+{
+    FEMASR_REQUIRE(x && out && rows > 0 && D > 0 && D % 4 == 0, "row_sqsum: bad args");
+    hipLaunchKernelGGL(row_sqsum_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, x,
+                       (long long)rows, D, out);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_vq(void *stream, const float *z, int64_t M, int D, const float *cb, const float *cbT, const float *ee,
+              int n_e, int64_t *idx, float *zq, void *scratch)
+{
+    FEMASR_REQUIRE(z && cb && cbT && ee && idx && zq && scratch && M > 0, "vq: bad args");
+    FEMASR_REQUIRE(D % 32 == 0 && n_e % 128 == 0, "vq: needs e_dim %% 32 == 0 and n_e %% 128 == 0 (D=%d n_e=%d)", D, n_e);
+    FEMASR_REQUIRE(M < (1ll << 31) - 256, "vq: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    float *zz = (float *)scratch;
+    float *part = zz + ((M + 63) / 64) * 64;
+    const int nblk = n_e / 128;
+    int rc = femasr_row_sqsum(stream, z, M, D, zz);
+    if (rc) return rc;
+    femasr_conv_args a{};
+    a.in = z; a.B = 1; a.H = (int)M; a.W = 1; a.Cin = D; a.w = cbT; a.bias = nullptr; a.Cout = n_e;
+    a.ksz = 1; a.stride = 1; a.pad = 0; a.up2 = 0; a.prologue = FEMASR_PRO_NONE; a.act = 0;
+    a.Ho = (int)M; a.Wo = 1;
+    conv_vq_epilogue ep{zz, ee, part, nblk};
+    rc = femasr_conv2d_launch(s, &a, &ep, nullptr, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, z, (long long)M, D, cb, part,
+                       nblk, (long long *)idx, zq);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, const float *cb, int n_e, float *zq)
+{
+    FEMASR_REQUIRE(idx && cb && zq && M > 0 && D % 4 == 0 && n_e > 0, "codebook_gather: bad args");
+    hipLaunchKernelGGL(codebook_gather_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)idx, (long long)M, D, cb, n_e, zq);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out)
+{
+    FEMASR_REQUIRE(in && out && O > 0 && I > 0 && kh > 0 && kw > 0, "repack: bad args");
+    const size_t total = (size_t)O * I * kh * kw;
+    hipLaunchKernelGGL(repack_oihw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, O, I, kh, kw, out,
+                       total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_conv2d(void *stream, const femasr_conv_args *a)
+{
+    return femasr_conv2d_launch((hipStream_t)stream, a, nullptr, nullptr, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,775 @@
+// model.hip — host side of libfemasr_hip.so: the model handle (weights by state-dict key),
+// the workspace planner and the launch schedule of the whole hot path.
+//
+// Mirrors, op for op, what the reference executes for one call of
+//   FeMaSRNet.test / .forward      basicsr/archs/femasr_arch.py:449-479
+//   FeMaSRNet.encode_and_decode    femasr_arch.py:311-374
+//   MultiScaleEncoder.forward      femasr_arch.py:184-192 (block list built at :150-180)
+//   SwinLayers / RSTB / SwinTransformerBlock   femasr_arch.py:114-132; network_swinir.py:442-482,239-279
+//   DecoderBlock x3 + out_conv     femasr_arch.py:195-211,267-273,366-369
+//   FeMaSRNet.decode_indices       femasr_arch.py:376-385
+// but on NHWC activations, with every elementwise / normalisation op folded into the
+// neighbouring implicit-GEMM launch (see kernels_conv.hip) — about 300 launches per forward,
+// all on the caller's stream, no host synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+int femasr_set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
+int channels_at(int res)   // femasr_arch.py:244-252
+{
+    switch (res) {
+    case 8: case 16: case 32: case 64: return 256;
+    case 128: return 128;
+    case 256: return 64;
+    case 512: return 32;
+    default: return -1;
+    }
+}
+
+int ilog2(int v)
+{
+    int r = 0;
+    while ((1 << (r + 1)) <= v) ++r;
+    return r;
+}
+
+enum WKind { W_CONV, W_LINEAR, W_VEC, W_TABLE, W_CODEBOOK };
+
+struct WSpec {
+    std::string key;
+    WKind kind;
+    int64_t shape[4];
+    int ndim;
+    float *dev = nullptr;   // repacked, owned
+    bool set = false;
+    size_t numel() const { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i]; return n; }
+};
+
+struct T {          // NHWC activation view
+    float *p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    size_t numel() const { return (size_t)B * H * W * C; }
+};
+
+// offsets-only first-fit arena over the caller's workspace (plan == execution order, so reuse of a
+// freed range by a later launch is safe under stream ordering).
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, peak = 0;
+    bool dry = true;
+    std::map<size_t, size_t> free_;   // offset -> size
+    std::map<size_t, size_t> used_;
+    void reset(void *b, size_t c, bool d)
+    {
+        base = d ? (char *)4096 : (char *)b; cap = c; dry = d; peak = 0;   // dry: fake non-null base, offsets only
+        free_.clear(); used_.clear();
+        free_[0] = d ? ((size_t)1 << 60) : c;
+    }
+    void *alloc(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        for (auto it = free_.begin(); it != free_.end(); ++it) {
+            if (it->second >= bytes) {
+                const size_t off = it->first, rest = it->second - bytes;
+                free_.erase(it);
+                if (rest) free_[off + bytes] = rest;
+                used_[off] = bytes;
+                peak = std::max(peak, off + bytes);
+                return base + off;
+            }
+        }
+        return nullptr;
+    }
+    void release(void *ptr)
+    {
+        const size_t off = (size_t)((char *)ptr - base);
+        auto it = used_.find(off);
+        if (it == used_.end()) return;
+        size_t sz = it->second, o = off;
+        used_.erase(it);
+        auto nx = free_.lower_bound(o);
+        if (nx != free_.end() && o + sz == nx->first) { sz += nx->second; nx = free_.erase(nx); }
+        if (nx != free_.begin()) {
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == o) { o = pv->first; sz += pv->second; free_.erase(pv); }
+        }
+        free_[o] = sz;
+    }
+};
+
+struct ProfRec { int slot; hipEvent_t e0, e1; double flops, bytes; };
+
+}  // namespace
+
+struct femasr_handle {
+    femasr_config cfg;
+    int scale = 1, max_depth = 0, encode_depth = 0;
+    std::vector<WSpec> specs;
+    std::map<std::string, int> index;
+    float *cbT = nullptr, *ee = nullptr;
+    bool finalized = false;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    std::vector<double> acc_ms, acc_flops, acc_bytes;
+    std::vector<int64_t> acc_n;
+    std::vector<std::string> slot_names;
+    // per-forward state
+    Arena arena;
+    hipStream_t stream = nullptr;
+    int status = 0;
+};
+
+namespace {
+
+enum { SLOT_GN = 0, SLOT_LN, SLOT_ATTN, SLOT_VQ, SLOT_LAYOUT, SLOT_SMALL_COUNT };
+const char *kSmallNames[SLOT_SMALL_COUNT] = {"gn_moments", "ln_moments", "window_attention", "vq(row_sqsum+distance_argmin+finalize)",
+                                             "pad/crop/gather layout"};
+
+struct Scope {   // event pair around one launch (or a small group of launches)
+    femasr_handle *h;
+    ProfRec rec{};
+    bool on;
+    Scope(femasr_handle *hh, int slot, double flops, double bytes) : h(hh), on(hh->prof && !hh->arena.dry)
+    {
+        if (!on) return;
+        auto get = [&]() {
+            if (h->pool_used == h->pool.size()) {
+                hipEvent_t e;
+                (void)hipEventCreate(&e);
+                h->pool.push_back(e);
+            }
+            return h->pool[h->pool_used++];
+        };
+        rec.slot = slot; rec.flops = flops; rec.bytes = bytes;
+        rec.e0 = get(); rec.e1 = get();
+        (void)hipEventRecord(rec.e0, h->stream);
+    }
+    void set_slot(int s) { rec.slot = s; }
+    void set_flops(double f) { rec.flops = f; }
+    ~Scope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(rec.e1, h->stream);
+        h->recs.push_back(rec);
+    }
+};
+
+void add_conv(femasr_handle *h, const std::string &p, int cin, int cout, int k)
+{
+    WSpec w; w.key = p + ".weight"; w.kind = W_CONV; w.ndim = 4;
+    w.shape[0] = cout; w.shape[1] = cin; w.shape[2] = k; w.shape[3] = k;
+    h->specs.push_back(w);
+    WSpec b; b.key = p + ".bias"; b.kind = W_VEC; b.ndim = 1; b.shape[0] = cout;
+    h->specs.push_back(b);
+}
+void add_linear(femasr_handle *h, const std::string &p, int cin, int cout)
+{
+    WSpec w; w.key = p + ".weight"; w.kind = W_LINEAR; w.ndim = 2; w.shape[0] = cout; w.shape[1] = cin;
+    h->specs.push_back(w);
+    WSpec b; b.key = p + ".bias"; b.kind = W_VEC; b.ndim = 1; b.shape[0] = cout;
+    h->specs.push_back(b);
+}
+void add_norm(femasr_handle *h, const std::string &p, int c)
+{
+    for (const char *leaf : {".weight", ".bias"}) {
+        WSpec w; w.key = p + leaf; w.kind = W_VEC; w.ndim = 1; w.shape[0] = c;
+        h->specs.push_back(w);
+    }
+}
+void add_resblock(femasr_handle *h, const std::string &p, int c)
+{
+    add_norm(h, p + ".conv.0.norm", c);
+    add_conv(h, p + ".conv.2", c, c, 3);
+    add_norm(h, p + ".conv.3.norm", c);
+    add_conv(h, p + ".conv.5", c, c, 3);
+}
+
+int build_specs(femasr_handle *h)
+{
+    const femasr_config &c = h->cfg;
+    const std::string enc = "multiscale_encoder";
+    int res = c.gt_resolution / h->scale;
+    FEMASR_REQUIRE(channels_at(res) > 0, "unsupported encoder input resolution %d", res);
+    add_conv(h, enc + ".in_conv", c.in_channel, channels_at(res), 4);
+    int bi = 0;
+    for (int i = 0; i < h->encode_depth; ++i, ++bi) {
+        const int ic = channels_at(res), oc = channels_at(res / 2);
+        FEMASR_REQUIRE(ic > 0 && oc > 0, "unsupported resolution %d", res);
+        const std::string p = enc + ".blocks." + std::to_string(bi);
+        add_conv(h, p + ".0", ic, oc, 3);
+        add_resblock(h, p + ".1", oc);
+        add_resblock(h, p + ".2", oc);
+        res /= 2;
+    }
+    if (c.lq_stage) {
+        FEMASR_REQUIRE(channels_at(res) == 256, "Swin stage needs 256 channels at res %d", res);
+        const std::string sp = enc + ".blocks." + std::to_string(bi++);
+        for (int r = 0; r < 4; ++r) {
+            const std::string rp = sp + ".swin_blks." + std::to_string(r);
+            for (int k = 0; k < 6; ++k) {
+                const std::string bp = rp + ".residual_group.blocks." + std::to_string(k);
+                add_norm(h, bp + ".norm1", 256);
+                WSpec tb; tb.key = bp + ".attn.relative_position_bias_table"; tb.kind = W_TABLE; tb.ndim = 2;
+                tb.shape[0] = 225; tb.shape[1] = 8;
+                h->specs.push_back(tb);
+                add_linear(h, bp + ".attn.qkv", 256, 768);
+                add_linear(h, bp + ".attn.proj", 256, 256);
+                add_norm(h, bp + ".norm2", 256);
+                add_linear(h, bp + ".mlp.fc1", 256, 1024);
+                add_linear(h, bp + ".mlp.fc2", 1024, 256);
+            }
+            add_conv(h, rp + ".conv", 256, 256, 3);
+        }
+        for (int u = 0; u < 2; ++u, ++bi) {
+            const int ic = channels_at(res), oc = channels_at(res * 2);
+            const std::string p = enc + ".blocks." + std::to_string(bi);
+            add_conv(h, p + ".1", ic, oc, 3);
+            add_resblock(h, p + ".2", oc);
+            add_resblock(h, p + ".3", oc);
+            res *= 2;
+        }
+    }
+    int out_ch = 0;
+    for (int i = 0; i < h->max_depth; ++i) {
+        const int r = c.gt_resolution / (1 << h->max_depth) * (1 << i);
+        const int ic = channels_at(r), oc = channels_at(r * 2);
+        FEMASR_REQUIRE(ic > 0 && oc > 0, "unsupported decoder resolution %d", r);
+        const std::string p = "decoder_group." + std::to_string(i) + ".block";
+        add_conv(h, p + ".1", ic, oc, 3);
+        add_resblock(h, p + ".2", oc);
+        add_resblock(h, p + ".3", oc);
+        out_ch = oc;
+    }
+    add_conv(h, "out_conv", out_ch, 3, 3);
+    WSpec cb; cb.key = "quantize_group.0.embedding.weight"; cb.kind = W_CODEBOOK; cb.ndim = 2;
+    cb.shape[0] = c.n_e; cb.shape[1] = c.e_dim;
+    h->specs.push_back(cb);
+    const int qc = channels_at(c.codebook_scale);
+    add_conv(h, "before_quant_group.0", qc, c.e_dim, 1);
+    add_conv(h, "after_quant_group.0.conv", c.e_dim, qc, 3);
+    for (size_t i = 0; i < h->specs.size(); ++i) h->index[h->specs[i].key] = (int)i;
+    return FEMASR_OK;
+}
+
+// ---------------------------------------------------------------- forward-time helpers
+struct Ctx {
+    femasr_handle *h;
+    int rc = 0;
+    bool dry() const { return h->arena.dry; }
+    hipStream_t s() const { return h->stream; }
+
+    const float *Wt(const std::string &key)
+    {
+        auto it = h->index.find(key);
+        if (it == h->index.end()) { if (!rc) rc = femasr_set_error(FEMASR_ERR_WEIGHT, "internal: unknown weight %s", key.c_str()); return nullptr; }
+        return h->specs[it->second].dev;
+    }
+    float *alloc_f(size_t n)
+    {
+        void *p = h->arena.alloc(n * sizeof(float));
+        if (!p && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small (need > %zu bytes)", h->arena.cap);
+        return (float *)p;
+    }
+    T alloc_t(int B, int H, int W, int C)
+    {
+        T t; t.B = B; t.H = H; t.W = W; t.C = C;
+        t.p = alloc_f(t.numel());
+        return t;
+    }
+    void release(void *p) { if (p) h->arena.release(p); }
+    void release(T &t) { release(t.p); t.p = nullptr; }
+
+    struct ConvOpt {
+        int ksz = 3, stride = 1, pad = 1, up2 = 0, act = 0;
+        int pro = FEMASR_PRO_NONE;
+        const float *pa = nullptr, *pb = nullptr, *pc = nullptr;
+        const float *res1 = nullptr, *res2 = nullptr;
+    };
+    T conv(const T &x, const std::string &prefix, int cout, const ConvOpt &o)
+    {
+        const int Hv = o.up2 ? 2 * x.H : x.H, Wv = o.up2 ? 2 * x.W : x.W;
+        const int Ho = (Hv + 2 * o.pad - o.ksz) / o.stride + 1, Wo = (Wv + 2 * o.pad - o.ksz) / o.stride + 1;
+        T y = alloc_t(x.B, Ho, Wo, cout);
+        if (rc || dry()) return y;
+        femasr_conv_args a{};
+        a.in = x.p; a.B = x.B; a.H = x.H; a.W = x.W; a.Cin = x.C;
+        a.w = Wt(prefix + ".weight"); a.bias = Wt(prefix + ".bias"); a.Cout = cout;
+        a.ksz = o.ksz; a.stride = o.stride; a.pad = o.pad; a.up2 = o.up2;
+        a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
+        a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
+        if (rc) return y;
+        Scope sc(h, 0, 0.0, 0.0);
+        int variant = 0; double flops = 0;
+        const int r = femasr_conv2d_launch(s(), &a, nullptr, &variant, &flops);
+        sc.set_slot(SLOT_SMALL_COUNT + variant);
+        sc.set_flops(flops);
+        if (r && !rc) rc = r;
+        return y;
+    }
+
+    // GroupNorm moments -> (a,b); returns a pointer pair inside one allocation
+    float *gn(const T &x, const std::string &norm_prefix)
+    {
+        float *ab = alloc_f((size_t)2 * x.B * x.C);
+        double *scratch = (double *)h->arena.alloc((size_t)x.B * x.H * 32 * 2 * sizeof(double));
+        if (!scratch && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
+        if (!rc && !dry()) {
+            Scope sc(h, SLOT_GN, 0.0, (double)x.numel() * 4.0);
+            const int r = femasr_gn_coeffs(s(), x.p, x.B, x.H, x.W, x.C, 32, Wt(norm_prefix + ".weight"), Wt(norm_prefix + ".bias"),
+                                           1e-6f, ab, ab + (size_t)x.B * x.C, scratch);
+            if (r && !rc) rc = r;
+        }
+        release(scratch);
+        return ab;
+    }
+
+    // fema_utils.py:65-84 (+ optional fused `x + enc_feats[i]`, femasr_arch.py:361-362)
+    T resblock(T x, const std::string &p, const float *res2, bool free_x)
+    {
+        const size_t bc = (size_t)x.B * x.C;
+        float *ab = gn(x, p + ".conv.0.norm");
+        ConvOpt o1; o1.pro = FEMASR_PRO_GN_SILU; o1.pa = ab; o1.pb = ab ? ab + bc : nullptr;
+        T u = conv(x, p + ".conv.2", x.C, o1);
+        release(ab);
+        float *ab2 = gn(u, p + ".conv.3.norm");
+        ConvOpt o2; o2.pro = FEMASR_PRO_GN_SILU; o2.pa = ab2; o2.pb = ab2 ? ab2 + bc : nullptr;
+        o2.res1 = x.p; o2.res2 = res2;
+        T y = conv(u, p + ".conv.5", x.C, o2);
+        release(ab2);
+        release(u);
+        if (free_x) release(x);
+        return y;
+    }
+
+    // network_swinir.py:239-279 on tokens (1, rows, 1, C)
+    T swin_block(const T &y, int B, int H, int W, const std::string &bp, int shift)
+    {
+        const int rows = B * H * W, C = 256;
+        float *stats = alloc_f((size_t)rows * 2);
+        auto ln = [&](const T &t) {
+            if (rc || dry()) return;
+            Scope sc(h, SLOT_LN, 0.0, (double)t.numel() * 4.0);
+            const int r = femasr_ln_stats(s(), t.p, rows, C, 1e-5f, stats);
+            if (r && !rc) rc = r;
+        };
+        ln(y);
+        ConvOpt oq; oq.ksz = 1; oq.pad = 0; oq.pro = FEMASR_PRO_LN; oq.pa = stats; oq.pb = Wt(bp + ".norm1.weight"); oq.pc = Wt(bp + ".norm1.bias");
+        T qkv = conv(y, bp + ".attn.qkv", 3 * C, oq);
+        T att = alloc_t(1, rows, 1, C);
+        if (!rc && !dry()) {
+            Scope sc(h, SLOT_ATTN, 4.0 * (double)rows * 64.0 * C, (double)rows * C * 16.0);
+            const int r = femasr_window_attention(s(), qkv.p, B, H, W, C, 8, shift, Wt(bp + ".attn.relative_position_bias_table"), att.p);
+            if (r && !rc) rc = r;
+        }
+        release(qkv);
+        ConvOpt op; op.ksz = 1; op.pad = 0; op.res1 = y.p;
+        T y1 = conv(att, bp + ".attn.proj", C, op);
+        release(att);
+        ln(y1);
+        ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.pro = FEMASR_PRO_LN; o1.pa = stats; o1.pb = Wt(bp + ".norm2.weight"); o1.pc = Wt(bp + ".norm2.bias");
+        o1.act = FEMASR_ACT_GELU;
+        T hdn = conv(y1, bp + ".mlp.fc1", 4 * C, o1);
+        ConvOpt o2; o2.ksz = 1; o2.pad = 0; o2.res1 = y1.p;
+        T y2 = conv(hdn, bp + ".mlp.fc2", C, o2);
+        release(hdn);
+        release(y1);
+        release(stats);
+        return y2;
+    }
+
+    // femasr_arch.py:114-132 + network_swinir.py:442-482; consumes x
+    T swin_layers(T x, const std::string &sp)
+    {
+        const int B = x.B, H = x.H, W = x.W, C = x.C;
+        for (int r = 0; r < 4; ++r) {
+            const std::string rp = sp + ".swin_blks." + std::to_string(r);
+            T y; y.p = x.p; y.B = 1; y.H = B * H * W; y.W = 1; y.C = C;
+            for (int k = 0; k < 6; ++k) {
+                T yn = swin_block(y, B, H, W, rp + ".residual_group.blocks." + std::to_string(k), (k & 1) ? 4 : 0);
+                if (y.p != x.p) release(y);
+                y = yn;
+            }
+            T yi; yi.p = y.p; yi.B = B; yi.H = H; yi.W = W; yi.C = C;
+            ConvOpt o; o.res1 = x.p;
+            T nx = conv(yi, rp + ".conv", C, o);
+            release(y);
+            release(x);
+            x = nx;
+        }
+        return x;
+    }
+
+    T up_block(const T &x, const std::string &p, int cout, const float *res2_last)   // Upsample x2 -> conv -> RB -> RB
+    {
+        ConvOpt o; o.up2 = 1;
+        T c = conv(x, p + ".1", cout, o);
+        T r1 = resblock(c, p + ".2", nullptr, true);
+        return resblock(r1, p + ".3", res2_last, true);
+    }
+};
+
+int run_decoder(Ctx &c, T x, T feats[3], bool fuse_skip, float *out_nchw, int crop_h, int crop_w)
+{
+    femasr_handle *h = c.h;
+    const femasr_config &cfg = h->cfg;
+    for (int i = 0; i < h->max_depth; ++i) {
+        const int r = cfg.gt_resolution / (1 << h->max_depth) * (1 << i);
+        const float *skip = (fuse_skip && i + 1 < h->max_depth) ? feats[i + 1].p : nullptr;
+        T y = c.up_block(x, "decoder_group." + std::to_string(i) + ".block", channels_at(r * 2), skip);
+        c.release(x);
+        if (skip) c.release(feats[i + 1]);
+        x = y;
+    }
+    Ctx::ConvOpt oo;
+    T img = c.conv(x, "out_conv", 3, oo);
+    c.release(x);
+    if (!c.rc && !c.dry()) {
+        Scope sc(h, SLOT_LAYOUT, 0.0, (double)img.B * 3.0 * crop_h * crop_w * 8.0);
+        const int r = femasr_crop_nhwc_to_nchw(c.s(), img.p, img.B, img.H, img.W, 3, crop_h, crop_w, out_nchw);
+        if (r && !c.rc) c.rc = r;
+    }
+    c.release(img);
+    return c.rc;
+}
+
+int run_forward(femasr_handle *h, const float *in_nchw, int B, int H, int W, int pad_mode, float *out_nchw, int64_t *indices)
+{
+    const femasr_config &cfg = h->cfg;
+    Ctx c{h};
+    int Hp = H, Wp = W;
+    if (pad_mode) {
+        const int wsz = 8 / h->scale * 8;
+        Hp = (H / wsz + 1) * wsz;
+        Wp = (W / wsz + 1) * wsz;
+        FEMASR_REQUIRE(Hp - H <= H && Wp - W <= W, "test(): image %dx%d smaller than its mirror pad", H, W);
+    }
+    const int down = 1 << h->encode_depth;   // total stride of the encoder's down path
+    FEMASR_REQUIRE(Hp >= 2 && Wp >= 2, "input too small");
+    // geometry checks: in_conv gives Hp-1; each stride-2 conv gives floor((h-1)/2)+1
+    int eh = Hp - 1, ew = Wp - 1;
+    for (int i = 0; i < h->encode_depth; ++i) { eh = (eh - 1) / 2 + 1; ew = (ew - 1) / 2 + 1; }
+    (void)down;
+    if (cfg.lq_stage) FEMASR_REQUIRE(eh % 8 == 0 && ew % 8 == 0, "Swin stage needs a feature map divisible by 8, got %dx%d", eh, ew);
+
+    T x0 = c.alloc_t(B, Hp, Wp, cfg.in_channel);
+    if (!c.rc && !c.dry()) {
+        Scope sc(h, SLOT_LAYOUT, 0.0, (double)x0.numel() * 8.0);
+        const int r = femasr_pad_nchw_to_nhwc(c.s(), in_nchw, B, cfg.in_channel, H, W, Hp, Wp, x0.p);
+        if (r) c.rc = r;
+    }
+    const std::string enc = "multiscale_encoder";
+    int res = cfg.gt_resolution / h->scale;
+    Ctx::ConvOpt oin; oin.ksz = 4; oin.pad = 1;
+    T t = c.conv(x0, enc + ".in_conv", channels_at(res), oin);
+    c.release(x0);
+    int bi = 0;
+    for (int i = 0; i < h->encode_depth; ++i, ++bi) {
+        const std::string p = enc + ".blocks." + std::to_string(bi);
+        Ctx::ConvOpt od; od.stride = 2;
+        T d = c.conv(t, p + ".0", channels_at(res / 2), od);
+        c.release(t);
+        t = c.resblock(d, p + ".1", nullptr, true);
+        t = c.resblock(t, p + ".2", nullptr, true);
+        res /= 2;
+    }
+    T feats[3];
+    if (cfg.lq_stage) {
+        t = c.swin_layers(t, enc + ".blocks." + std::to_string(bi++));
+        feats[0] = t;
+        for (int u = 0; u < 2; ++u, ++bi) {
+            feats[u + 1] = c.up_block(feats[u], enc + ".blocks." + std::to_string(bi), channels_at(res * 2), nullptr);
+            res *= 2;
+        }
+    } else {
+        feats[0] = t;
+    }
+    // quantise (femasr_arch.py:332-359)
+    Ctx::ConvOpt oq; oq.ksz = 1; oq.pad = 0;
+    T z = c.conv(feats[0], "before_quant_group.0", cfg.e_dim, oq);
+    c.release(feats[0]);
+    const int64_t M = (int64_t)z.B * z.H * z.W;
+    T zq = c.alloc_t(z.B, z.H, z.W, cfg.e_dim);
+    int64_t *idx_tmp = nullptr;
+    if (!indices) idx_tmp = (int64_t *)h->arena.alloc((size_t)M * 8);
+    {
+        const int nblk = cfg.n_e / 128;
+        float *scratch = c.alloc_f((size_t)M * nblk * 2 + M + 64);
+        if (!c.rc && !c.dry()) {
+            Scope sc(h, SLOT_VQ, 2.0 * (double)M * cfg.n_e * cfg.e_dim, (double)M * cfg.e_dim * 8.0 + (double)cfg.n_e * cfg.e_dim * 4.0 + M * 8.0);
+            const int r = femasr_vq(c.s(), z.p, M, cfg.e_dim, c.Wt("quantize_group.0.embedding.weight"), h->cbT, h->ee, cfg.n_e,
+                                    indices ? indices : idx_tmp, zq.p, scratch);
+            if (r && !c.rc) c.rc = r;
+        }
+        c.release(scratch);
+    }
+    if (idx_tmp) c.release(idx_tmp);
+    T q = cfg.use_quantize ? zq : z;
+    Ctx::ConvOpt oa;
+    T x = c.conv(q, "after_quant_group.0.conv", channels_at(cfg.codebook_scale), oa);
+    c.release(z);
+    c.release(zq);
+    const int s_out = pad_mode ? h->scale : 1;
+    const int crop_h = pad_mode ? H * s_out : 0, crop_w = pad_mode ? W * s_out : 0;
+    const int full_h = x.H << h->max_depth, full_w = x.W << h->max_depth;
+    return run_decoder(c, x, feats, cfg.lq_stage && cfg.use_residual, out_nchw, pad_mode ? crop_h : full_h, pad_mode ? crop_w : full_w);
+}
+
+int run_decode_indices(femasr_handle *h, const int64_t *indices, int B, int hq, int wq, float *out_nchw)
+{
+    const femasr_config &cfg = h->cfg;
+    Ctx c{h};
+    T zq = c.alloc_t(B, hq, wq, cfg.e_dim);
+    if (!c.rc && !c.dry()) {
+        Scope sc(h, SLOT_LAYOUT, 0.0, (double)zq.numel() * 8.0);
+        const int r = femasr_codebook_gather(c.s(), indices, (int64_t)B * hq * wq, cfg.e_dim, c.Wt("quantize_group.0.embedding.weight"), cfg.n_e, zq.p);
+        if (r) c.rc = r;
+    }
+    Ctx::ConvOpt oa;
+    T x = c.conv(zq, "after_quant_group.0.conv", channels_at(cfg.codebook_scale), oa);
+    c.release(zq);
+    T feats[3];
+    return run_decoder(c, x, feats, false, out_nchw, hq << h->max_depth, wq << h->max_depth);
+}
+
+int check_ready(const femasr_handle *h)
+{
+    FEMASR_REQUIRE(h, "null handle");
+    if (!h->finalized) return femasr_set_error(FEMASR_ERR_WEIGHT, "weights not finalized: call femasr_set_weight for every key, then femasr_finalize_weights");
+    return FEMASR_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *femasr_last_error(void) { return g_err; }
+int femasr_version(void) { return 100; }
+
+int femasr_create(const femasr_config *cfg, femasr_handle **out)
+{
+    FEMASR_REQUIRE(cfg && out, "create: null argument");
+    FEMASR_REQUIRE(cfg->in_channel == 3, "create: in_channel must be 3");
+    FEMASR_REQUIRE(cfg->n_e > 0 && cfg->n_e % 128 == 0 && cfg->e_dim > 0 && cfg->e_dim % 32 == 0, "create: codebook %dx%d unsupported (n_e %% 128, e_dim %% 32)", cfg->n_e, cfg->e_dim);
+    FEMASR_REQUIRE(cfg->codebook_scale > 0 && cfg->gt_resolution % cfg->codebook_scale == 0, "create: bad codebook scale");
+    femasr_handle *h = new femasr_handle();
+    h->cfg = *cfg;
+    h->scale = cfg->lq_stage ? cfg->scale_factor : 1;
+    if (!(h->scale == 1 || h->scale == 2 || h->scale == 4)) { delete h; return femasr_set_error(FEMASR_ERR_INVALID, "create: scale_factor %d unsupported", h->scale); }
+    h->max_depth = ilog2(cfg->gt_resolution / cfg->codebook_scale);
+    h->encode_depth = ilog2(cfg->gt_resolution / h->scale / cfg->codebook_scale);
+    if (h->max_depth < 1 || h->max_depth > 3) { delete h; return femasr_set_error(FEMASR_ERR_INVALID, "create: max_depth %d unsupported", h->max_depth); }
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { delete h; return femasr_set_error(FEMASR_ERR_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e)); }
+    const int rc = build_specs(h);
+    if (rc) { delete h; return rc; }
+    const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count();
+    h->acc_ms.assign(nslots, 0.0); h->acc_flops.assign(nslots, 0.0); h->acc_bytes.assign(nslots, 0.0); h->acc_n.assign(nslots, 0);
+    for (int i = 0; i < SLOT_SMALL_COUNT; ++i) h->slot_names.push_back(kSmallNames[i]);
+    for (int i = 0; i < femasr_conv_variant_count(); ++i) h->slot_names.push_back(femasr_conv_variant_name(i));
+    *out = h;
+    return FEMASR_OK;
+}
+
+void femasr_destroy(femasr_handle *h)
+{
+    if (!h) return;
+    for (auto &w : h->specs) if (w.dev) (void)hipFree(w.dev);
+    if (h->cbT) (void)hipFree(h->cbT);
+    if (h->ee) (void)hipFree(h->ee);
+    for (auto e : h->pool) (void)hipEventDestroy(e);
+    delete h;
+}
+
+int femasr_num_weights(const femasr_handle *h) { return h ? (int)h->specs.size() : 0; }
+
+int femasr_weight_info(const femasr_handle *h, int i, const char **key, int64_t shape[4], int *ndim)
+{
+    FEMASR_REQUIRE(h && i >= 0 && i < (int)h->specs.size(), "weight_info: bad index");
+    const WSpec &w = h->specs[i];
+    if (key) *key = w.key.c_str();
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = k < w.ndim ? w.shape[k] : 1;
+    if (ndim) *ndim = w.ndim;
+    return FEMASR_OK;
+}
+
+int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, const int64_t *shape, int ndim)
+{
+    FEMASR_REQUIRE(h && key && dev_ptr && shape, "set_weight: null argument");
+    const std::string k(key);
+    // buffers that live in checkpoints but are recomputed analytically
+    if (k.size() > 24 && (k.rfind(".relative_position_index") == k.size() - 24)) return FEMASR_OK;
+    if (k.size() > 10 && (k.rfind(".attn_mask") == k.size() - 10)) return FEMASR_OK;
+    auto it = h->index.find(k);
+    if (it == h->index.end()) return femasr_set_error(FEMASR_ERR_WEIGHT, "set_weight: unknown key '%s'", key);
+    WSpec &w = h->specs[it->second];
+    bool same = (ndim == w.ndim);
+    for (int i = 0; same && i < ndim; ++i) same = (shape[i] == w.shape[i]);
+    if (!same) return femasr_set_error(FEMASR_ERR_WEIGHT, "set_weight: shape mismatch for '%s'", key);
+    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
+    const size_t n = w.numel();
+    if (!w.dev) FEMASR_CHECK_HIP(hipMalloc((void **)&w.dev, n * sizeof(float)));
+    int rc = FEMASR_OK;
+    if (w.kind == W_CONV)
+        rc = femasr_repack_oihw(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], (int)w.shape[2], (int)w.shape[3], w.dev);
+    else if (w.kind == W_LINEAR)
+        rc = femasr_repack_oihw(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], 1, 1, w.dev);
+    else
+        FEMASR_CHECK_HIP(hipMemcpyAsync(w.dev, dev_ptr, n * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+    if (rc) return rc;
+    FEMASR_CHECK_HIP(hipStreamSynchronize(nullptr));
+    w.set = true;
+    h->finalized = false;
+    return FEMASR_OK;
+}
+
+int femasr_finalize_weights(femasr_handle *h)
+{
+    FEMASR_REQUIRE(h, "finalize: null handle");
+    for (const auto &w : h->specs)
+        if (!w.set) return femasr_set_error(FEMASR_ERR_WEIGHT, "finalize: weight '%s' was never set", w.key.c_str());
+    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
+    const int n_e = h->cfg.n_e, D = h->cfg.e_dim;
+    if (!h->cbT) FEMASR_CHECK_HIP(hipMalloc((void **)&h->cbT, (size_t)n_e * D * sizeof(float)));
+    if (!h->ee) FEMASR_CHECK_HIP(hipMalloc((void **)&h->ee, (size_t)n_e * sizeof(float)));
+    const float *cb = h->specs[h->index["quantize_group.0.embedding.weight"]].dev;
+    int rc = femasr_repack_oihw(nullptr, cb, n_e, D, 1, 1, h->cbT);     // [D][n_e]
+    if (rc) return rc;
+    rc = femasr_row_sqsum(nullptr, cb, n_e, D, h->ee);
+    if (rc) return rc;
+    FEMASR_CHECK_HIP(hipStreamSynchronize(nullptr));
+    h->finalized = true;
+    return FEMASR_OK;
+}
+
+int femasr_workspace_bytes(const femasr_handle *hc, int B, int H, int W, int pad_mode, size_t *bytes)
+{
+    femasr_handle *h = const_cast<femasr_handle *>(hc);
+    FEMASR_REQUIRE(h && bytes && B > 0 && H > 0 && W > 0, "workspace_bytes: bad args");
+    h->arena.reset(nullptr, 0, true);
+    const int rc = run_forward(h, nullptr, B, H, W, pad_mode, nullptr, nullptr);
+    if (rc) return rc;
+    *bytes = h->arena.peak + 256;
+    return FEMASR_OK;
+}
+
+int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, int H, int W, int pad_mode,
+                   float *out_nchw, int64_t *indices, void *ws, size_t ws_bytes)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    FEMASR_REQUIRE(in_nchw && out_nchw && ws && B > 0 && H > 0 && W > 0, "forward: bad args");
+    FEMASR_REQUIRE(((uintptr_t)ws & 255) == 0, "forward: workspace must be 256-byte aligned");
+    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
+    h->arena.reset(ws, ws_bytes, false);
+    h->stream = (hipStream_t)stream;
+    return run_forward(h, in_nchw, B, H, W, pad_mode, out_nchw, indices);
+}
+
+int femasr_decode_workspace_bytes(const femasr_handle *hc, int B, int hq, int wq, size_t *bytes)
+{
+    femasr_handle *h = const_cast<femasr_handle *>(hc);
+    FEMASR_REQUIRE(h && bytes && B > 0 && hq > 0 && wq > 0, "decode_workspace_bytes: bad args");
+    h->arena.reset(nullptr, 0, true);
+    const int rc = run_decode_indices(h, nullptr, B, hq, wq, nullptr);
+    if (rc) return rc;
+    *bytes = h->arena.peak + 256;
+    return FEMASR_OK;
+}
+
+int femasr_decode_indices(femasr_handle *h, void *stream, const int64_t *indices, int B, int hq, int wq,
+                          float *out_nchw, void *ws, size_t ws_bytes)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    FEMASR_REQUIRE(indices && out_nchw && ws && B > 0 && hq > 0 && wq > 0, "decode_indices: bad args");
+    FEMASR_REQUIRE(((uintptr_t)ws & 255) == 0, "decode_indices: workspace must be 256-byte aligned");
+    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
+    h->arena.reset(ws, ws_bytes, false);
+    h->stream = (hipStream_t)stream;
+    return run_decode_indices(h, indices, B, hq, wq, out_nchw);
+}
+
+int femasr_profile_enable(femasr_handle *h, int on)
+{
+    FEMASR_REQUIRE(h, "null handle");
+    h->prof = on != 0;
+    return FEMASR_OK;
+}
+
+static int profile_drain(femasr_handle *h)
+{
+    for (auto &r : h->recs) {
+        FEMASR_CHECK_HIP(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        FEMASR_CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        h->acc_ms[r.slot] += ms;
+        h->acc_flops[r.slot] += r.flops;
+        h->acc_bytes[r.slot] += r.bytes;
+        h->acc_n[r.slot] += 1;
+    }
+    h->recs.clear();
+    h->pool_used = 0;
+    return FEMASR_OK;
+}
+
+int femasr_profile_reset(femasr_handle *h)
+{
+    FEMASR_REQUIRE(h, "null handle");
+    const int rc = profile_drain(h);
+    std::fill(h->acc_ms.begin(), h->acc_ms.end(), 0.0);
+    std::fill(h->acc_flops.begin(), h->acc_flops.end(), 0.0);
+    std::fill(h->acc_bytes.begin(), h->acc_bytes.end(), 0.0);
+    std::fill(h->acc_n.begin(), h->acc_n.end(), 0);
+    return rc;
+}
+
+int femasr_profile_slots(const femasr_handle *h) { return h ? (int)h->slot_names.size() : 0; }
+
+const char *femasr_profile_name(const femasr_handle *h, int slot)
+{
+    return (h && slot >= 0 && slot < (int)h->slot_names.size()) ? h->slot_names[slot].c_str() : "";
+}
+
+int femasr_profile_get(femasr_handle *h, int slot, double *ms, int64_t *launches, double *flops, double *bytes)
+{
+    FEMASR_REQUIRE(h && slot >= 0 && slot < (int)h->slot_names.size(), "profile_get: bad slot");
+    const int rc = profile_drain(h);
+    if (rc) return rc;
+    if (ms) *ms = h->acc_ms[slot];
+    if (launches) *launches = h->acc_n[slot];
+    if (flops) *flops = h->acc_flops[slot];
+    if (bytes) *bytes = h->acc_bytes[slot];
+    return FEMASR_OK;
+}
+
+}  // extern "C"

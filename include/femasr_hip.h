@@ -1,0 +1,159 @@
+/*
+ * femasr_hip.h — flat C ABI of libfemasr_hip.so (MI355X / gfx950 HIP kernels for the
+ * FeMaSR SR-inference hot path).
+ *
+ * The reference is pure PyTorch: it has NO native boundary for this path
+ * (SURVEY 2.2).  Each entry point therefore cites the reference *Python* interface
+ * whose arithmetic it replaces; `INTEGRATION.md` shows the ctypes binding a
+ * reference maintainer would add (it is the binding femasr_amd/_lib.py uses).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every tensor pointer is a DEVICE pointer owned by the
+ *     caller (e.g. torch allocations, `.data_ptr()`); the library never frees or keeps
+ *     them past the call, except weights, which `femasr_set_weight` COPIES (repacked)
+ *     into allocations the handle owns and frees in `femasr_destroy`.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is
+ *     enqueued on it, no hidden synchronisation (except set_weight/finalize, which sync).
+ *   - activations inside the library are NHWC fp32 ("tokens (B,HW,C)" == NHWC);
+ *     NCHW only at femasr_forward / femasr_decode_indices / pad / crop edges.
+ *   - every function returns 0 on success or a negative femasr_status; the message is
+ *     available from femasr_last_error() (thread-local).  No C++ exception crosses the ABI.
+ *   - a handle is bound to one device and is not thread-safe; one handle per rank.
+ */
+#ifndef FEMASR_HIP_H
+#define FEMASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    FEMASR_OK = 0,
+    FEMASR_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    FEMASR_ERR_HIP = -2,       /* a HIP runtime call failed                */
+    FEMASR_ERR_WEIGHT = -3,    /* unknown key, wrong shape, or missing weight at finalize */
+    FEMASR_ERR_WORKSPACE = -4  /* workspace too small                      */
+} femasr_status;
+
+typedef struct femasr_handle femasr_handle;
+
+/* Mirrors FeMaSRNet.__init__ keyword arguments (basicsr/archs/femasr_arch.py:216-228);
+ * single-codebook configurations only (codebook_params = [[scale, n_e, e_dim]]). */
+typedef struct {
+    int32_t in_channel;      /* 3 */
+    int32_t gt_resolution;   /* 256 */
+    int32_t lq_stage;        /* LQ_stage */
+    int32_t scale_factor;    /* 4 / 2 (ignored -> 1 when !lq_stage, femasr_arch.py:241) */
+    int32_t use_quantize;
+    int32_t use_residual;
+    int32_t codebook_scale;  /* 32 */
+    int32_t n_e;             /* 1024 */
+    int32_t e_dim;           /* 512 */
+    int32_t device;          /* HIP device ordinal the handle is bound to */
+} femasr_config;
+
+const char *femasr_last_error(void);
+int femasr_version(void);
+
+/* ---- model handle ------------------------------------------------------------------ */
+int femasr_create(const femasr_config *cfg, femasr_handle **out);
+void femasr_destroy(femasr_handle *h);
+
+/* Number of weight tensors the configuration expects, and the i-th key / shape
+ * (state-dict names and torch layouts of the reference, SURVEY 8b "Weights"). */
+int femasr_num_weights(const femasr_handle *h);
+int femasr_weight_info(const femasr_handle *h, int i, const char **key, int64_t shape[4], int *ndim);
+
+/* Copy one fp32 tensor (device pointer, torch layout: conv OIHW, linear (out,in), vectors)
+ * into the handle, repacking conv/linear weights to [kh][kw][Cin][Cout].
+ * Replaces nn.Module.load_state_dict for the path (inference_femasr.py:40). */
+int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr,
+                      const int64_t *shape, int ndim);
+/* Verify every expected weight was set; build derived tensors (codebook^T, |e|^2). */
+int femasr_finalize_weights(femasr_handle *h);
+
+/* pad_mode 1 = FeMaSRNet.test geometry (mirror-pad to (h/wsz+1)*wsz, crop to h*s; femasr_arch.py:449-468)
+ * pad_mode 0 = FeMaSRNet.forward (no pad, output (H*s_out) as produced; femasr_arch.py:470-479)          */
+int femasr_workspace_bytes(const femasr_handle *h, int B, int H, int W, int pad_mode, size_t *bytes);
+
+/* Whole hot path: in NCHW fp32 (B,3,H,W) -> out NCHW fp32 (B,3,H*s,W*s) and, if non-NULL,
+ * VQ indices int64 (B,1,h,w).  Replaces FeMaSRNet.encode_and_decode (femasr_arch.py:311-374)
+ * inside .test / .forward.  `ws` must be >= femasr_workspace_bytes and 256-byte aligned. */
+int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, int H, int W,
+                   int pad_mode, float *out_nchw, int64_t *indices, void *ws, size_t ws_bytes);
+
+/* indices (B,1,h,w) int64 -> image NCHW (B,3,8h,8w).  Replaces FeMaSRNet.decode_indices
+ * (femasr_arch.py:376-385) incl. VectorQuantizer.get_codebook_entry (:102-112). */
+int femasr_decode_workspace_bytes(const femasr_handle *h, int B, int hq, int wq, size_t *bytes);
+int femasr_decode_indices(femasr_handle *h, void *stream, const int64_t *indices, int B, int hq, int wq,
+                          float *out_nchw, void *ws, size_t ws_bytes);
+
+/* Per-kernel timing (HIP events recorded on `stream` around every launch) while enabled.
+ * Slots = one per conv_igemm instantiation + one per small-kernel family; femasr_profile_get
+ * synchronises the recorded events and returns, for launches since the last reset, the summed
+ * milliseconds, launch count and algorithmic FLOPs (0 for the HBM-bound families) / bytes. */
+int femasr_profile_enable(femasr_handle *h, int on);
+int femasr_profile_reset(femasr_handle *h);
+int femasr_profile_slots(const femasr_handle *h);
+const char *femasr_profile_name(const femasr_handle *h, int slot);
+int femasr_profile_get(femasr_handle *h, int slot, double *ms, int64_t *launches, double *flops, double *bytes);
+
+/* ---- per-kernel entry points (unit parity tests; same kernels femasr_forward launches) ---- */
+
+/* test() pad + layout: NCHW (B,C,H,W) -> NHWC (B,Hp,Wp,C), mirror rows/cols (femasr_arch.py:454-460). */
+int femasr_pad_nchw_to_nhwc(void *stream, const float *in, int B, int C, int H, int W, int Hp, int Wp, float *out);
+/* crop + layout: NHWC (B,Hs,Ws,C) -> NCHW (B,C,Hc,Wc) top-left (femasr_arch.py:464-465). */
+int femasr_crop_nhwc_to_nchw(void *stream, const float *in, int B, int Hs, int Ws, int C, int Hc, int Wc, float *out);
+
+enum { FEMASR_PRO_NONE = 0, FEMASR_PRO_GN_SILU = 1, FEMASR_PRO_LN = 2 };
+enum { FEMASR_ACT_NONE = 0, FEMASR_ACT_GELU = 1 };
+
+/* Implicit-GEMM convolution / linear on fp32 MFMA.  Replaces nn.Conv2d (femasr_arch.py:150,159,173,
+ * 203,273,298; fema_utils.py:75,78,90; network_swinir.py:465), nn.Upsample(x2) fused on load
+ * (femasr_arch.py:172,202), nn.Linear (network_swinir.py:19-21,105-112; ksz=1 on (1,rows,1,Cin)),
+ * GroupNorm-apply+SiLU / LayerNorm-apply fused on load, bias / GELU / residual adds fused on store. */
+typedef struct {
+    const float *in;      /* (B,H,W,Cin) NHWC, pre-upsample size */
+    int32_t B, H, W, Cin;
+    const float *w;       /* [ksz][ksz][Cin][Cout] */
+    const float *bias;    /* [Cout] */
+    int32_t Cout, ksz, stride, pad, up2;
+    int32_t prologue;     /* FEMASR_PRO_* */
+    const float *pro_a;   /* GN: a[B][Cin]      LN: stats[rows][2] = (mean, rstd) */
+    const float *pro_b;   /* GN: b[B][Cin]      LN: gamma[Cin]                    */
+    const float *pro_c;   /*                    LN: beta[Cin]                     */
+    int32_t act;          /* FEMASR_ACT_* (applied after bias, before residuals) */
+    const float *res1;    /* optional (B,Ho,Wo,Cout) added after act   */
+    const float *res2;    /* optional second residual                   */
+    float *out;           /* (B,Ho,Wo,Cout) */
+    int32_t Ho, Wo;
+} femasr_conv_args;
+int femasr_conv2d(void *stream, const femasr_conv_args *a);
+
+/* GroupNorm(32,eps) moments folded into per-(n,c) scale/shift: y = fmaf(x,a,b) (fema_utils.py:22).
+ * scratch: >= B*H*G*2 doubles. */
+int femasr_gn_coeffs(void *stream, const float *x, int B, int H, int W, int C, int G,
+                     const float *gamma, const float *beta, float eps, float *a, float *b, void *scratch);
+/* LayerNorm(C=256) row moments -> stats[rows][2] = (mean, rstd) (network_swinir.py:199,205). */
+int femasr_ln_stats(void *stream, const float *x, int64_t rows, int C, float eps, float *stats);
+/* 8x8 (shifted-)window multi-head attention incl. rel-pos bias and shift mask
+ * (network_swinir.py:114-145, 216-237, 249-272).  qkv (B,H*W,3C) -> out (B,H*W,C), natural token order. */
+int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W, int C, int heads, int shift,
+                            const float *table, float *out);
+/* VectorQuantizer.forward (femasr_arch.py:35-38,50-100): z (M,D) rows; cbT = codebook^T [D][n_e];
+ * ee[j] = |e_j|^2 (femasr_row_sqsum).  Writes idx (M) int64 first-min, zq (M,D) straight-through.
+ * scratch: >= (M*(n_e/128)*2 + M + 64) floats. */
+int femasr_vq(void *stream, const float *z, int64_t M, int D, const float *cb, const float *cbT,
+              const float *ee, int n_e, int64_t *idx, float *zq, void *scratch);
+int femasr_row_sqsum(void *stream, const float *x, int64_t rows, int D, float *out);
+int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, const float *cb, int n_e, float *zq);
+/* OIHW -> [kh][kw][I][O] repack (also (out,in)->(in,out) with kh=kw=1, and codebook^T). */
+int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEMASR_HIP_H */

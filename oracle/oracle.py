@@ -1,0 +1,373 @@
+"""Python driver of the CPU oracle (oracle/femasr_oracle.c).
+
+>>> TEST INFRASTRUCTURE ONLY — see the header of femasr_oracle.c. <<<
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+
+`OracleNet` orchestrates the C ops into the reference's forward
+(basicsr/archs/femasr_arch.py:311-374 encode_and_decode, :449-468 test,
+:387-447 test_tile, :376-385 decode_indices) from a plain {key: ndarray}
+state dict with the reference's key names and OIHW / (out,in) weight layouts.
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libfemasr_oracle.so')
+_SRC = os.path.join(_HERE, 'femasr_oracle.c')
+_CFLAGS = ['-O3', '-mavx2', '-mfma', '-ffp-contract=off', '-fno-math-errno', '-fopenmp',
+           '-shared', '-fPIC', '-std=gnu11']
+
+
+def build(force=False):
+    """Compile the C restatement (gcc).  No -march=native: the .so travels to the GPU box."""
+    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(_SRC):
+        return _SO
+    subprocess.check_call(['gcc'] + _CFLAGS + ['-o', _SO, _SRC, '-lm'])
+    return _SO
+
+
+_lib = None
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        i, i64, f, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+        L.orc_math_eval.argtypes = [i, vp, vp, i64]
+        L.orc_pad_nchw_to_nhwc.argtypes = [vp, i, i, i, i, i, i, vp]
+        L.orc_crop_nhwc_to_nchw.argtypes = [vp, i, i, i, i, i, i, vp]
+        L.orc_conv2d.argtypes = [vp, i, i, i, i, vp, vp, i, i, i, i, i, i, vp, vp, vp, i, i]
+        L.orc_gn_coeffs.argtypes = [vp, i, i, i, i, i, vp, vp, f, vp, vp]
+        L.orc_scale_shift_silu.argtypes = [vp, i, i64, i, vp, vp, vp]
+        L.orc_layernorm.argtypes = [vp, i64, i, vp, vp, f, vp]
+        L.orc_window_attention.argtypes = [vp, i, i, i, i, i, i, vp, vp]
+        L.orc_vq.argtypes = [vp, i64, i, vp, i, vp, vp, vp, vp]
+        L.orc_codebook_gather.argtypes = [vp, i64, i, vp, vp]
+        for fn in ('orc_math_eval', 'orc_pad_nchw_to_nhwc', 'orc_crop_nhwc_to_nchw', 'orc_conv2d',
+                   'orc_gn_coeffs', 'orc_scale_shift_silu', 'orc_layernorm', 'orc_window_attention',
+                   'orc_vq', 'orc_codebook_gather'):
+            getattr(L, fn).restype = None
+        _lib = L
+    return _lib
+
+
+def _c(a, dtype=np.float32):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ------------------------------------------------------------------ op wrappers
+def math_eval(which, x):
+    x = _c(x)
+    y = np.empty_like(x)
+    lib().orc_math_eval({'exp': 0, 'erf': 1, 'silu': 2, 'gelu': 3}[which], _p(x), _p(y), x.size)
+    return y
+
+
+def pad_nchw_to_nhwc(x, hp, wp):
+    x = _c(x)
+    b, c, h, w = x.shape
+    out = np.empty((b, hp, wp, c), np.float32)
+    lib().orc_pad_nchw_to_nhwc(_p(x), b, c, h, w, hp, wp, _p(out))
+    return out
+
+
+def crop_nhwc_to_nchw(x, hc, wc):
+    x = _c(x)
+    b, hs, ws, c = x.shape
+    out = np.empty((b, c, hc, wc), np.float32)
+    lib().orc_crop_nhwc_to_nchw(_p(x), b, hs, ws, c, hc, wc, _p(out))
+    return out
+
+
+def repack_conv_weight(w_oihw):
+    """OIHW (torch Conv2d) -> [kh][kw][Cin][Cout]."""
+    return _c(np.transpose(np.asarray(w_oihw), (2, 3, 1, 0)))
+
+
+def repack_linear_weight(w_oi):
+    """(out,in) (torch Linear) -> [1][1][in][out]."""
+    return _c(np.asarray(w_oi).T)
+
+
+def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, act=0, res1=None, res2=None):
+    x = _c(x)
+    b, h, w, cin = x.shape
+    cout = w_khwc.shape[-1]
+    hv, wv = (2 * h, 2 * w) if up2 else (h, w)
+    ho = (hv + 2 * pad - ksz) // stride + 1
+    wo = (wv + 2 * pad - ksz) // stride + 1
+    out = np.empty((b, ho, wo, cout), np.float32)
+    w_khwc = _c(w_khwc)
+    bias = _c(bias)
+    if res1 is not None:
+        res1 = _c(res1)
+        assert res1.size == out.size
+    if res2 is not None:
+        res2 = _c(res2)
+        assert res2.size == out.size
+    lib().orc_conv2d(_p(x), b, h, w, cin, _p(w_khwc), _p(bias), cout, ksz, stride, pad, int(up2), act,
+                     _p(res1), _p(res2), _p(out), ho, wo)
+    return out
+
+
+def linear(x_tokens, w_io, bias, act=0, res=None):
+    """x: (..., Cin) -> (..., Cout); w_io is [in][out]."""
+    shp = x_tokens.shape
+    rows = int(np.prod(shp[:-1]))
+    y = conv2d(_c(x_tokens).reshape(1, rows, 1, shp[-1]), w_io, bias, 1, act=act,
+               res1=None if res is None else _c(res).reshape(1, rows, 1, -1))
+    return y.reshape(shp[:-1] + (w_io.shape[-1],))
+
+
+def gn_coeffs(x, gamma, beta, eps=1e-6, groups=32):
+    x = _c(x)
+    b, h, w, c = x.shape
+    a = np.empty((b, c), np.float32)
+    bb = np.empty((b, c), np.float32)
+    gamma, beta = _c(gamma), _c(beta)
+    lib().orc_gn_coeffs(_p(x), b, h, w, c, groups, _p(gamma), _p(beta), eps, _p(a), _p(bb))
+    return a, bb
+
+
+def scale_shift_silu(x, a, b):
+    x = _c(x)
+    bsz, h, w, c = x.shape
+    y = np.empty_like(x)
+    a, b = _c(a), _c(b)
+    lib().orc_scale_shift_silu(_p(x), bsz, h * w, c, _p(a), _p(b), _p(y))
+    return y
+
+
+def gn_silu(x, gamma, beta):
+    a, b = gn_coeffs(x, gamma, beta)
+    return scale_shift_silu(x, a, b)
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    x = _c(x)
+    c = x.shape[-1]
+    rows = x.size // c
+    y = np.empty_like(x)
+    gamma, beta = _c(gamma), _c(beta)
+    lib().orc_layernorm(_p(x), rows, c, _p(gamma), _p(beta), eps, _p(y))
+    return y
+
+
+def window_attention(qkv, b, h, w, c, heads, shift, table):
+    qkv = _c(qkv)
+    out = np.empty((b, h * w, c), np.float32)
+    table = _c(table)
+    lib().orc_window_attention(_p(qkv), b, h, w, c, heads, shift, _p(table), _p(out))
+    return out
+
+
+def vq(z_rows, codebook, want_dists=False):
+    z_rows = _c(z_rows)
+    m, d = z_rows.shape
+    codebook = _c(codebook)
+    idx = np.empty((m,), np.int64)
+    zq = np.empty_like(z_rows)
+    dmin = np.empty((m,), np.float32) if want_dists else None
+    d2 = np.empty((m,), np.float32) if want_dists else None
+    lib().orc_vq(_p(z_rows), m, d, _p(codebook), codebook.shape[0], _p(idx), _p(zq), _p(dmin), _p(d2))
+    return (idx, zq, dmin, d2) if want_dists else (idx, zq)
+
+
+def codebook_gather(idx, codebook):
+    idx = np.ascontiguousarray(idx, np.int64).reshape(-1)
+    codebook = _c(codebook)
+    zq = np.empty((idx.size, codebook.shape[1]), np.float32)
+    lib().orc_codebook_gather(_p(idx), idx.size, codebook.shape[1], _p(codebook), _p(zq))
+    return zq
+
+
+# ------------------------------------------------------------------ network
+_CHANNELS = {8: 256, 16: 256, 32: 256, 64: 256, 128: 128, 256: 64, 512: 32}   # femasr_arch.py:244-252
+
+
+class OracleNet:
+    """Reference forward restated on the C ops.  `sd` = {key: ndarray} with the reference key names."""
+
+    def __init__(self, sd, codebook_params=((32, 1024, 512),), gt_resolution=256, LQ_stage=False,
+                 scale_factor=4, use_quantize=True, use_residual=True):
+        assert len(codebook_params) == 1, 'single-codebook configs only (SURVEY 8b)'
+        self.sd = {k: np.asarray(v) for k, v in sd.items()}
+        self.LQ_stage = bool(LQ_stage)
+        self.scale_factor = int(scale_factor) if LQ_stage else 1
+        self.gt_res = int(gt_resolution)
+        self.codebook_scale = int(codebook_params[0][0])
+        self.use_quantize = use_quantize
+        self.use_residual = use_residual
+        self.max_depth = int(math.log2(self.gt_res // self.codebook_scale))
+        self.encode_depth = int(math.log2(self.gt_res // self.scale_factor // self.codebook_scale))
+        self.probes = None
+        self._wcache = {}
+
+    # -- weight access (repacked once)
+    def _conv_w(self, prefix):
+        if prefix not in self._wcache:
+            self._wcache[prefix] = (repack_conv_weight(self.sd[prefix + '.weight']), _c(self.sd[prefix + '.bias']))
+        return self._wcache[prefix]
+
+    def _lin_w(self, prefix):
+        if prefix not in self._wcache:
+            self._wcache[prefix] = (repack_linear_weight(self.sd[prefix + '.weight']), _c(self.sd[prefix + '.bias']))
+        return self._wcache[prefix]
+
+    def _probe(self, name, val):
+        if self.probes is not None:
+            self.probes[name] = val
+
+    # -- blocks
+    def _conv(self, x, prefix, ksz, stride=1, pad=1, up2=False, res1=None, res2=None):
+        w, b = self._conv_w(prefix)
+        return conv2d(x, w, b, ksz, stride, pad, up2, 0, res1, res2)
+
+    def _resblock(self, x, prefix, res2=None):
+        # fema_utils.py:65-84: conv2(silu(gn2(conv1(silu(gn1(x)))))) + x   (+ optional fused skip add)
+        t = gn_silu(x, self.sd[prefix + '.conv.0.norm.weight'], self.sd[prefix + '.conv.0.norm.bias'])
+        t = self._conv(t, prefix + '.conv.2', 3)
+        t = gn_silu(t, self.sd[prefix + '.conv.3.norm.weight'], self.sd[prefix + '.conv.3.norm.bias'])
+        return self._conv(t, prefix + '.conv.5', 3, res1=x, res2=res2)
+
+    def _swin_block(self, x, b, h, w, prefix, shift):
+        # network_swinir.py:239-279
+        c = x.shape[-1]
+        t = layernorm(x, self.sd[prefix + '.norm1.weight'], self.sd[prefix + '.norm1.bias'])
+        wq, bq = self._lin_w(prefix + '.attn.qkv')
+        qkv = linear(t, wq, bq)
+        att = window_attention(qkv, b, h, w, c, 8, shift, self.sd[prefix + '.attn.relative_position_bias_table'])
+        wp, bp = self._lin_w(prefix + '.attn.proj')
+        x = linear(att, wp, bp, res=x)
+        t = layernorm(x, self.sd[prefix + '.norm2.weight'], self.sd[prefix + '.norm2.bias'])
+        w1, b1 = self._lin_w(prefix + '.mlp.fc1')
+        hdn = linear(t, w1, b1, act=1)
+        w2, b2 = self._lin_w(prefix + '.mlp.fc2')
+        return linear(hdn, w2, b2, res=x)
+
+    def _swin_layers(self, x, prefix):
+        # femasr_arch.py:114-132 + network_swinir.py:442-482 (tokens (B,HW,C) == NHWC)
+        b, h, w, c = x.shape
+        for r in range(4):
+            rp = f'{prefix}.swin_blks.{r}'
+            y = x.reshape(b, h * w, c)
+            for k in range(6):
+                y = self._swin_block(y, b, h, w, f'{rp}.residual_group.blocks.{k}', 0 if k % 2 == 0 else 4)
+            x = self._conv(y.reshape(b, h, w, c), rp + '.conv', 3, res1=x)
+            self._probe(f'swin_rstb{r}', x)
+        return x
+
+    def _encoder(self, x):
+        p = 'multiscale_encoder'
+        x = self._conv(x, p + '.in_conv', 4, 1, 1)
+        self._probe('in_conv', x)
+        outs = []
+        bi = 0
+        for _ in range(self.encode_depth):
+            x = self._conv(x, f'{p}.blocks.{bi}.0', 3, 2, 1)
+            x = self._resblock(x, f'{p}.blocks.{bi}.1')
+            x = self._resblock(x, f'{p}.blocks.{bi}.2')
+            self._probe(f'enc_block{bi}', x)
+            outs.append(x)
+            bi += 1
+        if self.LQ_stage:
+            x = self._swin_layers(x, f'{p}.blocks.{bi}')
+            self._probe(f'enc_block{bi}', x)
+            outs.append(x)
+            bi += 1
+            for _ in range(2):
+                x = self._conv(x, f'{p}.blocks.{bi}.1', 3, 1, 1, up2=True)
+                x = self._resblock(x, f'{p}.blocks.{bi}.2')
+                x = self._resblock(x, f'{p}.blocks.{bi}.3')
+                self._probe(f'enc_block{bi}', x)
+                outs.append(x)
+                bi += 1
+        return outs
+
+    def _decoder_block(self, x, i, res2=None):
+        p = f'decoder_group.{i}.block'
+        x = self._conv(x, p + '.1', 3, 1, 1, up2=True)
+        x = self._resblock(x, p + '.2')
+        return self._resblock(x, p + '.3', res2=res2)
+
+    def encode_and_decode(self, x_nhwc):
+        """femasr_arch.py:311-374; returns (out NHWC, indices (B,1,h,w) int64)."""
+        feats = self._encoder(x_nhwc)
+        feats = feats[-3:] if self.LQ_stage else feats[::-1]
+        fuse_skip = self.LQ_stage and self.use_residual
+        z = self._conv(feats[0], 'before_quant_group.0', 1, 1, 0)
+        self._probe('z', z)
+        b, h, w, d = z.shape
+        idx, zq = vq(z.reshape(-1, d), self.sd['quantize_group.0.embedding.weight'])
+        zq = zq.reshape(b, h, w, d)
+        self._probe('z_q', zq)
+        if not self.use_quantize:
+            zq = z
+        x = self._conv(zq, 'after_quant_group.0.conv', 3)
+        self._probe('after_quant', x)
+        for i in range(self.max_depth):
+            # `x = x + enc_feats[i+1]` (femasr_arch.py:361-362) folded into block i's last conv epilogue
+            skip = feats[i + 1] if (fuse_skip and i + 1 < self.max_depth) else None
+            x = self._decoder_block(x, i, res2=skip)
+            self._probe(f'dec{i}' + ('_plus_skip' if skip is not None else ''), x)
+        wout, bout = self._conv_w('out_conv')
+        out = conv2d(x, wout, bout, 3, 1, 1)
+        return out, idx.reshape(b, 1, h, w)
+
+    # -- public surface (NCHW in / out like the reference module)
+    def forward(self, x_nchw):
+        x = _c(x_nchw)
+        b, c, h, w = x.shape
+        out, idx = self.encode_and_decode(pad_nchw_to_nhwc(x, h, w))
+        return crop_nhwc_to_nchw(out, out.shape[1], out.shape[2]), idx
+
+    def test(self, x_nchw, return_indices=False):
+        x = _c(x_nchw)
+        b, c, h, w = x.shape
+        wsz = 8 // self.scale_factor * 8
+        hp = (h // wsz + 1) * wsz
+        wp = (w // wsz + 1) * wsz
+        out, idx = self.encode_and_decode(pad_nchw_to_nhwc(x, hp, wp))
+        y = crop_nhwc_to_nchw(out, h * self.scale_factor, w * self.scale_factor)
+        return (y, idx) if return_indices else y
+
+    def test_tile(self, x_nchw, tile_size=240, tile_pad=16):
+        x = _c(x_nchw)
+        b, c, h, w = x.shape
+        s = self.scale_factor
+        out = np.zeros((b, c, h * s, w * s), np.float32)
+        for ty in range(math.ceil(h / tile_size)):
+            for tx in range(math.ceil(w / tile_size)):
+                x0, y0 = tx * tile_size, ty * tile_size
+                x1, y1 = min(x0 + tile_size, w), min(y0 + tile_size, h)
+                x0p, y0p = max(x0 - tile_pad, 0), max(y0 - tile_pad, 0)
+                x1p, y1p = min(x1 + tile_pad, w), min(y1 + tile_pad, h)
+                t = self.test(x[:, :, y0p:y1p, x0p:x1p])
+                oy, ox = (y0 - y0p) * s, (x0 - x0p) * s
+                out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = t[:, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
+        return out
+
+    def decode_indices(self, indices):
+        indices = np.asarray(indices)
+        assert indices.ndim == 4
+        b, _, h, w = indices.shape
+        cb = self.sd['quantize_group.0.embedding.weight']
+        zq = codebook_gather(indices, cb).reshape(b, h, w, -1)
+        x = self._conv(zq, 'after_quant_group.0.conv', 3)
+        for i in range(self.max_depth):
+            x = self._decoder_block(x, i)
+        wout, bout = self._conv_w('out_conv')
+        out = conv2d(x, wout, bout, 3, 1, 1)
+        return crop_nhwc_to_nchw(out, out.shape[1], out.shape[2])
