@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""bench.py — SR output megapixels/s at x4 (128 -> 512) on N MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path (`FeMaSRNet.test`) over one batch of synthetic input already resident
+in HBM: BASELINE config[1] — x4, batch 16 of 128x128 LR tiles per GPU, random-init (synthetic) weights.
+Weak scaling: every rank processes its own 16 tiles per step (tiles are independent units); with N > 1
+the step also contains the path's one real exchange, the RCCL all-gather of the upscaled tiles that
+precedes the paste (femasr_amd/distributed.py), unless --no-gather.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel,
+HIP-event timed on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle timed
+on a bounded sample on this box's host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+TILE_GFLOP = 964.47                  # algorithmic GFLOP per x4 128^2 tile (SURVEY 8d / BASELINE.md 3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=16, help='128x128 LR tiles per GPU per step')
+    ap.add_argument('--no-gather', action='store_true', help='N>1: skip the all-gather of upscaled tiles')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='do not record per-kernel HIP events')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from femasr_amd import distributed as fd
+    from femasr_amd import synth
+    from helpers import synth_weights
+    import gpu_utils as G
+
+    rank, world, local = fd.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    weights = synth_weights('x4', 0, 'trained')
+    net = G.build_net('x4', weights, dev)
+    B = args.batch
+    x = torch.from_numpy(synth.synth_input(1000 + rank, (B, 3, 128, 128))).to(dev)
+    gathered = [torch.empty((B, 3, 512, 512), dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        y = net.test(x)
+        if world > 1 and not args.no_gather:
+            dist.all_gather(gathered, y)
+        return y
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        net.enable_profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = {} if args.no_profile else net.profile()
+    if not args.no_profile:
+        net.enable_profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(y).all()
+
+    out_mpix = world * B * 512 * 512 / 1e6
+    value = out_mpix * args.steps / dt
+    res = {
+        'metric': 'SR output megapixels/sec at x4 (128->512)', 'value': round(value, 4), 'unit': 'MPix/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'x4 SR FeMaSRNet.test, batch {B} of 128x128 LR tiles per GPU -> 512x512 (padded 144->576 '
+                               'inside, reference geometry), synthetic random-init weights (seed 0), inputs resident in HBM',
+                   'global_batch': B * world, 'tile': '128x128->512x512', 'parallelism': f'tile-parallel x{world}',
+                   'gather': bool(world > 1 and not args.no_gather),
+                   'algorithmic_gflop_per_tile': TILE_GFLOP,
+                   'end_to_end_tflops': round(TILE_GFLOP * B * world * args.steps / dt / 1e3, 2)},
+    }
+    if rank == 0:
+        if prof:
+            convs = {k: v for k, v in prof.items() if k.startswith('conv_igemm')}
+            dom = max(convs, key=lambda k: convs[k][0])
+            ms, n, fl, _ = convs[dom]
+            tot_ms = sum(v[0] for v in convs.values())
+            tot_fl = sum(v[2] for v in convs.values())
+            ach = fl / (ms * 1e-3) / 1e12
+            res['roofline'] = {
+                'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'launches': n, 'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
+                'all_conv_igemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                   'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   'share_of_step_time': round(tot_ms / (dt * 1e3), 4)},
+                'per_kernel_ms_per_step': {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            from helpers import oracle_net
+            onet = oracle_net('x4', weights)
+            xs = x[:1].cpu().numpy()
+            t1 = time.perf_counter()
+            yo = onet.test(xs)
+            tc = time.perf_counter() - t1
+            res['cpu_baseline'] = {
+                'value': round(512 * 512 / 1e6 / tc, 5), 'unit': 'MPix/s', 'cores': os.cpu_count(), 'kind': 'port',
+                'sample': f'1 of the {B} tiles of one step (x4 128x128->512x512, {TILE_GFLOP} GFLOP) through oracle/ '
+                          f'(C, OpenMP, fp32 fmaf) in {tc:.1f} s',
+                'max_abs_vs_gpu': float(np.abs(yo - y[:1].cpu().numpy()).max()),
+            }
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

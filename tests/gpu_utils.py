@@ -1,0 +1,99 @@
+"""Thin wrappers over the C ABI for the GPU parity tests (torch only moves memory)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from femasr_amd import _lib
+
+
+def dev(a, device='cuda'):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
+           res1=None, res2=None):
+    """x NHWC numpy -> numpy, through femasr_conv2d."""
+    lib = _lib.load()
+    b, h, w, cin = x.shape
+    cout = w_khwc.shape[-1]
+    hv, wv = (2 * h, 2 * w) if up2 else (h, w)
+    ho, wo = (hv + 2 * pad - ksz) // stride + 1, (wv + 2 * pad - ksz) // stride + 1
+    tx, tw, tb = dev(x), dev(w_khwc), dev(bias)
+    tp = [None if p is None else dev(p) for p in pro]
+    t1 = None if res1 is None else dev(res1)
+    t2 = None if res2 is None else dev(res2)
+    out = torch.full((b, ho, wo, cout), float('nan'), dtype=torch.float32, device='cuda')
+    a = _lib.ConvArgs()
+    a.in_ = tx.data_ptr(); a.B, a.H, a.W, a.Cin = b, h, w, cin
+    a.w = tw.data_ptr(); a.bias = tb.data_ptr()
+    a.Cout, a.ksz, a.stride, a.pad, a.up2, a.prologue = cout, ksz, stride, pad, int(up2), prologue
+    a.pro_a = None if tp[0] is None else tp[0].data_ptr()
+    a.pro_b = None if tp[1] is None else tp[1].data_ptr()
+    a.pro_c = None if tp[2] is None else tp[2].data_ptr()
+    a.act = act
+    a.res1 = None if t1 is None else t1.data_ptr()
+    a.res2 = None if t2 is None else t2.data_ptr()
+    a.out = out.data_ptr(); a.Ho, a.Wo = ho, wo
+    _lib.check(lib.femasr_conv2d(None, ctypes.byref(a)))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def gn_coeffs(x, gamma, beta, eps=1e-6, groups=32):
+    lib = _lib.load()
+    b, h, w, c = x.shape
+    tx, tg, tb = dev(x), dev(gamma), dev(beta)
+    a = torch.empty((b, c), dtype=torch.float32, device='cuda')
+    bb = torch.empty((b, c), dtype=torch.float32, device='cuda')
+    scratch = torch.empty(b * h * groups * 2, dtype=torch.float64, device='cuda')
+    _lib.check(lib.femasr_gn_coeffs(None, _lib.ptr(tx), b, h, w, c, groups, _lib.ptr(tg), _lib.ptr(tb), eps,
+                                    _lib.ptr(a), _lib.ptr(bb), _lib.ptr(scratch)))
+    torch.cuda.synchronize()
+    return a.cpu().numpy(), bb.cpu().numpy()
+
+
+def ln_stats(x, eps=1e-5):
+    lib = _lib.load()
+    rows, c = x.shape
+    tx = dev(x)
+    st = torch.empty((rows, 2), dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_ln_stats(None, _lib.ptr(tx), rows, c, eps, _lib.ptr(st)))
+    torch.cuda.synchronize()
+    return st.cpu().numpy()
+
+
+def window_attention(qkv, b, h, w, c, heads, shift, table):
+    lib = _lib.load()
+    tq, tt = dev(qkv), dev(table)
+    out = torch.full((b, h * w, c), float('nan'), dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_window_attention(None, _lib.ptr(tq), b, h, w, c, heads, shift, _lib.ptr(tt), _lib.ptr(out)))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def vq(z_rows, codebook):
+    lib = _lib.load()
+    m, d = z_rows.shape
+    n_e = codebook.shape[0]
+    tz, tcb = dev(z_rows), dev(codebook)
+    cbt = torch.empty((d, n_e), dtype=torch.float32, device='cuda')
+    ee = torch.empty((n_e,), dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(tcb), n_e, d, 1, 1, _lib.ptr(cbt)))
+    _lib.check(lib.femasr_row_sqsum(None, _lib.ptr(tcb), n_e, d, _lib.ptr(ee)))
+    idx = torch.full((m,), -1, dtype=torch.int64, device='cuda')
+    zq = torch.full((m, d), float('nan'), dtype=torch.float32, device='cuda')
+    scratch = torch.empty(m * (n_e // 128) * 2 + m + 64, dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_vq(None, _lib.ptr(tz), m, d, _lib.ptr(tcb), _lib.ptr(cbt), _lib.ptr(ee), n_e,
+                             _lib.ptr(idx), _lib.ptr(zq), _lib.ptr(scratch)))
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), zq.cpu().numpy(), cbt.cpu().numpy(), ee.cpu().numpy()
+
+
+def build_net(cfg_name, weights, device='cuda'):
+    from femasr_amd.archs import build_network
+    from helpers import CONFIGS
+    net = build_network(dict(type='FeMaSRNet', **CONFIGS[cfg_name]))
+    missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=False)
+    assert not missing.unexpected_keys
+    return net.to(device).eval()

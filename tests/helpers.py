@@ -1,0 +1,77 @@
+"""Shared test helpers: golden loading, synthetic weights, the VQ near-tie rule."""
+import json
+import os
+
+import numpy as np
+
+from femasr_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+CONFIGS = {
+    'x4': dict(codebook_params=[[32, 1024, 512]], LQ_stage=True, scale_factor=4),
+    'x2': dict(codebook_params=[[32, 1024, 512]], LQ_stage=True, scale_factor=2),
+    'hq': dict(codebook_params=[[32, 1024, 512]], LQ_stage=False),
+}
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+
+
+def key_table(cfg_name):
+    with open(os.path.join(GOLDEN, 'state_dict_keys.json')) as f:
+        return json.load(f)[cfg_name]
+
+
+def cfg_name_of(g):
+    if not int(g['cfg_LQ_stage']):
+        return 'hq'
+    return 'x4' if int(g['cfg_scale_factor']) == 4 else 'x2'
+
+
+def synth_weights(cfg_name, seed, codebook):
+    """{key: ndarray} for every float tensor of the config, from the committed key table."""
+    out = {}
+    for key, shape, dtype in key_table(cfg_name):
+        leaf = key.rsplit('.', 1)[-1]
+        if leaf in ('relative_position_index', 'attn_mask'):
+            continue
+        out[key] = synth.synth_tensor(seed, key, tuple(shape), codebook)
+    return out
+
+
+def oracle_net(cfg_name, weights):
+    from oracle import oracle as orc
+    cfg = CONFIGS[cfg_name]
+    return orc.OracleNet(weights, LQ_stage=cfg['LQ_stage'], scale_factor=cfg.get('scale_factor', 4))
+
+
+def ulp_of(x):
+    return np.spacing(np.abs(np.asarray(x, np.float32)))
+
+
+def check_indices_near_tie(idx, g, max_ulp=2):
+    """VQ index parity against the reference with the documented near-tie allowance (hard part 1):
+    a mismatch is accepted only if the REFERENCE's own distances of its winner and its runner-up are
+    within `max_ulp` ulp AND the candidate picked that runner-up.  Returns (n_mismatch, n_accepted)."""
+    ref = g['vq_indices'].reshape(-1)
+    idx = np.asarray(idx).reshape(-1)
+    assert idx.shape == ref.shape
+    bad = np.nonzero(idx != ref)[0]
+    accepted = 0
+    for r in bad:
+        gap = float(g['vq_d_second'][r]) - float(g['vq_d_best'][r])
+        tol = max_ulp * float(ulp_of(g['vq_d_best'][r]))
+        if gap <= tol and idx[r] == g['vq_idx_second'][r]:
+            accepted += 1
+    return len(bad), accepted
+
+
+def probe_err(g, name, arr):
+    pos = g['probe_pos_' + name]
+    val = g['probe_val_' + name]
+    flat = np.ascontiguousarray(arr).reshape(-1)
+    assert tuple(g['probe_shape_' + name]) == tuple(arr.shape), (name, g['probe_shape_' + name], arr.shape)
+    got = flat[pos]
+    return float(np.max(np.abs(got - val))), float(np.max(np.abs(val)))

@@ -1,0 +1,176 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against the CPU oracle on the same seeded inputs.
+Bar: BIT-EXACT (the kernels implement the oracle's arithmetic specification: fmaf chains in ascending
+k on the fp32 matrix cores, fixed-order moments, explicit exp/erf) — asserted with array_equal; the
+message reports max-abs so a regression is quantified."""
+import numpy as np
+import pytest
+import torch
+
+from femasr_amd import _lib, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(got, ref, what):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    if not np.array_equal(got, ref):
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        raise AssertionError(f'{what}: not bit-identical: max-abs {np.nanmax(d):.3e}, mismatching {np.sum(got != ref)} '
+                             f'of {got.size}, nan {np.isnan(got).sum()}')
+
+
+def test_native_library_is_loaded(cuda_device):
+    lib = _lib.load()
+    assert lib.femasr_version() >= 100
+    with open('/proc/self/maps') as f:
+        assert 'libfemasr_hip.so' in f.read()
+
+
+def test_pad_crop_exact(cuda_device):
+    import gpu_utils as G
+    lib = _lib.load()
+    x = synth.uniform(0, 'px', (3, 3, 21, 30), 0, 1)
+    tx = G.dev(x)
+    out = torch.empty((3, 32, 32, 3), dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_pad_nchw_to_nhwc(None, _lib.ptr(tx), 3, 3, 21, 30, 32, 32, _lib.ptr(out)))
+    _same(out.cpu().numpy(), orc.pad_nchw_to_nhwc(x, 32, 32), 'pad')
+    y = synth.uniform(1, 'cy', (2, 40, 48, 3), -1, 1)
+    ty = G.dev(y)
+    o2 = torch.empty((2, 3, 33, 47), dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_crop_nhwc_to_nchw(None, _lib.ptr(ty), 2, 40, 48, 3, 33, 47, _lib.ptr(o2)))
+    _same(o2.cpu().numpy(), orc.crop_nhwc_to_nchw(y, 33, 47), 'crop')
+    # error behaviour: pad larger than the image is refused (the reference would mis-slice silently)
+    assert lib.femasr_pad_nchw_to_nhwc(None, _lib.ptr(tx), 3, 3, 21, 30, 64, 32, _lib.ptr(out)) != 0
+
+
+CONV_CASES = [
+    # name, (B,H,W,Cin), Cout, k, s, p, up2
+    ('in_conv_k4_cin3', (2, 31, 33, 3), 256, 4, 1, 1, False),
+    ('in_conv_k4_cin3_c64', (1, 17, 16, 3), 64, 4, 1, 1, False),
+    ('down_s2_odd', (2, 31, 29, 256), 256, 3, 2, 1, False),
+    ('k3_256', (1, 16, 24, 256), 256, 3, 1, 1, False),
+    ('up2_256_128', (2, 9, 12, 256), 128, 3, 1, 1, True),
+    ('k1_256_512', (1, 16, 16, 256), 512, 1, 1, 0, False),
+    ('k3_512_256', (1, 8, 8, 512), 256, 3, 1, 1, False),
+    ('cout64', (1, 20, 24, 128), 64, 3, 1, 1, True),
+    ('cout3', (2, 24, 20, 64), 3, 3, 1, 1, False),
+    ('tiny_m', (1, 3, 5, 32), 96, 3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_bit_exact(cuda_device, case):
+    import gpu_utils as G
+    name, shp, cout, k, s, p, up = case
+    x = synth.uniform(1, name + 'x', shp, -1.5, 1.5)
+    w = synth.uniform(1, name + 'w', (k, k, shp[3], cout), -0.1, 0.1)
+    b = synth.uniform(1, name + 'b', (cout,), -0.5, 0.5)
+    _same(G.conv2d(x, w, b, k, s, p, up), orc.conv2d(x, w, b, k, s, p, up), name)
+
+
+@pytest.mark.parametrize('cin,cout', [(256, 256), (128, 128), (64, 64), (64, 3), (128, 64)])
+def test_conv_gn_silu_prologue_and_residuals(cuda_device, cin, cout):
+    """ResBlock conv: GroupNorm-apply + SiLU fused on load, bias + two residual adds fused on store."""
+    import gpu_utils as G
+    x = synth.uniform(2, 'gx', (2, 13, 10, cin), -3, 4)
+    gamma = synth.uniform(2, 'gg', (cin,), 0.5, 1.5)
+    beta = synth.uniform(2, 'gb', (cin,), -0.5, 0.5)
+    a_ref, b_ref = orc.gn_coeffs(x, gamma, beta)
+    a, bb = G.gn_coeffs(x, gamma, beta)
+    _same(a, a_ref, 'gn a')
+    _same(bb, b_ref, 'gn b')
+    w = synth.uniform(2, 'gw', (3, 3, cin, cout), -0.1, 0.1)
+    bias = synth.uniform(2, 'gbias', (cout,), -0.5, 0.5)
+    r1 = synth.uniform(2, 'r1', (2, 13, 10, cout), -1, 1)
+    r2 = synth.uniform(2, 'r2', (2, 13, 10, cout), -1, 1)
+    ref = orc.conv2d(orc.scale_shift_silu(x, a_ref, b_ref), w, bias, 3, 1, 1, res1=r1, res2=r2)
+    got = G.conv2d(x, w, bias, 3, 1, 1, prologue=_lib.PRO_GN_SILU, pro=(a_ref, b_ref, None), res1=r1, res2=r2)
+    _same(got, ref, f'conv gn_silu {cin}->{cout}')
+
+
+def test_gn_moments_large_and_offset(cuda_device):
+    """Cancellation-prone case: large mean, small variance, H*W big enough for many rows."""
+    import gpu_utils as G
+    x = synth.uniform(3, 'big', (1, 96, 80, 64), 99.0, 101.0)
+    g = synth.uniform(3, 'g', (64,), 0.5, 1.5)
+    b = synth.uniform(3, 'b', (64,), -0.5, 0.5)
+    a_ref, b_ref = orc.gn_coeffs(x, g, b)
+    a, bb = G.gn_coeffs(x, g, b)
+    _same(a, a_ref, 'gn a (offset)')
+    _same(bb, b_ref, 'gn b (offset)')
+
+
+@pytest.mark.parametrize('cout,act', [(768, 0), (1024, 1), (256, 0)])
+def test_linear_ln_prologue_gelu(cuda_device, cout, act):
+    """Swin linears: LayerNorm-apply on load (qkv / fc1), exact-erf GELU + residual on store."""
+    import gpu_utils as G
+    rows = 300
+    x = synth.uniform(4, 'lx', (rows, 256), -4, 6)
+    gamma = synth.uniform(4, 'lg', (256,), 0.5, 1.5)
+    beta = synth.uniform(4, 'lb', (256,), -0.5, 0.5)
+    w = synth.uniform(4, 'lw', (256, cout), -0.1, 0.1)
+    bias = synth.uniform(4, 'lbias', (cout,), -0.5, 0.5)
+    res = synth.uniform(4, 'lres', (rows, cout), -1, 1) if cout == 256 else None
+    stats = G.ln_stats(x)
+    ref = orc.linear(orc.layernorm(x, gamma, beta), w, bias, act=act, res=res)
+    got = G.conv2d(x.reshape(1, rows, 1, 256), w.reshape(1, 1, 256, cout), bias, 1, prologue=_lib.PRO_LN,
+                   pro=(stats, gamma, beta), act=act, res1=None if res is None else res.reshape(1, rows, 1, cout))
+    _same(got.reshape(rows, cout), ref, f'linear ln cout={cout} act={act}')
+
+
+def test_linear_k1024(cuda_device):
+    import gpu_utils as G
+    rows = 200
+    x = synth.uniform(5, 'fx', (rows, 1024), -1, 1)
+    w = synth.uniform(5, 'fw', (1024, 256), -0.05, 0.05)
+    bias = synth.uniform(5, 'fb', (256,), -0.5, 0.5)
+    res = synth.uniform(5, 'fr', (rows, 256), -1, 1)
+    got = G.conv2d(x.reshape(1, rows, 1, 1024), w.reshape(1, 1, 1024, 256), bias, 1, res1=res.reshape(1, rows, 1, 256))
+    _same(got.reshape(rows, 256), orc.linear(x, w, bias, res=res), 'fc2')
+
+
+@pytest.mark.parametrize('shift', [0, 4])
+def test_window_attention_bit_exact(cuda_device, shift):
+    import gpu_utils as G
+    b, h, w, c = 2, 16, 24, 256
+    qkv = synth.uniform(6 + shift, 'qkv', (b, h * w, 3 * c), -2, 2)
+    table = synth.uniform(6, 'tab', (225, 8), -0.5, 0.5)
+    _same(G.window_attention(qkv, b, h, w, c, 8, shift, table),
+          orc.window_attention(qkv, b, h, w, c, 8, shift, table), f'window attention shift={shift}')
+
+
+def test_vq_bit_exact_and_first_min_tie(cuda_device):
+    import gpu_utils as G
+    cb = synth.uniform(5, 'vq.codebook', (1024, 512), -1.0, 1.0)
+    cb[700] = cb[13]
+    cb[901] = cb[13]                       # exact ties across n-blocks (cols 13, 700, 901 -> blocks 0, 5, 7)
+    cb[14] = cb[13]                        # and inside one 32-column MFMA tile
+    z = synth.uniform(6, 'vq.rows', (333, 512), -1.0, 1.0)
+    z[0] = cb[13] * 0.97
+    z[200] = cb[700] * 1.02
+    idx_ref, zq_ref = orc.vq(z, cb)
+    idx, zq, cbt, ee = G.vq(z, cb)
+    assert idx[0] == 13 and idx[200] == 13
+    assert np.array_equal(cbt, cb.T)
+    _same(idx, idx_ref, 'vq indices')
+    _same(zq, zq_ref, 'vq z_q')
+    # reference init regime: codes tiny against |z|^2 -> distances quantised to the ulp of |z|^2, many exact ties
+    cb2 = synth.uniform(7, 'vq.cb.init', (1024, 512), -1.0 / 1024, 1.0 / 1024)
+    z2 = synth.uniform(7, 'vq.rows2', (257, 512), -1.0, 1.0)
+    idx_ref2, zq_ref2 = orc.vq(z2, cb2)
+    idx2, zq2, _, _ = G.vq(z2, cb2)
+    _same(idx2, idx_ref2, 'vq indices (init codebook)')
+    _same(zq2, zq_ref2, 'vq z_q (init codebook)')
+
+
+def test_bad_arguments_are_refused(cuda_device):
+    import ctypes
+    lib = _lib.load()
+    x = torch.zeros((1, 8, 8, 32), device='cuda')
+    assert lib.femasr_window_attention(None, _lib.ptr(x), 1, 9, 8, 256, 8, 0, _lib.ptr(x), _lib.ptr(x)) != 0
+    assert b'multiples of 8' in lib.femasr_last_error()
+    assert lib.femasr_ln_stats(None, _lib.ptr(x), 4, 128, 1e-5, _lib.ptr(x)) != 0
+    a = _lib.ConvArgs()
+    assert lib.femasr_conv2d(None, ctypes.byref(a)) != 0

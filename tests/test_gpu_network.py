@@ -1,0 +1,144 @@
+"""-m gpu: the whole hot path (FeMaSRNet on the HIP library) against
+  (1) the CPU oracle on the same seeded weights/inputs — BIT-EXACT outputs and VQ indices, and
+  (2) the committed golden vectors recorded from the reference — outputs within 1e-3 max-abs fp32,
+      indices exact (near-tie rule of helpers.check_indices_near_tie; currently zero mismatches),
+plus size-independent properties at BASELINE.json's full sizes (batch invariance, determinism,
+tiled == batched, decode(encode) consistency)."""
+import numpy as np
+import pytest
+import torch
+
+from femasr_amd import synth
+from helpers import cfg_name_of, check_indices_near_tie, load_golden, oracle_net, synth_weights
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3       # north-star tolerance vs the reference forward (max-abs, fp32)
+
+
+def _case(name):
+    import gpu_utils as G
+    g = load_golden(name)
+    cn = cfg_name_of(g)
+    w = synth_weights(cn, int(g['seed']), str(g['codebook']))
+    x = synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))
+    return g, cn, w, x, G.build_net(cn, w)
+
+
+@pytest.mark.parametrize('name', ['x4_small_init', 'x4_small_trained', 'x2_small_trained'])
+def test_test_path_vs_oracle_and_reference(cuda_device, name):
+    g, cn, w, x, net = _case(name)
+    y, idx = net.test_with_indices(torch.from_numpy(x).cuda())
+    y, idx = y.cpu().numpy(), idx.cpu().numpy()
+    assert y.shape == tuple(g['out_shape']) and idx.dtype == np.int64 and idx.shape == g['vq_indices'].shape
+    # (2) reference goldens
+    assert np.abs(y - g['output']).max() < TOL
+    nbad, nacc = check_indices_near_tie(idx, g)
+    assert nbad == 0, f'{nbad} VQ index mismatches vs the reference ({nacc} near-tie acceptable)'
+    # (1) oracle, bit-exact
+    yo, io = oracle_net(cn, w).test(x, return_indices=True)
+    assert np.array_equal(idx, io), f'{np.sum(idx != io)} index mismatches vs oracle'
+    assert np.array_equal(y, yo), f'not bit-identical to the oracle: max-abs {np.abs(y - yo).max():.3e}'
+
+
+def test_hq_forward_and_decode_indices(cuda_device):
+    g, cn, w, x, net = _case('hq_small_trained')
+    out, cl, sl, idx_list = net(torch.from_numpy(x).cuda())
+    assert float(cl) == 0.0 and float(sl) == 0.0 and len(idx_list) == 1
+    y, idx = out.cpu().numpy(), idx_list[0].cpu().numpy()
+    assert np.abs(y - g['output']).max() < TOL
+    assert np.array_equal(idx, g['vq_indices'])
+    yo, io = oracle_net(cn, w).forward(x)
+    assert np.array_equal(idx, io) and np.array_equal(y, yo)
+    # decode_indices(indices) reproduces the decoder half exactly (same kernels, same order)
+    y2 = net.decode_indices(idx_list[0]).cpu().numpy()
+    assert np.array_equal(y2, y)
+    # and matches the reference's decode_indices golden
+    gd = load_golden('hq_decode_indices')
+    import gpu_utils as G
+    net2 = G.build_net('hq', synth_weights('hq', int(gd['seed']), str(gd['codebook'])))
+    yd = net2.decode_indices(torch.from_numpy(gd['indices'])).cpu().numpy()
+    assert np.abs(yd - gd['output']).max() < TOL
+    with pytest.raises(AssertionError):
+        net2.decode_indices(torch.zeros(4, 4, dtype=torch.int64))
+
+
+def test_test_tile_vs_reference_and_oracle(cuda_device):
+    g, cn, w, x, net = _case('x4_tiled_trained')
+    ts, pad = int(g['kw_tile_size']), int(g['kw_tile_pad'])
+    y = net.test_tile(torch.from_numpy(x).cuda(), ts, pad).cpu().numpy()
+    assert y.shape == tuple(g['out_shape'])
+    assert np.abs(y - g['output']).max() < TOL
+    yo = oracle_net(cn, w).test_tile(x, ts, pad)
+    assert np.array_equal(y, yo), f'max-abs vs oracle {np.abs(y - yo).max():.3e}'
+    # two "ranks" in one process: partition + gather is a pure function of (tiles, world)
+    from femasr_amd import tiling
+    xt = torch.from_numpy(x).cuda()
+
+    def fake_gather(results, classes, batch, channel, scale):
+        other = {}
+        for hw, tl in tiling.partition(classes, 1, 2).items():
+            other[hw] = torch.cat([net.test(xt[:, :, t.y0p:t.y1p, t.x0p:t.x1p]) for t in tl], 0) if tl else \
+                xt.new_zeros((0, channel, hw[0] * scale, hw[1] * scale))
+        return [results, other]
+    y2 = net.test_tile(xt, ts, pad, rank=0, world_size=2, gather=fake_gather).cpu().numpy()
+    assert np.array_equal(y2, y)
+
+
+def test_full_size_tile_vs_reference(cuda_device):
+    """BASELINE config-2 geometry: 128x128 LR -> (144 padded) -> 512x512, both codebook regimes."""
+    for name in ('x4_tile128_init', 'x4_tile128_trained'):
+        g, cn, w, x, net = _case(name)
+        xb = torch.from_numpy(np.concatenate([x, x[:, :, ::-1].copy()], 0)).cuda()      # B=2: golden + a flipped copy
+        y, idx = net.test_with_indices(xb)
+        y, idx = y.cpu().numpy(), idx.cpu().numpy()
+        st = int(g['out_stride'])
+        assert np.abs(y[:1, :, ::st, ::st] - g['output']).max() < TOL
+        assert abs(float(y[:1].astype(np.float64).mean()) - float(g['out_mean'])) < 1e-5
+        nbad, nacc = check_indices_near_tie(idx[:1], g)
+        assert nbad == 0, f'{name}: {nbad} index mismatches vs the reference ({nacc} near-tie acceptable)'
+        del net
+        torch.cuda.empty_cache()
+
+
+def test_full_size_batch16_properties(cuda_device):
+    """x4, batch 16 of 128x128 tiles (the benchmarked workload): size-independent properties."""
+    import gpu_utils as G
+    w = synth_weights('x4', 0, 'trained')
+    net = G.build_net('x4', w)
+    x = torch.from_numpy(synth.synth_input(5, (16, 3, 128, 128))).cuda()
+    y, idx = net.test_with_indices(x)
+    assert y.shape == (16, 3, 512, 512) and idx.shape == (16, 1, 72, 72) and torch.isfinite(y).all()
+    # determinism: same bits twice
+    y2, idx2 = net.test_with_indices(x)
+    assert torch.equal(y, y2) and torch.equal(idx, idx2)
+    # batch invariance: sample i alone == sample i inside the batch (all ops are per-sample)
+    for i in (0, 7, 15):
+        yi, ii = net.test_with_indices(x[i:i + 1])
+        assert torch.equal(yi[0], y[i]) and torch.equal(ii[0], idx[i])
+    # tiled == batched: a 512x512 image cut into 16 tiles of 128 with no halo IS the batch of its crops
+    img = torch.cat([torch.cat([x[r * 4 + c] for c in range(4)], 2) for r in range(4)], 1)[None]
+    yt = net.test_tile(img, 128, 0)
+    for r in range(4):
+        for c in range(4):
+            assert torch.equal(yt[0, :, r * 512:(r + 1) * 512, c * 512:(c + 1) * 512], y[r * 4 + c])
+    # indices index real codes; decode path accepts them
+    assert int(idx.min()) >= 0 and int(idx.max()) < 1024
+
+
+def test_weight_updates_are_picked_up_and_errors_are_loud(cuda_device):
+    import gpu_utils as G
+    from femasr_amd._lib import FemasrError
+    w = synth_weights('hq', 3, 'trained')
+    net = G.build_net('hq', w)
+    x = torch.from_numpy(synth.synth_input(9, (1, 3, 32, 32))).cuda()
+    y0 = net(x)[0].clone()
+    with torch.no_grad():
+        net.out_conv.bias.add_(1.0)
+    y1 = net(x)[0]
+    assert torch.allclose(y1, y0 + 1.0, atol=1e-5) and not torch.equal(y1, y0)
+    with pytest.raises(ValueError):
+        net.test(torch.zeros(1, 4, 32, 32, device='cuda'))
+    with pytest.raises(FemasrError):
+        net.test(torch.zeros(1, 3, 32, 32))            # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 30, 32, device='cuda'))  # forward() needs /8 sizes (reference would crash in the decoder)

@@ -1,0 +1,139 @@
+"""Host-side logic that needs no GPU: registry semantics, state-dict surface, tile geometry,
+rank partition, the deterministic generator, the C-ABI library's exported symbols."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from femasr_amd import synth, tiling
+from femasr_amd.archs import ARCH_REGISTRY, build_network
+from femasr_amd.registry import Registry
+from helpers import CONFIGS, key_table
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_semantics():
+    reg = Registry('t')
+
+    @reg.register()
+    class A:
+        pass
+
+    class B:
+        pass
+    reg.register(B)
+    assert reg.get('A') is A and reg.get('B') is B and 'A' in reg
+    with pytest.raises(AssertionError):
+        reg.register(A)                      # duplicate name asserts (registry.py:38-41)
+    with pytest.raises(KeyError):
+        reg.get('missing')
+    assert set(reg.keys()) == {'A', 'B'}
+
+
+@pytest.mark.parametrize('cfg', ['x4', 'x2', 'hq'])
+def test_state_dict_surface_matches_reference(cfg):
+    """Same keys, order, shapes and dtypes as the reference module (fixture recorded from it)."""
+    net = build_network(dict(type='FeMaSRNet', frozen_module_keywords=['quantize'], **CONFIGS[cfg]))
+    got = [[k, list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()]
+    assert got == key_table(cfg)
+    assert 'FeMaSRNet' in ARCH_REGISTRY
+    assert net.scale_factor == (CONFIGS[cfg].get('scale_factor', 4) if CONFIGS[cfg]['LQ_stage'] else 1)
+    assert net.max_depth == 3 and net.gt_res == 256 and net.use_semantic_loss is False
+
+
+def test_unsupported_variants_raise():
+    with pytest.raises(NotImplementedError):
+        build_network(dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512], [64, 1024, 256]]))
+    with pytest.raises(NotImplementedError):
+        build_network(dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512]], norm_type='bn'))
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a GPU instead of computing on the CPU."""
+    from femasr_amd._lib import FemasrError
+    net = build_network(dict(type='FeMaSRNet', **CONFIGS['hq']))
+    with pytest.raises(FemasrError):
+        net.test(torch.zeros(1, 3, 16, 16))
+
+
+def _reference_tiles(h, w, ts, pad):
+    """test_tile's loop restated literally (femasr_arch.py:401-441) as the checker."""
+    out = []
+    for y in range(math.ceil(h / ts)):
+        for x in range(math.ceil(w / ts)):
+            ox, oy = x * ts, y * ts
+            ex, ey = min(ox + ts, w), min(oy + ts, h)
+            out.append((max(oy - pad, 0), min(ey + pad, h), max(ox - pad, 0), min(ex + pad, w), oy, ey, ox, ex))
+    return out
+
+
+@pytest.mark.parametrize('h,w,ts,pad', [(2048, 2048, 240, 16), (2048, 2048, 128, 0), (2048, 2048, 96, 16),
+                                         (40, 56, 24, 8), (600, 720, 240, 16), (17, 5, 240, 16)])
+def test_tile_enumeration(h, w, ts, pad):
+    tiles = tiling.enumerate_tiles(h, w, ts, pad)
+    ref = _reference_tiles(h, w, ts, pad)
+    assert [(t.y0p, t.y1p, t.x0p, t.x1p, t.y0, t.y1, t.x0, t.x1) for t in tiles] == ref
+    cover = np.zeros((h, w), np.int32)
+    for t in tiles:
+        cover[t.y0:t.y1, t.x0:t.x1] += 1
+        ys, ye, xs, xe = t.out_src(4)
+        assert ye - ys == (t.y1 - t.y0) * 4 and xe - xs == (t.x1 - t.x0) * 4
+        assert ye <= t.in_hw[0] * 4 and xe <= t.in_hw[1] * 4
+    assert cover.min() == 1 and cover.max() == 1            # bodies tile the image exactly once
+
+
+def test_shape_classes_2048():
+    """2048^2 at 240/16 -> 81 tiles in 9 classes 49/7/7/7/7/1/1/1/1; at 128/0 -> one class of 256."""
+    cl = tiling.shape_classes(tiling.enumerate_tiles(2048, 2048, 240, 16))
+    assert sorted((len(v) for v in cl.values()), reverse=True) == [49, 7, 7, 7, 7, 1, 1, 1, 1]
+    cl = tiling.shape_classes(tiling.enumerate_tiles(2048, 2048, 128, 0))
+    assert list(cl.keys()) == [(128, 128)] and len(cl[(128, 128)]) == 256
+    cl = tiling.shape_classes(tiling.enumerate_tiles(2048, 2048, 96, 16))
+    assert sum(len(v) for v in cl.values()) == 484
+
+
+@pytest.mark.parametrize('n,world', [(256, 8), (81, 8), (7, 8), (1, 8), (0, 4), (49, 3)])
+def test_rank_partition_is_a_partition(n, world):
+    got = []
+    for r in range(world):
+        lo, hi = tiling.rank_slice(n, r, world)
+        assert 0 <= lo <= hi <= n and hi - lo in (n // world, n // world + 1)
+        got += list(range(lo, hi))
+    assert got == list(range(n))
+
+
+def test_padded_hw_always_pads():
+    assert tiling.padded_hw(128, 128, 4) == (144, 144)      # divisible input still gains one block
+    assert tiling.padded_hw(256, 256, 2) == (288, 288)
+    assert tiling.padded_hw(20, 28, 4) == (32, 32)
+    assert tiling.padded_hw(64, 48, 1) == (128, 64)           # wsz = 64 when scale_factor is 1
+
+
+def test_synth_is_deterministic_and_keyed():
+    a = synth.synth_tensor(0, 'out_conv.bias', (3,))
+    b = synth.synth_tensor(0, 'out_conv.bias', (3,))
+    c = synth.synth_tensor(1, 'out_conv.bias', (3,))
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    # pinned values: the generator must not drift between the golden container and the GPU box
+    u = synth.uniform01(0, 'pin', 4)
+    assert [float(v).hex() for v in u] == [float(v).hex() for v in synth.uniform01(0, 'pin', 4)]
+    assert np.all((u >= 0) & (u < 1)) and np.all(u * (1 << 24) == np.floor(u * (1 << 24)))
+    x = synth.synth_input(3, (1, 3, 8, 8))
+    assert x.dtype == np.float32 and x.min() >= 0 and x.max() < 1
+
+
+def test_cabi_exports_every_declared_symbol():
+    """The shared library loads (no GPU needed) and exports every function include/femasr_hip.h declares."""
+    from femasr_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'femasr_hip.h')).read()
+    declared = set(re.findall(r'\b(femasr_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'femasr_status'}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.femasr_version() >= 100

@@ -1,0 +1,68 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the REFERENCE itself
+(tests/golden/make_golden.py imports /root/reference and records its outputs).
+Tolerance: 1e-3 max-abs fp32 on outputs (north-star bound); VQ indices bit-exact, with the
+documented near-tie allowance (helpers.check_indices_near_tie) — every committed fixture
+currently matches with ZERO mismatches, which the tests assert."""
+import numpy as np
+import pytest
+
+from femasr_amd import synth
+from helpers import (cfg_name_of, check_indices_near_tie, load_golden, oracle_net, probe_err, synth_weights)
+
+TOL = 1e-3
+
+
+def _run(name):
+    g = load_golden(name)
+    cn = cfg_name_of(g)
+    net = oracle_net(cn, synth_weights(cn, int(g['seed']), str(g['codebook'])))
+    x = synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))
+    return g, net, x
+
+
+@pytest.mark.parametrize('name', ['x4_small_init', 'x4_small_trained', 'x2_small_trained'])
+def test_test_path_matches_reference(name):
+    g, net, x = _run(name)
+    net.probes = {}
+    y, idx = net.test(x, return_indices=True)
+    assert y.shape == tuple(g['out_shape'])
+    assert np.abs(y - g['output']).max() < TOL
+    nbad, nacc = check_indices_near_tie(idx, g)
+    assert nbad == 0, f'{nbad} index mismatches ({nacc} would be near-tie acceptable)'
+    assert idx.dtype == np.int64 and idx.shape == g['vq_indices'].shape
+    for k, v in net.probes.items():
+        if 'probe_pos_' + k in g:
+            err, scale = probe_err(g, k, v)
+            assert err <= 2e-5 * max(scale, 1.0), (k, err, scale)
+
+
+def test_hq_forward_matches_reference():
+    g, net, x = _run('hq_small_trained')
+    y, idx = net.forward(x)
+    assert np.abs(y - g['output']).max() < TOL
+    assert np.array_equal(idx, g['vq_indices'])
+
+
+def test_test_tile_matches_reference():
+    g, net, x = _run('x4_tiled_trained')
+    y = net.test_tile(x, int(g['kw_tile_size']), int(g['kw_tile_pad']))
+    assert y.shape == tuple(g['out_shape'])
+    assert np.abs(y - g['output']).max() < TOL
+
+
+def test_decode_indices_matches_reference():
+    g = load_golden('hq_decode_indices')
+    net = oracle_net('hq', synth_weights('hq', int(g['seed']), str(g['codebook'])))
+    y = net.decode_indices(g['indices'])
+    assert np.abs(y - g['output']).max() < TOL
+
+
+def test_full_tile_128_matches_reference():
+    """One full-size x4 tile (128x128 -> 512x512, 964 GFLOP): ~12 s of CPU."""
+    g, net, x = _run('x4_tile128_trained')
+    y, idx = net.test(x, return_indices=True)
+    st = int(g['out_stride'])
+    assert np.abs(y[:, :, ::st, ::st] - g['output']).max() < TOL
+    assert abs(float(y.astype(np.float64).mean()) - float(g['out_mean'])) < 1e-5
+    nbad, _ = check_indices_near_tie(idx, g)
+    assert nbad == 0

@@ -1,0 +1,139 @@
+"""Unit pins of the oracle's ops: against reference-module goldens (Swin block, VQ with exact ties)
+and against plain PyTorch fp32 ops of the same definition (conv, GroupNorm+SiLU, LayerNorm, GELU)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from femasr_amd import synth
+from helpers import load_golden
+from oracle import oracle as orc
+
+
+def test_math_spec_accuracy():
+    x = np.linspace(-12, 12, 100001).astype(np.float32)
+    xd = x.astype(np.float64)
+    assert np.max(np.abs(orc.math_eval('exp', x) - np.exp(xd)) / np.exp(xd)) < 4e-7
+    assert np.max(np.abs(orc.math_eval('erf', x) - np.vectorize(math.erf)(xd))) < 3e-7
+    silu = xd / (1 + np.exp(-xd))
+    assert np.max(np.abs(orc.math_eval('silu', x) - silu)) < 2e-6
+    gelu = 0.5 * xd * (1 + np.vectorize(math.erf)(xd / math.sqrt(2)))
+    assert np.max(np.abs(orc.math_eval('gelu', x) - gelu)) < 2e-6
+    # clamps: no inf / nan at the extremes
+    ext = np.array([-1e30, -200, -88, 88, 200, 1e30], np.float32)
+    for f in ('exp', 'erf', 'silu', 'gelu'):
+        assert np.all(np.isfinite(orc.math_eval(f, ext))), f
+
+
+def _torch_conv(x_nhwc, w_oihw, b, stride, pad, up2):
+    t = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2)
+    if up2:
+        t = F.interpolate(t, scale_factor=2)       # nn.Upsample default = nearest
+    y = F.conv2d(t, torch.from_numpy(w_oihw), torch.from_numpy(b), stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def test_conv_variants_match_torch():
+    cases = [  # (B,H,W,Cin,Cout,k,s,p,up2)
+        (2, 9, 11, 3, 40, 4, 1, 1, False),      # in_conv shape class (k4 p1, odd sizes)
+        (1, 13, 9, 32, 48, 3, 2, 1, False),     # stride-2 on odd input
+        (2, 6, 7, 64, 33, 3, 1, 1, True),       # fused nearest x2
+        (1, 5, 5, 96, 64, 1, 1, 0, False),      # 1x1
+        (1, 8, 8, 64, 3, 3, 1, 1, False),       # Cout = 3 (out_conv)
+    ]
+    for i, (b, h, w, ci, co, k, s, p, up) in enumerate(cases):
+        x = synth.uniform(i, 'cx', (b, h, w, ci), -1, 1)
+        wt = synth.uniform(i, 'cw', (co, ci, k, k), -0.2, 0.2)
+        bias = synth.uniform(i, 'cb', (co,), -0.5, 0.5)
+        y = orc.conv2d(x, orc.repack_conv_weight(wt), bias, k, s, p, up)
+        ref = _torch_conv(x, wt, bias, s, p, up)
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() < 2e-5, (i, np.abs(y - ref).max())
+
+
+def test_conv_epilogue_order():
+    x = synth.uniform(3, 'ex', (1, 4, 4, 32), -1, 1)
+    wt = synth.uniform(3, 'ew', (32, 32, 3, 3), -0.2, 0.2)
+    bias = synth.uniform(3, 'eb', (32,), -0.5, 0.5)
+    r1 = synth.uniform(3, 'r1', (1, 4, 4, 32), -1, 1)
+    r2 = synth.uniform(3, 'r2', (1, 4, 4, 32), -1, 1)
+    base = orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1)
+    full = orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, act=1, res1=r1, res2=r2)
+    expect = (orc.math_eval('gelu', base) + r1) + r2
+    assert np.array_equal(full, expect.astype(np.float32))
+
+
+def test_groupnorm_silu_matches_torch():
+    for c, seed in ((256, 0), (128, 1), (64, 2)):
+        x = synth.uniform(seed, 'gx', (2, 7, 9, c), -3, 5)
+        g = synth.uniform(seed, 'gg', (c,), 0.5, 1.5)
+        b = synth.uniform(seed, 'gb', (c,), -0.5, 0.5)
+        y = orc.gn_silu(x, g, b)
+        t = torch.from_numpy(x).permute(0, 3, 1, 2)
+        ref = F.silu(F.group_norm(t, 32, torch.from_numpy(g), torch.from_numpy(b), eps=1e-6))
+        assert np.abs(y - ref.permute(0, 2, 3, 1).numpy()).max() < 2e-5
+
+
+def test_layernorm_matches_torch():
+    x = synth.uniform(0, 'lx', (300, 256), -4, 6)
+    g = synth.uniform(0, 'lg', (256,), 0.5, 1.5)
+    b = synth.uniform(0, 'lb', (256,), -0.5, 0.5)
+    ref = F.layer_norm(torch.from_numpy(x), (256,), torch.from_numpy(g), torch.from_numpy(b), eps=1e-5).numpy()
+    assert np.abs(orc.layernorm(x, g, b) - ref).max() < 2e-5
+
+
+def _oracle_swin_block(x, w, shift, b, h, wd):
+    sd = {k: v for k, v in w.items()}
+    net = orc.OracleNet({'dummy': np.zeros(1)}, LQ_stage=True, scale_factor=4)
+    net.sd = {'blk.' + k: v for k, v in sd.items()}
+    return net._swin_block(x, b, h, wd, 'blk', shift)
+
+
+def test_swin_block_matches_reference_module():
+    """network_swinir.py:164-279 at x_size != input_resolution (mask recomputed), shift 0 and 4."""
+    g = load_golden('unit_swin_block')
+    keys = ['norm1.weight', 'norm1.bias', 'attn.relative_position_bias_table', 'attn.qkv.weight', 'attn.qkv.bias',
+            'attn.proj.weight', 'attn.proj.bias', 'norm2.weight', 'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias',
+            'mlp.fc2.weight', 'mlp.fc2.bias']
+    shapes = {'norm1.weight': (256,), 'norm1.bias': (256,), 'attn.relative_position_bias_table': (225, 8),
+              'attn.qkv.weight': (768, 256), 'attn.qkv.bias': (768,), 'attn.proj.weight': (256, 256),
+              'attn.proj.bias': (256,), 'norm2.weight': (256,), 'norm2.bias': (256,), 'mlp.fc1.weight': (1024, 256),
+              'mlp.fc1.bias': (1024,), 'mlp.fc2.weight': (256, 1024), 'mlp.fc2.bias': (256,)}
+    for shift in (0, 4):
+        seed = int(g[f'seed_shift{shift}'])
+        w = {k: synth.synth_tensor(seed, k, shapes[k]) for k in keys}
+        x = synth.uniform(int(g[f'xseed_shift{shift}']), 'swin.x', (2, 16 * 24, 256), -2.0, 2.0)
+        y = _oracle_swin_block(x, w, shift, 2, 16, 24)
+        assert np.abs(y - g[f'y_shift{shift}']).max() < 5e-5, shift
+
+
+def test_vq_exact_tie_first_index():
+    """femasr_arch.py:63-66: duplicated codebook rows -> torch.argmin returns the FIRST index."""
+    g = load_golden('unit_vq_tie')
+    cb = synth.uniform(5, 'vq.codebook', (1024, 512), -1.0, 1.0)
+    cb[700] = cb[13]
+    cb[901] = cb[13]
+    z = synth.uniform(6, 'vq.z', (2, 512, 5, 7), -1.0, 1.0)
+    z[0, :, 0, 0] = cb[13] * 0.97
+    z[1, :, 4, 6] = cb[700] * 1.02
+    rows = np.ascontiguousarray(z.transpose(0, 2, 3, 1)).reshape(-1, 512)
+    idx, zq, dmin, d2 = orc.vq(rows, cb, want_dists=True)
+    assert np.array_equal(idx.reshape(2, 1, 5, 7), g['indices'])
+    assert idx.reshape(2, 5, 7)[0, 0, 0] == 13 and idx.reshape(2, 5, 7)[1, 4, 6] == 13
+    assert dmin[0] == d2[0]                         # the tie is exact in the oracle too
+    zq_nchw = zq.reshape(2, 5, 7, 512).transpose(0, 3, 1, 2)
+    assert np.abs(zq_nchw - g['z_q']).max() < 1e-6
+    # straight-through is NOT a no-op in fp32 (hard part 2)
+    assert np.array_equal(zq, rows + (cb[idx] - rows))
+
+
+def test_pad_crop_geometry():
+    x = synth.uniform(0, 'px', (2, 3, 5, 7), 0, 1)
+    p = orc.pad_nchw_to_nhwc(x, 8, 12)
+    ref = torch.from_numpy(x)
+    ref = torch.cat([ref, torch.flip(ref, [2])], 2)[:, :, :8]
+    ref = torch.cat([ref, torch.flip(ref, [3])], 3)[:, :, :, :12]
+    assert np.array_equal(p, ref.permute(0, 2, 3, 1).numpy())
+    c = orc.crop_nhwc_to_nchw(p, 5, 7)
+    assert np.array_equal(c, x)
