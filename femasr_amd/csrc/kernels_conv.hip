@@ -48,7 +48,7 @@ constexpr int ALD = BK + 1;
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ>
+template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ, bool WVEC>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
 {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -100,32 +100,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
         }
     }
     const int Hv = p.up2 ? 2 * p.H : p.H, Wv = p.up2 ? 2 * p.W : p.W;
-    const bool wvec = (p.Cout & 3) == 0;
 
     float4 ra[AROWS], rga[AROWS], rgb[AROWS], rb[BUNITS];
     float4 lng, lnb;
-    unsigned amask = 0;
+    unsigned amask = 0, bmask = 0;
 
     // ---- global -> register staging of K-chunk c
     auto load_chunk = [&](int c) {
         amask = 0;
+        bmask = 0;
         if (CINVEC) {
             const int tap = c / p.cpt, c0 = (c - tap * p.cpt) * BK + 4 * kq;
             const int ky = tap / p.ksz, kx = tap - ky * p.ksz;
 #pragma unroll
             for (int j = 0; j < AROWS; ++j) {
+                // branch-free: out-of-image taps / tail rows read element 0 and are zeroed at store time,
+                // so all loads of a chunk issue back-to-back and stay in flight across the MFMA steps
                 const int iy = riy[j] + ky, ix = rix[j] + kx;
                 const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
-                if (ok) {
-                    const int sy = p.up2 ? (iy >> 1) : iy, sx = p.up2 ? (ix >> 1) : ix;
-                    const size_t off = (((size_t)rn[j] * p.H + sy) * p.W + sx) * p.Cin + c0;
-                    ra[j] = ld4(p.in + off);
-                    if (PRO == FEMASR_PRO_GN_SILU) {
-                        rga[j] = ld4(p.pro_a + (size_t)rn[j] * p.Cin + c0);
-                        rgb[j] = ld4(p.pro_b + (size_t)rn[j] * p.Cin + c0);
-                    }
-                    amask |= 1u << j;
+                const int sy = p.up2 ? (iy >> 1) : iy, sx = p.up2 ? (ix >> 1) : ix;
+                const size_t off = ok ? ((((size_t)rn[j] * p.H + sy) * p.W + sx) * p.Cin + c0) : (size_t)0;
+                ra[j] = ld4(p.in + off);
+                if (PRO == FEMASR_PRO_GN_SILU) {
+                    rga[j] = ld4(p.pro_a + (size_t)rn[j] * p.Cin + c0);
+                    rgb[j] = ld4(p.pro_b + (size_t)rn[j] * p.Cin + c0);
                 }
+                amask |= (ok ? 1u : 0u) << j;
             }
             if (PRO == FEMASR_PRO_LN) {
                 lng = ld4(p.pro_b + c0);
@@ -158,12 +158,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
             const int unit = t + 256 * u;
             const int nq = unit % (BN / 4), kr = unit / (BN / 4);
             const int k = c * BK + kr, n = n0 + 4 * nq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < p.K) {
-                const float *wp = p.w + (size_t)k * p.Cout + n;
-                if (wvec) {
-                    if (n < p.Cout) v = ld4(wp);
-                } else {
+            float4 v;
+            if (WVEC) {
+                // Cout % 4 == 0: one 16-B load; rows past K / columns past Cout read row 0 and are zeroed
+                const bool ok = (k < p.K) & (n < p.Cout);
+                v = ld4(p.w + (ok ? ((size_t)k * p.Cout + n) : (size_t)0));
+                bmask |= (ok ? 1u : 0u) << u;          // zeroed at store time (keeps the load in flight)
+            } else {
+                v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < p.K) {
+                    const float *wp = p.w + (size_t)k * p.Cout + n;
                     if (n + 0 < p.Cout) v.x = wp[0];
                     if (n + 1 < p.Cout) v.y = wp[1];
                     if (n + 2 < p.Cout) v.z = wp[2];
@@ -180,21 +184,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
         float *Bb = Bs + buf * BK * BN;
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (amask & (1u << j)) {
-                v = ra[j];
-                if (PRO == FEMASR_PRO_GN_SILU) {
-                    v.x = det_silu(__builtin_fmaf(v.x, rga[j].x, rgb[j].x));
-                    v.y = det_silu(__builtin_fmaf(v.y, rga[j].y, rgb[j].y));
-                    v.z = det_silu(__builtin_fmaf(v.z, rga[j].z, rgb[j].z));
-                    v.w = det_silu(__builtin_fmaf(v.w, rga[j].w, rgb[j].w));
-                } else if (PRO == FEMASR_PRO_LN) {
-                    v.x = __builtin_fmaf((v.x - lmean[j]) * lrstd[j], lng.x, lnb.x);
-                    v.y = __builtin_fmaf((v.y - lmean[j]) * lrstd[j], lng.y, lnb.y);
-                    v.z = __builtin_fmaf((v.z - lmean[j]) * lrstd[j], lng.z, lnb.z);
-                    v.w = __builtin_fmaf((v.w - lmean[j]) * lrstd[j], lng.w, lnb.w);
-                }
+            float4 v = ra[j];
+            if (PRO == FEMASR_PRO_GN_SILU) {
+                v.x = det_silu(__builtin_fmaf(v.x, rga[j].x, rgb[j].x));
+                v.y = det_silu(__builtin_fmaf(v.y, rga[j].y, rgb[j].y));
+                v.z = det_silu(__builtin_fmaf(v.z, rga[j].z, rgb[j].z));
+                v.w = det_silu(__builtin_fmaf(v.w, rga[j].w, rgb[j].w));
+            } else if (PRO == FEMASR_PRO_LN) {
+                v.x = __builtin_fmaf((v.x - lmean[j]) * lrstd[j], lng.x, lnb.x);
+                v.y = __builtin_fmaf((v.y - lmean[j]) * lrstd[j], lng.y, lnb.y);
+                v.z = __builtin_fmaf((v.z - lmean[j]) * lrstd[j], lng.z, lnb.z);
+                v.w = __builtin_fmaf((v.w - lmean[j]) * lrstd[j], lng.w, lnb.w);
             }
+            if (!(amask & (1u << j))) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
             float *dst = Ab + (mrow + 32 * j) * ALD + 4 * kq;
             dst[0] = v.x;
             dst[1] = v.y;
@@ -205,7 +207,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
         for (int u = 0; u < BUNITS; ++u) {
             const int unit = t + 256 * u;
             const int nq = unit % (BN / 4), kr = unit / (BN / 4);
-            *reinterpret_cast<float4 *>(Bb + kr * BN + 4 * nq) = rb[u];
+            float4 v = rb[u];
+            if (WVEC && !(bmask & (1u << u))) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(Bb + kr * BN + 4 * nq) = v;
         }
     };
 
@@ -327,34 +331,35 @@ struct Variant {
     bool attr_set;
 };
 
-#define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ)                                                   \
-    { "conv_igemm<" #BM "x" #BN "," #PRO "," #VEC "," #VQ ">", BM, BN,                                 \
-      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ>, conv_lds_bytes<BM, BN>(), false }
+#define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ, WVEC)                                             \
+    { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",wvec=" #WVEC ">", BM, BN,        \
+      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ, WVEC>, conv_lds_bytes<BM, BN>(), false }
 
 Variant g_variants[] = {
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, false),     // 0
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_GN_SILU, true, false),  // 1
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_LN, true, false),       // 2
-    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, true, false),      // 3
-    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_GN_SILU, true, false),   // 4
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false),      // 5
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_GN_SILU, true, false),   // 6
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, false, false),    // 7  generic Cin (in_conv)
-    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, false, false),     // 8
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, true),      // 9  VQ distance + argmin
-    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_LN, true, false),        // 10
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false),        // 11
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, false, true),     // 0
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_GN_SILU, true, false, true),  // 1
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_LN, true, false, true),       // 2
+    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, true, false, true),      // 3
+    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_GN_SILU, true, false, true),   // 4
+    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_LN, true, false, true),        // 5
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false, false),     // 6  any Cout (out_conv: Cout = 3)
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_GN_SILU, true, false, false),  // 7
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false, false),       // 8
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, false, false, true),    // 9  generic Cin (in_conv)
+    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, false, false, true),     // 10
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false, false, false),    // 11
+    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, true, true),      // 12 VQ distance + argmin
 };
 constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
 
 int pick_variant(const femasr_conv_args *a, bool vq)
 {
     const bool vec = (a->Cin % BK) == 0;
-    if (vq) return 9;
-    if (!vec) return a->Cout > 64 ? 7 : 8;
-    const int cls = a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2);
-    static const int table[3][3] = {{0, 1, 2}, {3, 4, 10}, {5, 6, 11}};
-    return table[cls][a->prologue];
+    if (vq) return 12;
+    // BN by Cout; the 16-byte weight loads need Cout % 4 == 0, anything else goes to the BN=32 scalar-load variants
+    const int cls = (a->Cout & 3) ? 2 : (a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2));
+    if (!vec) return 9 + cls;
+    return cls * 3 + a->prologue;
 }
 
 }  // namespace

@@ -49,9 +49,11 @@ def test_hq_forward_and_decode_indices(cuda_device):
     assert np.array_equal(idx, g['vq_indices'])
     yo, io = oracle_net(cn, w).forward(x)
     assert np.array_equal(idx, io) and np.array_equal(y, yo)
-    # decode_indices(indices) reproduces the decoder half exactly (same kernels, same order)
+    # decode_indices(indices): bit-exact vs the oracle's decode_indices; vs forward() only CLOSE, because forward feeds
+    # the straight-through z + (e - z) (femasr_arch.py:95), which is not bit-equal to e (hard part 2)
     y2 = net.decode_indices(idx_list[0]).cpu().numpy()
-    assert np.array_equal(y2, y)
+    assert np.array_equal(y2, oracle_net(cn, w).decode_indices(idx))
+    assert np.abs(y2 - y).max() < 1e-5
     # and matches the reference's decode_indices golden
     gd = load_golden('hq_decode_indices')
     import gpu_utils as G
