@@ -100,7 +100,7 @@ def main():
     }
     if rank == 0:
         if prof:
-            convs = {k: v for k, v in prof.items() if k.startswith('conv_igemm')}
+            convs = {k: v for k, v in prof.items() if k.startswith('conv')}      # conv_igemm<..> and conv3x3_halo<..>: the MFMA kernels
             dom = max(convs, key=lambda k: convs[k][0])
             ms, n, fl, _ = convs[dom]
             tot_ms = sum(v[0] for v in convs.values())
@@ -110,7 +110,7 @@ def main():
                 'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
                 'launches': n, 'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
-                'all_conv_igemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                'all_mfma_conv_kernels': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                    'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                    'share_of_step_time': round(tot_ms / (dt * 1e3), 4)},
                 'per_kernel_ms_per_step': {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},

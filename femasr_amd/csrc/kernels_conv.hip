@@ -40,7 +40,8 @@ struct ConvParams {
     float *vq_part;
     int vq_nblk;
     int B, H, W, Cin, Cout, ksz, stride, pad, up2, act, Ho, Wo;
-    int M, K, nchunks, cpt, MB, NB;
+    int M, K, nchunks, taps, MB, NB;
+    int tilesX, tilesY;
 };
 
 constexpr int BK = 32;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
         amask = 0;
         bmask = 0;
         if (CINVEC) {
-            const int tap = c / p.cpt, c0 = (c - tap * p.cpt) * BK + 4 * kq;
+            const int cc = c / p.taps, tap = c - cc * p.taps, c0 = cc * BK + 4 * kq;   // K order: (cin/32, ky, kx, cin%32)
             const int ky = tap / p.ksz, kx = tap - ky * p.ksz;
 #pragma unroll
             for (int j = 0; j < AROWS; ++j) {
@@ -320,6 +321,224 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 convolution with HALO RE-USE (the 753 of 964 GFLOP per tile that are 3x3 convs).
+// A block owns an 8 x 16 patch of output pixels of ONE image (BM = 128) and BN output channels.  For
+// each 32-channel block of the input it stages the (8+2) x (16+2) input halo patch (6 x 10 low-res
+// pixels when the nearest-x2 upsample is fused) ONCE — GroupNorm-apply + SiLU evaluated once per
+// staged element — and sweeps all 9 taps over it straight from LDS: the MFMA A-fragment of tap
+// (ky,kx) is the same LDS image read at a shifted pixel.  Versus the im2col kernel above this cuts
+// global loads, prologue VALU work and LDS stores per MFMA by 6.4x (9 x 128 -> 180 pixel-chunks).
+// K order = (cin/32, ky, kx, cin%32): exactly the oracle's blocked fmaf chain.
+// Pipeline: weights of the next (channel-block, tap) and — at tap 0 — the next channel block's
+// patch are loaded to registers before the 16 MFMA k-pair steps and written to the alternate LDS
+// buffers after them; one barrier per tap.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int WM, int WN, int PRO, bool UP2, bool WVEC>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvParams p)
+{
+    constexpr int BM = 128, TW = 16;
+    constexpr int PH = UP2 ? 6 : 10, PW = UP2 ? 10 : 18, PP = PH * PW;
+    constexpr int PUNITS = (PP * 8 + 255) / 256;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int BUNITS = (BK * BN / 4) / 256;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BUNITS >= 1, "tile config");
+    static_assert(PRO != FEMASR_PRO_LN, "no LayerNorm prologue on 3x3 convs");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PSZ = ((PP * ALD + 3) / 4) * 4;
+    float *Ps = smem;               // [2][PP][ALD]
+    float *Bs = smem + 2 * PSZ;     // [2][BK][BN]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    int L;
+    {
+        const int nblk = p.MB * p.NB, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int nb = L % p.NB;
+    int tile = L / p.NB;
+    const int tx = tile % p.tilesX;
+    tile /= p.tilesX;
+    const int ty = tile % p.tilesY;
+    const int n = tile / p.tilesY;
+    const int oy0 = ty * 8, ox0 = tx * TW, n0 = nb * BN;
+    const int sy0 = UP2 ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UP2 ? (ox0 >> 1) - 1 : ox0 - 1;
+
+    // ---- this thread's patch units: (pixel = (t>>3) + 32 i, channel quad kq)
+    const int kq = t & 7;
+    unsigned poff[PUNITS];
+    unsigned pmask = 0;
+#pragma unroll
+    for (int i = 0; i < PUNITS; ++i) {
+        const int pix = (t >> 3) + 32 * i;
+        const int ppy = pix / PW, ppx = pix - ppy * PW;
+        const int sy = sy0 + ppy, sx = sx0 + ppx;
+        const bool ok = (pix < PP) & (sy >= 0) & (sy < p.H) & (sx >= 0) & (sx < p.W);
+        poff[i] = ok ? (unsigned)((((size_t)n * p.H + sy) * p.W + sx) * p.Cin + 4 * kq) : 0u;
+        pmask |= (ok ? 1u : 0u) << i;
+    }
+
+    float4 rp[PUNITS], rb[BUNITS], ga, gb;
+    unsigned bmask = 0;
+
+    auto load_patch = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < PUNITS; ++i) rp[i] = ld4(p.in + (size_t)poff[i] + (size_t)cc * BK);
+        if (PRO == FEMASR_PRO_GN_SILU) {
+            ga = ld4(p.pro_a + (size_t)n * p.Cin + cc * BK + 4 * kq);
+            gb = ld4(p.pro_b + (size_t)n * p.Cin + cc * BK + 4 * kq);
+        }
+    };
+    auto store_patch = [&](int buf) {
+        float *Pb = Ps + buf * PSZ;
+#pragma unroll
+        for (int i = 0; i < PUNITS; ++i) {
+            const int pix = (t >> 3) + 32 * i;
+            if (PP % 32 != 0 && i == PUNITS - 1 && pix >= PP) break;     // tail units of the last round
+            float4 v = rp[i];
+            if (PRO == FEMASR_PRO_GN_SILU) {
+                v.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
+                v.y = det_silu(__builtin_fmaf(v.y, ga.y, gb.y));
+                v.z = det_silu(__builtin_fmaf(v.z, ga.z, gb.z));
+                v.w = det_silu(__builtin_fmaf(v.w, ga.w, gb.w));
+            }
+            if (!(pmask & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding AFTER the activation
+            float *dst = Pb + pix * ALD + 4 * kq;
+            dst[0] = v.x;
+            dst[1] = v.y;
+            dst[2] = v.z;
+            dst[3] = v.w;
+        }
+    };
+    auto load_w = [&](int q) {      // q = cc * 9 + tap : rows q*32 .. q*32+31 of the repacked weights
+        bmask = 0;
+#pragma unroll
+        for (int u = 0; u < BUNITS; ++u) {
+            const int unit = t + 256 * u;
+            const int nq = unit % (BN / 4), kr = unit / (BN / 4);
+            const int k = q * BK + kr, nn = n0 + 4 * nq;
+            float4 v;
+            if (WVEC) {
+                const bool ok = nn < p.Cout;
+                v = ld4(p.w + (ok ? ((size_t)k * p.Cout + nn) : (size_t)0));
+                bmask |= (ok ? 1u : 0u) << u;
+            } else {
+                v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float *wp = p.w + (size_t)k * p.Cout + nn;
+                if (nn + 0 < p.Cout) v.x = wp[0];
+                if (nn + 1 < p.Cout) v.y = wp[1];
+                if (nn + 2 < p.Cout) v.z = wp[2];
+                if (nn + 3 < p.Cout) v.w = wp[3];
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+        float *Bb = Bs + buf * BK * BN;
+#pragma unroll
+        for (int u = 0; u < BUNITS; ++u) {
+            const int unit = t + 256 * u;
+            const int nq = unit % (BN / 4), kr = unit / (BN / 4);
+            float4 v = rb[u];
+            if (WVEC && !(bmask & (1u << u))) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(Bb + kr * BN + 4 * nq) = v;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ncc = p.Cin / BK;
+    load_patch(0);
+    load_w(0);
+    store_patch(0);
+    store_w(0);
+    __syncthreads();
+
+    // lane's output pixels: m_i = (wm*TM + i)*32 + (lane&31) -> (py, px) = (m >> 4, m & 15)
+    int py[TM], px;
+    {
+        const int m = wm * TM * 32 + (lane & 31);
+        px = m & 15;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) py[i] = (m >> 4) + 2 * i;
+    }
+    const int bcol = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+
+    for (int cc = 0; cc < ncc; ++cc) {
+        const float *Pb = Ps + (cc & 1) * PSZ + (lane >> 5);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int q = cc * 9 + tap;
+            const bool more_w = (q + 1) < ncc * 9;
+            const bool more_p = (tap == 0) && (cc + 1 < ncc);
+            if (more_w) load_w(q + 1);
+            if (more_p) load_patch(cc + 1);
+            const int ky = tap / 3, kx = tap - ky * 3;
+            int aidx[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int prow = UP2 ? ((py[i] + ky - 1) >> 1) + 1 : py[i] + ky;
+                const int pcol = UP2 ? ((px + kx - 1) >> 1) + 1 : px + kx;
+                aidx[i] = (prow * PW + pcol) * ALD;
+            }
+            const float *Bb = Bs + (q & 1) * BK * BN + bcol;
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = Pb[aidx[i] + 2 * kk];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = Bb[2 * kk * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (more_w) store_w((q + 1) & 1);
+            if (more_p) store_patch((cc + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const float bv = col < p.Cout ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+                if (oy < p.Ho && ox < p.Wo && col < p.Cout) {
+                    float v = acc[i][j][r] + bv;
+                    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
+                    if (p.res1) v = v + p.res1[o];
+                    if (p.res2) v = v + p.res2[o];
+                    p.out[o] = v;
+                }
+            }
+        }
+}
+
+template <int BN, bool UP2>
+constexpr size_t halo_lds_bytes()
+{
+    return (size_t)(2 * ((((UP2 ? 60 : 180) * ALD + 3) / 4) * 4) + 2 * BK * BN) * sizeof(float);
+}
+
 template <int BM, int BN>
 constexpr size_t conv_lds_bytes() { return (size_t)(2 * BM * ALD + 2 * BK * BN) * sizeof(float); }
 
@@ -335,6 +554,10 @@ struct Variant {
     { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",wvec=" #WVEC ">", BM, BN,        \
       conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ, WVEC>, conv_lds_bytes<BM, BN>(), false }
 
+#define FEMASR_HALO(BN, WM, WN, PRO, UP2, WVEC)                                                        \
+    { "conv3x3_halo<8x16x" #BN "," #PRO ",up2=" #UP2 ",wvec=" #WVEC ">", 128, BN,                      \
+      conv3x3_halo_kernel<BN, WM, WN, PRO, UP2, WVEC>, halo_lds_bytes<BN, UP2>(), false }
+
 Variant g_variants[] = {
     FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, false, true),     // 0
     FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_GN_SILU, true, false, true),  // 1
@@ -349,8 +572,24 @@ Variant g_variants[] = {
     FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, false, false, true),     // 10
     FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false, false, false),    // 11
     FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, true, true),      // 12 VQ distance + argmin
+    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, false, true),                   // 13 3x3 s1 halo kernels
+    FEMASR_HALO(128, 2, 2, FEMASR_PRO_GN_SILU, false, true),                // 14
+    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, true, true),                    // 15 fused nearest-x2
+    FEMASR_HALO(64, 4, 1, FEMASR_PRO_NONE, false, true),                    // 16
+    FEMASR_HALO(64, 4, 1, FEMASR_PRO_GN_SILU, false, true),                 // 17
+    FEMASR_HALO(64, 4, 1, FEMASR_PRO_NONE, true, true),                     // 18
+    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, false, false),                   // 19 any Cout (out_conv)
+    FEMASR_HALO(32, 4, 1, FEMASR_PRO_GN_SILU, false, false),                // 20
+    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, true, false),                    // 21
 };
 constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
+
+bool use_halo(const femasr_conv_args *a, bool vq)
+{
+    return !vq && a->ksz == 3 && a->stride == 1 && a->pad == 1 && (a->Cin % BK) == 0 && a->prologue != FEMASR_PRO_LN &&
+           a->act == FEMASR_ACT_NONE && !(a->up2 && a->prologue != FEMASR_PRO_NONE) &&
+           (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31);
+}
 
 int pick_variant(const femasr_conv_args *a, bool vq)
 {
@@ -358,6 +597,7 @@ int pick_variant(const femasr_conv_args *a, bool vq)
     if (vq) return 12;
     // BN by Cout; the 16-byte weight loads need Cout % 4 == 0, anything else goes to the BN=32 scalar-load variants
     const int cls = (a->Cout & 3) ? 2 : (a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2));
+    if (use_halo(a, vq)) return 13 + cls * 3 + (a->up2 ? 2 : a->prologue);
     if (!vec) return 9 + cls;
     return cls * 3 + a->prologue;
 }
@@ -391,11 +631,16 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.ksz = a->ksz; p.stride = a->stride;
     p.pad = a->pad; p.up2 = a->up2; p.act = a->act; p.Ho = Ho; p.Wo = Wo;
-    p.M = (int)M; p.K = a->ksz * a->ksz * a->Cin; p.nchunks = (p.K + BK - 1) / BK; p.cpt = vec ? a->Cin / BK : 1;
+    p.M = (int)M; p.K = a->ksz * a->ksz * a->Cin; p.nchunks = (p.K + BK - 1) / BK; p.taps = a->ksz * a->ksz;
     const int vi = pick_variant(a, vq != nullptr);
     Variant &v = g_variants[vi];
     p.MB = (p.M + v.bm - 1) / v.bm;
     p.NB = (p.Cout + v.bn - 1) / v.bn;
+    if (vi >= 13) {   // halo kernels: 2-D tiles of 8 x 16 output pixels per image
+        p.tilesX = (Wo + 15) / 16;
+        p.tilesY = (Ho + 7) / 8;
+        p.MB = a->B * p.tilesX * p.tilesY;
+    }
     if (vq) {
         FEMASR_REQUIRE(vq->zz && vq->ee && vq->part && vq->nblk == p.NB && (a->Cout % 32) == 0, "vq epilogue: bad args");
         p.vq_zz = vq->zz; p.vq_ee = vq->ee; p.vq_part = vq->part; p.vq_nblk = vq->nblk;

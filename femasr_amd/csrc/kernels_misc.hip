@@ -332,17 +332,31 @@ __global__ void codebook_gather_kernel(const long long *__restrict__ idx, long l
         *reinterpret_cast<float4 *>(zq + (size_t)row * D + c) = ld4(cb + (size_t)i * D + c);
 }
 
-// OIHW -> [kh][kw][I][O]; thread per OUTPUT element (coalesced stores)
+// OIHW -> the library's K-major weight layout, rows = K index, O contiguous:
+//   I % 32 == 0:  k = ((ci/32)*kh*kw + y*kw + x)*32 + ci%32      (channel blocks outermost)
+//   otherwise  :  k = (y*kw + x)*I + ci
+// thread per OUTPUT element (coalesced stores)
 __global__ void repack_oihw_kernel(const float *__restrict__ in, int O, int I, int kh, int kw, float *__restrict__ out,
                                    size_t total)
 {
+    const bool blocked = (I % 32) == 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int o = (int)(i % O);
-        size_t r = i / O;
-        const int ci = (int)(r % I);
-        r /= I;
-        const int x = (int)(r % kw);
-        const int y = (int)(r / kw);
+        size_t k = i / O;
+        int ci, x, y;
+        if (blocked) {
+            const int cl = (int)(k % 32);
+            k /= 32;
+            x = (int)(k % kw);
+            k /= kw;
+            y = (int)(k % kh);
+            ci = (int)(k / kh) * 32 + cl;
+        } else {
+            ci = (int)(k % I);
+            k /= I;
+            x = (int)(k % kw);
+            y = (int)(k / kw);
+        }
         out[i] = in[(((size_t)o * I + ci) * kh + y) * kw + x];
     }
 }

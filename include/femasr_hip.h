@@ -68,7 +68,7 @@ int femasr_num_weights(const femasr_handle *h);
 int femasr_weight_info(const femasr_handle *h, int i, const char **key, int64_t shape[4], int *ndim);
 
 /* Copy one fp32 tensor (device pointer, torch layout: conv OIHW, linear (out,in), vectors)
- * into the handle, repacking conv/linear weights to [kh][kw][Cin][Cout].
+ * into the handle, repacking conv/linear weights to the K-major layout of femasr_conv_args.w.
  * Replaces nn.Module.load_state_dict for the path (inference_femasr.py:40). */
 int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr,
                       const int64_t *shape, int ndim);
@@ -118,7 +118,8 @@ enum { FEMASR_ACT_NONE = 0, FEMASR_ACT_GELU = 1 };
 typedef struct {
     const float *in;      /* (B,H,W,Cin) NHWC, pre-upsample size */
     int32_t B, H, W, Cin;
-    const float *w;       /* [ksz][ksz][Cin][Cout] */
+    const float *w;       /* K-major rows x Cout: k = ((ci/32)*ksz*ksz + ky*ksz + kx)*32 + ci%32 when
+                             Cin % 32 == 0, else k = (ky*ksz + kx)*Cin + ci  (what femasr_repack_oihw emits) */
     const float *bias;    /* [Cout] */
     int32_t Cout, ksz, stride, pad, up2;
     int32_t prologue;     /* FEMASR_PRO_* */
@@ -150,7 +151,8 @@ int femasr_vq(void *stream, const float *z, int64_t M, int D, const float *cb, c
               const float *ee, int n_e, int64_t *idx, float *zq, void *scratch);
 int femasr_row_sqsum(void *stream, const float *x, int64_t rows, int D, float *out);
 int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, const float *cb, int n_e, float *zq);
-/* OIHW -> [kh][kw][I][O] repack (also (out,in)->(in,out) with kh=kw=1, and codebook^T). */
+/* OIHW -> the K-major weight layout of femasr_conv_args.w (also (out,in)->(in,out) with kh=kw=1, and
+ * codebook^T). */
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out);
 
 #ifdef __cplusplus

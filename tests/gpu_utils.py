@@ -11,10 +11,20 @@ def dev(a, device='cuda'):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
+def lib_weight_layout(w_khwc):
+    """Oracle layout [kh][kw][Cin][Cout] -> the library's K-major rows (include/femasr_hip.h, femasr_conv_args.w):
+    channel blocks of 32 outermost when Cin % 32 == 0, plain (ky,kx,cin) otherwise."""
+    kh, kw, cin, cout = w_khwc.shape
+    if cin % 32:
+        return np.ascontiguousarray(w_khwc)
+    return np.ascontiguousarray(w_khwc.reshape(kh, kw, cin // 32, 32, cout).transpose(2, 0, 1, 3, 4))
+
+
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
            res1=None, res2=None):
-    """x NHWC numpy -> numpy, through femasr_conv2d."""
+    """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout)."""
     lib = _lib.load()
+    w_khwc = lib_weight_layout(np.asarray(w_khwc))
     b, h, w, cin = x.shape
     cout = w_khwc.shape[-1]
     hv, wv = (2 * h, 2 * w) if up2 else (h, w)

@@ -57,6 +57,10 @@ CONV_CASES = [
     ('cout64', (1, 20, 24, 128), 64, 3, 1, 1, True),
     ('cout3', (2, 24, 20, 64), 3, 3, 1, 1, False),
     ('tiny_m', (1, 3, 5, 32), 96, 3, 1, 1, False),
+    ('halo_edges_17x23', (2, 17, 23, 64), 128, 3, 1, 1, False),      # tiles overhang both edges
+    ('halo_up2_odd', (1, 7, 9, 128), 64, 3, 1, 1, True),              # fused x2, 14x18 output
+    ('halo_up2_cout3', (1, 5, 6, 32), 3, 3, 1, 1, True),
+    ('k3_no_pad', (1, 12, 12, 64), 64, 3, 1, 0, False),               # pad 0 -> im2col kernel
 ]
 
 
@@ -163,6 +167,19 @@ def test_vq_bit_exact_and_first_min_tie(cuda_device):
     idx2, zq2, _, _ = G.vq(z2, cb2)
     _same(idx2, idx_ref2, 'vq indices (init codebook)')
     _same(zq2, zq_ref2, 'vq z_q (init codebook)')
+
+
+def test_repack_oihw_layout(cuda_device):
+    """femasr_repack_oihw (what set_weight runs) == the documented K-major layout."""
+    import gpu_utils as G
+    lib = _lib.load()
+    for (o, i, k) in ((40, 64, 3), (8, 3, 4), (16, 96, 1)):
+        w = synth.uniform(9, f'rw{o}{i}{k}', (o, i, k, k), -1, 1)
+        tw = G.dev(w)
+        out = torch.empty(o * i * k * k, dtype=torch.float32, device='cuda')
+        _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(tw), o, i, k, k, _lib.ptr(out)))
+        ref = G.lib_weight_layout(orc.repack_conv_weight(w)).reshape(-1)
+        _same(out.cpu().numpy(), ref, f'repack {o}x{i}x{k}')
 
 
 def test_bad_arguments_are_refused(cuda_device):
