@@ -50,6 +50,7 @@ SIGNATURES = {
     'femasr_weight_info': (c_int, [vp, c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i64 * 4), ctypes.POINTER(c_int)]),
     'femasr_set_weight': (c_int, [vp, ctypes.c_char_p, vp, ctypes.POINTER(c_i64), c_int]),
     'femasr_finalize_weights': (c_int, [vp]),
+    'femasr_set_streams': (c_int, [vp, c_int]),
     'femasr_workspace_bytes': (c_int, [vp, c_int, c_int, c_int, c_int, ctypes.POINTER(szt)]),
     'femasr_forward': (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, szt]),
     'femasr_decode_workspace_bytes': (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(szt)]),

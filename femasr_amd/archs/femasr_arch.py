@@ -176,6 +176,8 @@ class FeMaSRNet(nn.Module):
         self._pushed = {}
         self._ws = None
         self.max_tile_batch = 16        # tiles per batched test() call inside test_tile
+        self.num_streams = 1            # sub-batch streams inside one forward (femasr_set_streams)
+        self._streams_set = None
 
     # ------------------------------------------------------------------ native handle
     def _native(self, device):
@@ -211,6 +213,9 @@ class FeMaSRNet(nn.Module):
             self._pushed[key] = stamp
         if dirty:
             _lib.check(lib.femasr_finalize_weights(self._handle))
+        if self._streams_set != (self._handle.value, self.num_streams):
+            _lib.check(lib.femasr_set_streams(self._handle, int(self.num_streams)))
+            self._streams_set = (self._handle.value, self.num_streams)
         return lib, self._handle
 
     def _release(self):

@@ -235,18 +235,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
         if (more) load_chunk(c + 1);
         const float *Ab = As + buf * BM * ALD + arow;
         const float *Bb = Bs + buf * BK * BN + bcol;
+        // fragments of k-pair kk+1 are fetched from LDS before the MFMAs of k-pair kk are issued, so one wave
+        // alone keeps its SIMD's matrix pipe fed (the LDS latency hides behind 4 x 64 cycles of MFMA)
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = Ab[i * 32 * ALD];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bb[j * 32];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float af[TM], bf[TN];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ab[i * 32 * ALD + 2 * kk];
+                for (int i = 0; i < TM; ++i) af[nxt][i] = Ab[i * 32 * ALD + 2 * (kk + 1)];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bb[2 * kk * BN + j * 32];
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = Bb[2 * (kk + 1) * BN + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this k-pair's MFMAs
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
@@ -336,14 +347,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
 // buffers after them; one barrier per tap.
 // ------------------------------------------------------------------------------------------------
 template <int BN, int WM, int WN, int PRO, bool UP2, bool WVEC>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvParams p)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_halo_kernel(const ConvParams p)
 {
     constexpr int BM = 128, TW = 16;
     constexpr int PH = UP2 ? 6 : 10, PW = UP2 ? 10 : 18, PP = PH * PW;
-    constexpr int PUNITS = (PP * 8 + 255) / 256;
+    constexpr int NT = WM * WN * 64;              // 256 (4 waves) or 512 (8 waves: 2 per SIMD inside the block)
+    constexpr int PUNITS = (PP * 8 + NT - 1) / NT;
+    constexpr int PROWS = NT / 8;                 // patch pixels covered per unit round
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int BUNITS = (BK * BN / 4) / 256;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BUNITS >= 1, "tile config");
+    constexpr int BUNITS = (BK * BN / 4) / NT;
+    static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && BUNITS >= 1, "tile config");
     static_assert(PRO != FEMASR_PRO_LN, "no LayerNorm prologue on 3x3 convs");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvParams p
     unsigned pmask = 0;
 #pragma unroll
     for (int i = 0; i < PUNITS; ++i) {
-        const int pix = (t >> 3) + 32 * i;
+        const int pix = (t >> 3) + PROWS * i;
         const int ppy = pix / PW, ppx = pix - ppy * PW;
         const int sy = sy0 + ppy, sx = sx0 + ppx;
         const bool ok = (pix < PP) & (sy >= 0) & (sy < p.H) & (sx >= 0) & (sx < p.W);
@@ -398,8 +411,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvParams p
         float *Pb = Ps + buf * PSZ;
 #pragma unroll
         for (int i = 0; i < PUNITS; ++i) {
-            const int pix = (t >> 3) + 32 * i;
-            if (PP % 32 != 0 && i == PUNITS - 1 && pix >= PP) break;     // tail units of the last round
+            const int pix = (t >> 3) + PROWS * i;
+            if (PP % PROWS != 0 && i == PUNITS - 1 && pix >= PP) break;     // tail units of the last round
             float4 v = rp[i];
             if (PRO == FEMASR_PRO_GN_SILU) {
                 v.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvParams p
         bmask = 0;
 #pragma unroll
         for (int u = 0; u < BUNITS; ++u) {
-            const int unit = t + 256 * u;
+            const int unit = t + NT * u;
             const int nq = unit % (BN / 4), kr = unit / (BN / 4);
             const int k = q * BK + kr, nn = n0 + 4 * nq;
             float4 v;
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvParams p
         float *Bb = Bs + buf * BK * BN;
 #pragma unroll
         for (int u = 0; u < BUNITS; ++u) {
-            const int unit = t + 256 * u;
+            const int unit = t + NT * u;
             const int nq = unit % (BN / 4), kr = unit / (BN / 4);
             float4 v = rb[u];
             if (WVEC && !(bmask & (1u << u))) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -493,18 +506,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvParams p
                 aidx[i] = (prow * PW + pcol) * ALD;
             }
             const float *Bb = Bs + (q & 1) * BK * BN + bcol;
+            float af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][i] = Pb[aidx[i]];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = Bb[j * 32];
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
-                float af[TM], bf[TN];
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < BK / 2) {     // prefetch the next k-pair's fragments before issuing this one's MFMAs
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = Pb[aidx[i] + 2 * kk];
+                    for (int i = 0; i < TM; ++i) af[nxt][i] = Pb[aidx[i] + 2 * (kk + 1)];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Bb[2 * kk * BN + j * 32];
+                    for (int j = 0; j < TN; ++j) bf[nxt][j] = Bb[2 * (kk + 1) * BN + j * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of this k-pair's MFMAs
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (more_w) store_w((q + 1) & 1);
             if (more_p) store_patch((cc + 1) & 1);
@@ -548,15 +570,16 @@ struct Variant {
     void (*kern)(const ConvParams);
     size_t lds;
     bool attr_set;
+    int threads;
 };
 
 #define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ, WVEC)                                             \
     { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",wvec=" #WVEC ">", BM, BN,        \
-      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ, WVEC>, conv_lds_bytes<BM, BN>(), false }
+      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ, WVEC>, conv_lds_bytes<BM, BN>(), false, 256 }
 
 #define FEMASR_HALO(BN, WM, WN, PRO, UP2, WVEC)                                                        \
-    { "conv3x3_halo<8x16x" #BN "," #PRO ",up2=" #UP2 ",wvec=" #WVEC ">", 128, BN,                      \
-      conv3x3_halo_kernel<BN, WM, WN, PRO, UP2, WVEC>, halo_lds_bytes<BN, UP2>(), false }
+    { "conv3x3_halo<8x16x" #BN "," #PRO ",up2=" #UP2 ",wvec=" #WVEC ",waves=" #WM "x" #WN ">", 128, BN,                      \
+      conv3x3_halo_kernel<BN, WM, WN, PRO, UP2, WVEC>, halo_lds_bytes<BN, UP2>(), false, WM * WN * 64 }
 
 Variant g_variants[] = {
     FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, false, true),     // 0
@@ -573,10 +596,10 @@ Variant g_variants[] = {
     FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false, false, false),    // 11
     FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, true, true),      // 12 VQ distance + argmin
     FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, false, true),                   // 13 3x3 s1 halo kernels
-    FEMASR_HALO(128, 2, 2, FEMASR_PRO_GN_SILU, false, true),                // 14
+    FEMASR_HALO(128, 4, 2, FEMASR_PRO_GN_SILU, false, true),                // 14 (8 waves)
     FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, true, true),                    // 15 fused nearest-x2
     FEMASR_HALO(64, 4, 1, FEMASR_PRO_NONE, false, true),                    // 16
-    FEMASR_HALO(64, 4, 1, FEMASR_PRO_GN_SILU, false, true),                 // 17
+    FEMASR_HALO(64, 4, 2, FEMASR_PRO_GN_SILU, false, true),                 // 17 (8 waves)
     FEMASR_HALO(64, 4, 1, FEMASR_PRO_NONE, true, true),                     // 18
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, false, false),                   // 19 any Cout (out_conv)
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_GN_SILU, false, false),                // 20
@@ -649,7 +672,7 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
         v.attr_set = true;
     }
-    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(256), v.lds, s, p);
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), v.lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
     if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K;

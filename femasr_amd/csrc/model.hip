@@ -140,10 +140,12 @@ struct femasr_handle {
     std::vector<double> acc_ms, acc_flops, acc_bytes;
     std::vector<int64_t> acc_n;
     std::vector<std::string> slot_names;
-    // per-forward state
-    Arena arena;
-    hipStream_t stream = nullptr;
-    int status = 0;
+    // sub-batch streams (femasr_set_streams): independent samples run on separate streams so that
+    // one sub-batch's kernels fill the tail / HBM-bound phases of the other's
+    int nsub = 1;
+    std::vector<hipStream_t> sub_streams;
+    std::vector<hipEvent_t> sub_done;
+    hipEvent_t ev_fork = nullptr;
 };
 
 namespace {
@@ -156,7 +158,9 @@ struct Scope {   // event pair around one launch (or a small group of launches)
     femasr_handle *h;
     ProfRec rec{};
     bool on;
-    Scope(femasr_handle *hh, int slot, double flops, double bytes) : h(hh), on(hh->prof && !hh->arena.dry)
+    hipStream_t st;
+    Scope(femasr_handle *hh, hipStream_t stream, bool dry, int slot, double flops, double bytes)
+        : h(hh), on(hh->prof && !dry), st(stream)
     {
         if (!on) return;
         auto get = [&]() {
@@ -169,14 +173,14 @@ struct Scope {   // event pair around one launch (or a small group of launches)
         };
         rec.slot = slot; rec.flops = flops; rec.bytes = bytes;
         rec.e0 = get(); rec.e1 = get();
-        (void)hipEventRecord(rec.e0, h->stream);
+        (void)hipEventRecord(rec.e0, st);
     }
     void set_slot(int s) { rec.slot = s; }
     void set_flops(double f) { rec.flops = f; }
     ~Scope()
     {
         if (!on) return;
-        (void)hipEventRecord(rec.e1, h->stream);
+        (void)hipEventRecord(rec.e1, st);
         h->recs.push_back(rec);
     }
 };
@@ -281,9 +285,11 @@ int build_specs(femasr_handle *h)
 // ---------------------------------------------------------------- forward-time helpers
 struct Ctx {
     femasr_handle *h;
+    Arena *arena;
+    hipStream_t stream;
     int rc = 0;
-    bool dry() const { return h->arena.dry; }
-    hipStream_t s() const { return h->stream; }
+    bool dry() const { return arena->dry; }
+    hipStream_t s() const { return stream; }
 
     const float *Wt(const std::string &key)
     {
@@ -293,8 +299,8 @@ struct Ctx {
     }
     float *alloc_f(size_t n)
     {
-        void *p = h->arena.alloc(n * sizeof(float));
-        if (!p && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small (need > %zu bytes)", h->arena.cap);
+        void *p = arena->alloc(n * sizeof(float));
+        if (!p && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small (need > %zu bytes)", arena->cap);
         return (float *)p;
     }
     T alloc_t(int B, int H, int W, int C)
@@ -303,7 +309,7 @@ struct Ctx {
         t.p = alloc_f(t.numel());
         return t;
     }
-    void release(void *p) { if (p) h->arena.release(p); }
+    void release(void *p) { if (p) arena->release(p); }
     void release(T &t) { release(t.p); t.p = nullptr; }
 
     struct ConvOpt {
@@ -325,7 +331,7 @@ struct Ctx {
         a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
         a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
         if (rc) return y;
-        Scope sc(h, 0, 0.0, 0.0);
+        Scope sc(h, s(), dry(), 0, 0.0, 0.0);
         int variant = 0; double flops = 0;
         const int r = femasr_conv2d_launch(s(), &a, nullptr, &variant, &flops);
         sc.set_slot(SLOT_SMALL_COUNT + variant);
@@ -338,10 +344,10 @@ struct Ctx {
     float *gn(const T &x, const std::string &norm_prefix)
     {
         float *ab = alloc_f((size_t)2 * x.B * x.C);
-        double *scratch = (double *)h->arena.alloc((size_t)x.B * x.H * 32 * 2 * sizeof(double));
+        double *scratch = (double *)arena->alloc((size_t)x.B * x.H * 32 * 2 * sizeof(double));
         if (!scratch && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
         if (!rc && !dry()) {
-            Scope sc(h, SLOT_GN, 0.0, (double)x.numel() * 4.0);
+            Scope sc(h, s(), dry(), SLOT_GN, 0.0, (double)x.numel() * 4.0);
             const int r = femasr_gn_coeffs(s(), x.p, x.B, x.H, x.W, x.C, 32, Wt(norm_prefix + ".weight"), Wt(norm_prefix + ".bias"),
                                            1e-6f, ab, ab + (size_t)x.B * x.C, scratch);
             if (r && !rc) rc = r;
@@ -375,7 +381,7 @@ struct Ctx {
         float *stats = alloc_f((size_t)rows * 2);
         auto ln = [&](const T &t) {
             if (rc || dry()) return;
-            Scope sc(h, SLOT_LN, 0.0, (double)t.numel() * 4.0);
+            Scope sc(h, s(), dry(), SLOT_LN, 0.0, (double)t.numel() * 4.0);
             const int r = femasr_ln_stats(s(), t.p, rows, C, 1e-5f, stats);
             if (r && !rc) rc = r;
         };
@@ -384,7 +390,7 @@ struct Ctx {
         T qkv = conv(y, bp + ".attn.qkv", 3 * C, oq);
         T att = alloc_t(1, rows, 1, C);
         if (!rc && !dry()) {
-            Scope sc(h, SLOT_ATTN, 4.0 * (double)rows * 64.0 * C, (double)rows * C * 16.0);
+            Scope sc(h, s(), dry(), SLOT_ATTN, 4.0 * (double)rows * 64.0 * C, (double)rows * C * 16.0);
             const int r = femasr_window_attention(s(), qkv.p, B, H, W, C, 8, shift, Wt(bp + ".attn.relative_position_bias_table"), att.p);
             if (r && !rc) rc = r;
         }
@@ -451,7 +457,7 @@ int run_decoder(Ctx &c, T x, T feats[3], bool fuse_skip, float *out_nchw, int cr
     T img = c.conv(x, "out_conv", 3, oo);
     c.release(x);
     if (!c.rc && !c.dry()) {
-        Scope sc(h, SLOT_LAYOUT, 0.0, (double)img.B * 3.0 * crop_h * crop_w * 8.0);
+        Scope sc(h, c.s(), c.dry(), SLOT_LAYOUT, 0.0, (double)img.B * 3.0 * crop_h * crop_w * 8.0);
         const int r = femasr_crop_nhwc_to_nchw(c.s(), img.p, img.B, img.H, img.W, 3, crop_h, crop_w, out_nchw);
         if (r && !c.rc) c.rc = r;
     }
@@ -459,10 +465,11 @@ int run_decoder(Ctx &c, T x, T feats[3], bool fuse_skip, float *out_nchw, int cr
     return c.rc;
 }
 
-int run_forward(femasr_handle *h, const float *in_nchw, int B, int H, int W, int pad_mode, float *out_nchw, int64_t *indices)
+int run_forward(femasr_handle *h, Arena *arena, hipStream_t stream, const float *in_nchw, int B, int H, int W, int pad_mode,
+                float *out_nchw, int64_t *indices)
 {
     const femasr_config &cfg = h->cfg;
-    Ctx c{h};
+    Ctx c{h, arena, stream};
     int Hp = H, Wp = W;
     if (pad_mode) {
         const int wsz = 8 / h->scale * 8;
@@ -480,7 +487,7 @@ int run_forward(femasr_handle *h, const float *in_nchw, int B, int H, int W, int
 
     T x0 = c.alloc_t(B, Hp, Wp, cfg.in_channel);
     if (!c.rc && !c.dry()) {
-        Scope sc(h, SLOT_LAYOUT, 0.0, (double)x0.numel() * 8.0);
+        Scope sc(h, c.s(), c.dry(), SLOT_LAYOUT, 0.0, (double)x0.numel() * 8.0);
         const int r = femasr_pad_nchw_to_nhwc(c.s(), in_nchw, B, cfg.in_channel, H, W, Hp, Wp, x0.p);
         if (r) c.rc = r;
     }
@@ -517,12 +524,12 @@ int run_forward(femasr_handle *h, const float *in_nchw, int B, int H, int W, int
     const int64_t M = (int64_t)z.B * z.H * z.W;
     T zq = c.alloc_t(z.B, z.H, z.W, cfg.e_dim);
     int64_t *idx_tmp = nullptr;
-    if (!indices) idx_tmp = (int64_t *)h->arena.alloc((size_t)M * 8);
+    if (!indices) idx_tmp = (int64_t *)c.arena->alloc((size_t)M * 8);
     {
         const int nblk = cfg.n_e / 128;
         float *scratch = c.alloc_f((size_t)M * nblk * 2 + M + 64);
         if (!c.rc && !c.dry()) {
-            Scope sc(h, SLOT_VQ, 2.0 * (double)M * cfg.n_e * cfg.e_dim, (double)M * cfg.e_dim * 8.0 + (double)cfg.n_e * cfg.e_dim * 4.0 + M * 8.0);
+            Scope sc(h, c.s(), c.dry(), SLOT_VQ, 2.0 * (double)M * cfg.n_e * cfg.e_dim, (double)M * cfg.e_dim * 8.0 + (double)cfg.n_e * cfg.e_dim * 4.0 + M * 8.0);
             const int r = femasr_vq(c.s(), z.p, M, cfg.e_dim, c.Wt("quantize_group.0.embedding.weight"), h->cbT, h->ee, cfg.n_e,
                                     indices ? indices : idx_tmp, zq.p, scratch);
             if (r && !c.rc) c.rc = r;
@@ -541,13 +548,14 @@ int run_forward(femasr_handle *h, const float *in_nchw, int B, int H, int W, int
     return run_decoder(c, x, feats, cfg.lq_stage && cfg.use_residual, out_nchw, pad_mode ? crop_h : full_h, pad_mode ? crop_w : full_w);
 }
 
-int run_decode_indices(femasr_handle *h, const int64_t *indices, int B, int hq, int wq, float *out_nchw)
+int run_decode_indices(femasr_handle *h, Arena *arena, hipStream_t stream, const int64_t *indices, int B, int hq, int wq,
+                       float *out_nchw)
 {
     const femasr_config &cfg = h->cfg;
-    Ctx c{h};
+    Ctx c{h, arena, stream};
     T zq = c.alloc_t(B, hq, wq, cfg.e_dim);
     if (!c.rc && !c.dry()) {
-        Scope sc(h, SLOT_LAYOUT, 0.0, (double)zq.numel() * 8.0);
+        Scope sc(h, c.s(), c.dry(), SLOT_LAYOUT, 0.0, (double)zq.numel() * 8.0);
         const int r = femasr_codebook_gather(c.s(), indices, (int64_t)B * hq * wq, cfg.e_dim, c.Wt("quantize_group.0.embedding.weight"), cfg.n_e, zq.p);
         if (r) c.rc = r;
     }
@@ -607,6 +615,9 @@ void femasr_destroy(femasr_handle *h)
     if (h->cbT) (void)hipFree(h->cbT);
     if (h->ee) (void)hipFree(h->ee);
     for (auto e : h->pool) (void)hipEventDestroy(e);
+    for (auto e : h->sub_done) (void)hipEventDestroy(e);
+    for (auto st : h->sub_streams) (void)hipStreamDestroy(st);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     delete h;
 }
 
@@ -671,14 +682,47 @@ int femasr_finalize_weights(femasr_handle *h)
     return FEMASR_OK;
 }
 
+// sub-batch i of S over B samples: [lo, hi)
+static void sub_range(int B, int S, int i, int *lo, int *hi)
+{
+    const int q = B / S, r = B % S;
+    *lo = i * q + (i < r ? i : r);
+    *hi = *lo + q + (i < r ? 1 : 0);
+}
+
 int femasr_workspace_bytes(const femasr_handle *hc, int B, int H, int W, int pad_mode, size_t *bytes)
 {
     femasr_handle *h = const_cast<femasr_handle *>(hc);
     FEMASR_REQUIRE(h && bytes && B > 0 && H > 0 && W > 0, "workspace_bytes: bad args");
-    h->arena.reset(nullptr, 0, true);
-    const int rc = run_forward(h, nullptr, B, H, W, pad_mode, nullptr, nullptr);
-    if (rc) return rc;
-    *bytes = h->arena.peak + 256;
+    const int S = std::min(h->nsub, B);
+    size_t total = 0;
+    for (int i = 0; i < S; ++i) {
+        int lo, hi;
+        sub_range(B, S, i, &lo, &hi);
+        Arena a;
+        a.reset(nullptr, 0, true);
+        const int rc = run_forward(h, &a, nullptr, nullptr, hi - lo, H, W, pad_mode, nullptr, nullptr);
+        if (rc) return rc;
+        total += (a.peak + 255) & ~(size_t)255;
+    }
+    *bytes = total + 256;
+    return FEMASR_OK;
+}
+
+int femasr_set_streams(femasr_handle *h, int n)
+{
+    FEMASR_REQUIRE(h && n >= 1 && n <= 8, "set_streams: n must be in [1, 8]");
+    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
+    while ((int)h->sub_streams.size() < n) {
+        hipStream_t st;
+        hipEvent_t ev;
+        FEMASR_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        FEMASR_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        h->sub_streams.push_back(st);
+        h->sub_done.push_back(ev);
+    }
+    if (!h->ev_fork) FEMASR_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    h->nsub = n;
     return FEMASR_OK;
 }
 
@@ -690,19 +734,60 @@ int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, 
     FEMASR_REQUIRE(in_nchw && out_nchw && ws && B > 0 && H > 0 && W > 0, "forward: bad args");
     FEMASR_REQUIRE(((uintptr_t)ws & 255) == 0, "forward: workspace must be 256-byte aligned");
     FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
-    h->arena.reset(ws, ws_bytes, false);
-    h->stream = (hipStream_t)stream;
-    return run_forward(h, in_nchw, B, H, W, pad_mode, out_nchw, indices);
+    hipStream_t caller = (hipStream_t)stream;
+    const int S = std::min(h->nsub, B);
+    if (S <= 1) {
+        Arena a;
+        a.reset(ws, ws_bytes, false);
+        return run_forward(h, &a, caller, in_nchw, B, H, W, pad_mode, out_nchw, indices);
+    }
+    // fork: every sub-batch stream waits for the caller's stream; join: the caller's stream waits for all of them.
+    // Only event dependencies are added — no host synchronisation.
+    const int s_out = pad_mode ? h->scale : 1;
+    const size_t in_stride = (size_t)h->cfg.in_channel * H * W;
+    size_t out_stride, idx_stride;
+    {
+        int Hp = H, Wp = W;
+        if (pad_mode) { const int wsz = 8 / h->scale * 8; Hp = (H / wsz + 1) * wsz; Wp = (W / wsz + 1) * wsz; }
+        const int down = 1 << h->encode_depth;
+        idx_stride = (size_t)(Hp / down) * (Wp / down);
+        out_stride = pad_mode ? (size_t)3 * (H * s_out) * (W * s_out)
+                              : (size_t)3 * ((Hp / down) << h->max_depth) * ((Wp / down) << h->max_depth);
+    }
+    FEMASR_CHECK_HIP(hipEventRecord(h->ev_fork, caller));
+    size_t off = 0;
+    for (int i = 0; i < S; ++i) {
+        int lo, hi;
+        sub_range(B, S, i, &lo, &hi);
+        Arena dry;
+        dry.reset(nullptr, 0, true);
+        rc = run_forward(h, &dry, nullptr, nullptr, hi - lo, H, W, pad_mode, nullptr, nullptr);
+        if (rc) return rc;
+        const size_t need = (dry.peak + 255) & ~(size_t)255;
+        if (off + need > ws_bytes) return femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small for %d sub-batches", S);
+        Arena a;
+        a.reset((char *)ws + off, need, false);
+        off += need;
+        hipStream_t st = h->sub_streams[i];
+        FEMASR_CHECK_HIP(hipStreamWaitEvent(st, h->ev_fork, 0));
+        rc = run_forward(h, &a, st, in_nchw + lo * in_stride, hi - lo, H, W, pad_mode, out_nchw + lo * out_stride,
+                         indices ? indices + lo * idx_stride : nullptr);
+        if (rc) return rc;
+        FEMASR_CHECK_HIP(hipEventRecord(h->sub_done[i], st));
+        FEMASR_CHECK_HIP(hipStreamWaitEvent(caller, h->sub_done[i], 0));
+    }
+    return FEMASR_OK;
 }
 
 int femasr_decode_workspace_bytes(const femasr_handle *hc, int B, int hq, int wq, size_t *bytes)
 {
     femasr_handle *h = const_cast<femasr_handle *>(hc);
     FEMASR_REQUIRE(h && bytes && B > 0 && hq > 0 && wq > 0, "decode_workspace_bytes: bad args");
-    h->arena.reset(nullptr, 0, true);
-    const int rc = run_decode_indices(h, nullptr, B, hq, wq, nullptr);
+    Arena a;
+    a.reset(nullptr, 0, true);
+    const int rc = run_decode_indices(h, &a, nullptr, nullptr, B, hq, wq, nullptr);
     if (rc) return rc;
-    *bytes = h->arena.peak + 256;
+    *bytes = a.peak + 256;
     return FEMASR_OK;
 }
 
@@ -714,9 +799,9 @@ int femasr_decode_indices(femasr_handle *h, void *stream, const int64_t *indices
     FEMASR_REQUIRE(indices && out_nchw && ws && B > 0 && hq > 0 && wq > 0, "decode_indices: bad args");
     FEMASR_REQUIRE(((uintptr_t)ws & 255) == 0, "decode_indices: workspace must be 256-byte aligned");
     FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
-    h->arena.reset(ws, ws_bytes, false);
-    h->stream = (hipStream_t)stream;
-    return run_decode_indices(h, indices, B, hq, wq, out_nchw);
+    Arena a;
+    a.reset(ws, ws_bytes, false);
+    return run_decode_indices(h, &a, (hipStream_t)stream, indices, B, hq, wq, out_nchw);
 }
 
 int femasr_profile_enable(femasr_handle *h, int on)

@@ -75,6 +75,11 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr,
 /* Verify every expected weight was set; build derived tensors (codebook^T, |e|^2). */
 int femasr_finalize_weights(femasr_handle *h);
 
+/* Number of internal streams the batch is split over (default 1).  Samples are independent (every op is
+ * per-sample), so sub-batches run concurrently on separate streams, forked from / joined to the caller's
+ * stream by events only; results are bit-identical for any n.  Call before femasr_workspace_bytes. */
+int femasr_set_streams(femasr_handle *h, int n);
+
 /* pad_mode 1 = FeMaSRNet.test geometry (mirror-pad to (h/wsz+1)*wsz, crop to h*s; femasr_arch.py:449-468)
  * pad_mode 0 = FeMaSRNet.forward (no pad, output (H*s_out) as produced; femasr_arch.py:470-479)          */
 int femasr_workspace_bytes(const femasr_handle *h, int B, int H, int W, int pad_mode, size_t *bytes);

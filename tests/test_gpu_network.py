@@ -123,6 +123,12 @@ def test_full_size_batch16_properties(cuda_device):
     for r in range(4):
         for c in range(4):
             assert torch.equal(yt[0, :, r * 512:(r + 1) * 512, c * 512:(c + 1) * 512], y[r * 4 + c])
+    # sub-batch streams (femasr_set_streams): same bits for any split, incl. an uneven one (16 = 6+5+5)
+    for ns in (2, 3):
+        net.num_streams = ns
+        ys, idxs = net.test_with_indices(x)
+        assert torch.equal(ys, y) and torch.equal(idxs, idx), ns
+    net.num_streams = 1
     # indices index real codes; decode path accepts them
     assert int(idx.min()) >= 0 and int(idx.max()) < 1024
 
