@@ -50,12 +50,14 @@ constexpr int ALD = BK + 1;
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ, bool WVEC>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_igemm_kernel(const ConvParams p)
 {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int AROWS = BM / 32;               // A float4 units per thread
-    constexpr int BUNITS = (BK * BN / 4) / 256;  // B float4 units per thread
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BUNITS >= 1, "tile config");
+    constexpr int NT = WM * WN * 64;             // 256 (4 waves) or 512 (8 waves, 2 per SIMD inside the block)
+    constexpr int RSTEP = NT / 8;                // A rows covered per unit round
+    constexpr int AROWS = BM / RSTEP;            // A float4 units per thread
+    constexpr int BUNITS = (BK * BN / 4) / NT;   // B float4 units per thread
+    static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && BUNITS >= 1 && AROWS >= 1, "tile config");
     static_assert(CINVEC || PRO == FEMASR_PRO_NONE, "generic-Cin path has no prologue");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int j = 0; j < AROWS; ++j) {
-        const int r = m0 + mrow + 32 * j;
+        const int r = m0 + mrow + RSTEP * j;
         if (r < p.M) {
             const int n = r / HoWo, rem = r - n * HoWo;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
         }
 #pragma unroll
         for (int u = 0; u < BUNITS; ++u) {
-            const int unit = t + 256 * u;
+            const int unit = t + NT * u;
             const int nq = unit % (BN / 4), kr = unit / (BN / 4);
             const int k = c * BK + kr, n = n0 + 4 * nq;
             float4 v;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
                 v.w = __builtin_fmaf((v.w - lmean[j]) * lrstd[j], lng.w, lnb.w);
             }
             if (!(amask & (1u << j))) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
-            float *dst = Ab + (mrow + 32 * j) * ALD + 4 * kq;
+            float *dst = Ab + (mrow + RSTEP * j) * ALD + 4 * kq;
             dst[0] = v.x;
             dst[1] = v.y;
             dst[2] = v.z;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
         }
 #pragma unroll
         for (int u = 0; u < BUNITS; ++u) {
-            const int unit = t + 256 * u;
+            const int unit = t + NT * u;
             const int nq = unit % (BN / 4), kr = unit / (BN / 4);
             float4 v = rb[u];
             if (WVEC && !(bmask & (1u << u))) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
                 }
             }
         __syncthreads();
-        if (t < BM && m0 + t < p.M) {
+        if (t < BM && m0 + t < p.M) {   // (BM <= NT)
             float bd = red[t * 2];
             int bi = __float_as_int(red[t * 2 + 1]);
 #pragma unroll
@@ -407,26 +409,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
             gb = ld4(p.pro_b + (size_t)n * p.Cin + cc * BK + 4 * kq);
         }
     };
-    auto store_patch = [&](int buf) {
+    auto store_patch_unit = [&](int buf, int i) {
         float *Pb = Ps + buf * PSZ;
-#pragma unroll
-        for (int i = 0; i < PUNITS; ++i) {
-            const int pix = (t >> 3) + PROWS * i;
-            if (PP % PROWS != 0 && i == PUNITS - 1 && pix >= PP) break;     // tail units of the last round
-            float4 v = rp[i];
-            if (PRO == FEMASR_PRO_GN_SILU) {
-                v.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
-                v.y = det_silu(__builtin_fmaf(v.y, ga.y, gb.y));
-                v.z = det_silu(__builtin_fmaf(v.z, ga.z, gb.z));
-                v.w = det_silu(__builtin_fmaf(v.w, ga.w, gb.w));
-            }
-            if (!(pmask & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding AFTER the activation
-            float *dst = Pb + pix * ALD + 4 * kq;
-            dst[0] = v.x;
-            dst[1] = v.y;
-            dst[2] = v.z;
-            dst[3] = v.w;
+        const int pix = (t >> 3) + PROWS * i;
+        if (PP % PROWS != 0 && i == PUNITS - 1 && pix >= PP) return;     // tail units of the last round
+        float4 v = rp[i];
+        if (PRO == FEMASR_PRO_GN_SILU) {
+            v.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
+            v.y = det_silu(__builtin_fmaf(v.y, ga.y, gb.y));
+            v.z = det_silu(__builtin_fmaf(v.z, ga.z, gb.z));
+            v.w = det_silu(__builtin_fmaf(v.w, ga.w, gb.w));
         }
+        if (!(pmask & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding AFTER the activation
+        float *dst = Pb + pix * ALD + 4 * kq;
+        dst[0] = v.x;
+        dst[1] = v.y;
+        dst[2] = v.z;
+        dst[3] = v.w;
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PUNITS; ++i) store_patch_unit(buf, i);
     };
     auto load_w = [&](int q) {      // q = cc * 9 + tap : rows q*32 .. q*32+31 of the repacked weights
         bmask = 0;
@@ -451,16 +454,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
             rb[u] = v;
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w_unit = [&](int buf, int u) {
         float *Bb = Bs + buf * BK * BN;
+        const int unit = t + NT * u;
+        const int nq = unit % (BN / 4), kr = unit / (BN / 4);
+        float4 v = rb[u];
+        if (WVEC && !(bmask & (1u << u))) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(Bb + kr * BN + 4 * nq) = v;
+    };
+    auto store_w = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < BUNITS; ++u) {
-            const int unit = t + NT * u;
-            const int nq = unit % (BN / 4), kr = unit / (BN / 4);
-            float4 v = rb[u];
-            if (WVEC && !(bmask & (1u << u))) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(Bb + kr * BN + 4 * nq) = v;
-        }
+        for (int u = 0; u < BUNITS; ++u) store_w_unit(buf, u);
     };
 
     f32x16 acc[TM][TN];
@@ -495,8 +499,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
             const int q = cc * 9 + tap;
             const bool more_w = (q + 1) < ncc * 9;
             const bool more_p = (tap == 0) && (cc + 1 < ncc);
-            if (more_w) load_w(q + 1);
-            if (more_p) load_patch(cc + 1);
             const int ky = tap / 3, kx = tap - ky * 3;
             int aidx[TM];
 #pragma unroll
@@ -506,6 +508,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
                 aidx[i] = (prow * PW + pcol) * ALD;
             }
             const float *Bb = Bs + (q & 1) * BK * BN + bcol;
+            // The staging work of the NEXT tap (weights) / channel block (patch) is cut into slices that sit
+            // BETWEEN the 16 MFMA k-pair steps of this tap, so VALU / LDS-store / global-load issue overlaps
+            // the matrix pipe inside every wave instead of alternating with it in lock-step across the CU.
+            constexpr int KW0 = BK / 2 - BUNITS;          // weight-tile stores in the last BUNITS steps
+            constexpr int KP0 = KW0 - PUNITS;             // patch units just before them
+            static_assert(KP0 >= 2, "not enough k-pair steps to hide the staging slices");
             float af[2][TM], bf[2][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[0][i] = Pb[aidx[i]];
@@ -520,16 +528,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bf[nxt][j] = Bb[2 * (kk + 1) * BN + j * 32];
                 }
-                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of this k-pair's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                if (kk == 0) {
+                    if (more_w) load_w(q + 1);
+                    if (more_p) load_patch(cc + 1);
+                }
+                if (kk >= KP0 && kk < KW0) {
+                    if (more_p) store_patch_unit((cc + 1) & 1, kk - KP0);
+                }
+                if (kk >= KW0) {
+                    if (more_w) store_w_unit((q + 1) & 1, kk - KW0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more_w) store_w((q + 1) & 1);
-            if (more_p) store_patch((cc + 1) & 1);
             __syncthreads();
         }
     }
@@ -574,17 +590,17 @@ struct Variant {
 };
 
 #define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ, WVEC)                                             \
-    { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",wvec=" #WVEC ">", BM, BN,        \
-      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ, WVEC>, conv_lds_bytes<BM, BN>(), false, 256 }
+    { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",wvec=" #WVEC ",waves=" #WM "x" #WN ">", BM, BN,        \
+      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ, WVEC>, conv_lds_bytes<BM, BN>(), false, WM * WN * 64 }
 
 #define FEMASR_HALO(BN, WM, WN, PRO, UP2, WVEC)                                                        \
     { "conv3x3_halo<8x16x" #BN "," #PRO ",up2=" #UP2 ",wvec=" #WVEC ",waves=" #WM "x" #WN ">", 128, BN,                      \
       conv3x3_halo_kernel<BN, WM, WN, PRO, UP2, WVEC>, halo_lds_bytes<BN, UP2>(), false, WM * WN * 64 }
 
 Variant g_variants[] = {
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, false, true),     // 0
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_GN_SILU, true, false, true),  // 1
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_LN, true, false, true),       // 2
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, false, true),     // 0 (8 waves)
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_GN_SILU, true, false, true),  // 1
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_LN, true, false, true),       // 2
     FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, true, false, true),      // 3
     FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_GN_SILU, true, false, true),   // 4
     FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_LN, true, false, true),        // 5
@@ -595,12 +611,12 @@ Variant g_variants[] = {
     FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, false, false, true),     // 10
     FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false, false, false),    // 11
     FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, true, true),      // 12 VQ distance + argmin
-    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, false, true),                   // 13 3x3 s1 halo kernels
+    FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, false, true),                   // 13 3x3 s1 halo kernels
     FEMASR_HALO(128, 4, 2, FEMASR_PRO_GN_SILU, false, true),                // 14 (8 waves)
-    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, true, true),                    // 15 fused nearest-x2
-    FEMASR_HALO(64, 4, 1, FEMASR_PRO_NONE, false, true),                    // 16
+    FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, true, true),                    // 15 fused nearest-x2
+    FEMASR_HALO(64, 4, 2, FEMASR_PRO_NONE, false, true),                    // 16
     FEMASR_HALO(64, 4, 2, FEMASR_PRO_GN_SILU, false, true),                 // 17 (8 waves)
-    FEMASR_HALO(64, 4, 1, FEMASR_PRO_NONE, true, true),                     // 18
+    FEMASR_HALO(64, 4, 2, FEMASR_PRO_NONE, true, true),                     // 18
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, false, false),                   // 19 any Cout (out_conv)
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_GN_SILU, false, false),                // 20
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, true, false),                    // 21

@@ -291,7 +291,7 @@ __global__ void row_sqsum_kernel(const float *__restrict__ x, long long rows, in
 // one wave per row: pick the first-min over the n-block partials (ascending block order),
 // write idx (int64) and z_q = z + (e[idx] - z).
 __global__ void vq_finalize_kernel(const float *__restrict__ z, long long M, int D, const float *__restrict__ cb,
-                                   const float *__restrict__ part, int nblk, long long *__restrict__ idx,
+                                   const float *__restrict__ part, int nblk, int n_e, long long *__restrict__ idx,
                                    float *__restrict__ zq)
 {
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -305,6 +305,7 @@ __global__ void vq_finalize_kernel(const float *__restrict__ z, long long M, int
         const int i = __float_as_int(pp[2 * b + 1]);
         if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
     }
+    bi = bi < 0 ? 0 : (bi >= n_e ? n_e - 1 : bi);     // NaN rows leave the sentinel: never index out of the codebook
     if (lane == 0) idx[row] = (long long)bi;
     const float *e = cb + (size_t)bi * D;
     const float *zr = z + (size_t)row * D;
@@ -474,7 +475,7 @@ int femasr_vq(void *stream, const float *z, int64_t M, int D, const float *cb, c
     rc = femasr_conv2d_launch(s, &a, &ep, nullptr, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, z, (long long)M, D, cb, part,
-                       nblk, (long long *)idx, zq);
+                       nblk, n_e, (long long *)idx, zq);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }
