@@ -362,6 +362,41 @@ __global__ void repack_oihw_kernel(const float *__restrict__ in, int O, int I, i
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// image pre / post-processing on the GPU (the steps either side of the path)
+// ------------------------------------------------------------------------------------------
+// img2tensor(...)/255. (basicsr/utils/img_util.py:9-35; inference_femasr.py:55): uint8 HWC (BGR or RGB)
+// -> fp32 CHW RGB, value = (float)u8 / 255.0f with an IEEE division.
+__global__ void image_u8_to_f32_kernel(const unsigned char *__restrict__ in, int H, int W, int swap_rb,
+                                       float *__restrict__ out, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        size_t r = i / W;
+        const int y = (int)(r % H);
+        const int c = (int)(r / H);
+        const int sc = swap_rb ? 2 - c : c;
+        out[i] = (float)in[((size_t)y * W + x) * 3 + sc] / 255.0f;
+    }
+}
+
+// tensor2img (img_util.py:38-94): clamp to [0,1], CHW RGB -> HWC (BGR or RGB), (x*255).round() (half to even) -> uint8
+__global__ void image_f32_to_u8_kernel(const float *__restrict__ in, int H, int W, int swap_rb,
+                                       unsigned char *__restrict__ out, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        size_t r = i / 3;
+        const int x = (int)(r % W);
+        const int y = (int)(r / W);
+        const int sc = swap_rb ? 2 - c : c;
+        float v = in[((size_t)sc * H + y) * W + x];
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);       // NaN -> 1 like neither; NaNs never reach here on finite inputs
+        if (!(v == v)) v = 0.f;
+        out[i] = (unsigned char)rintf(v * 255.0f);
+    }
+}
+
 inline unsigned grid_for(size_t total, int block = 256)
 {
     size_t g = (total + block - 1) / block;
@@ -495,6 +530,26 @@ int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int 
     const size_t total = (size_t)O * I * kh * kw;
     hipLaunchKernelGGL(repack_oihw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, O, I, kh, kw, out,
                        total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_image_u8_to_f32(void *stream, const uint8_t *in_hwc, int H, int W, int swap_rb, float *out_chw)
+{
+    FEMASR_REQUIRE(in_hwc && out_chw && H > 0 && W > 0, "image_u8_to_f32: bad args");
+    const size_t total = (size_t)3 * H * W;
+    hipLaunchKernelGGL(image_u8_to_f32_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in_hwc, H, W,
+                       swap_rb, out_chw, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_image_f32_to_u8(void *stream, const float *in_chw, int H, int W, int swap_rb, uint8_t *out_hwc)
+{
+    FEMASR_REQUIRE(in_chw && out_hwc && H > 0 && W > 0, "image_f32_to_u8: bad args");
+    const size_t total = (size_t)3 * H * W;
+    hipLaunchKernelGGL(image_f32_to_u8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in_chw, H, W,
+                       swap_rb, out_hwc, total);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

@@ -160,6 +160,14 @@ int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, c
  * codebook^T). */
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out);
 
+/* ---- image pre / post-processing (the steps either side of the path) ---- */
+/* uint8 HWC (3 channels; swap_rb=1 for cv2-style BGR input) -> fp32 CHW RGB in [0,1]: (float)u8 / 255.0f.
+ * Replaces img2tensor(...)/255. (basicsr/utils/img_util.py:9-35, inference_femasr.py:54-56). */
+int femasr_image_u8_to_f32(void *stream, const uint8_t *in_hwc, int H, int W, int swap_rb, float *out_chw);
+/* fp32 CHW RGB -> clamp [0,1] -> (x*255).round() half-to-even -> uint8 HWC (swap_rb=1: BGR for cv2.imwrite).
+ * Replaces tensor2img (basicsr/utils/img_util.py:38-94). */
+int femasr_image_f32_to_u8(void *stream, const float *in_chw, int H, int W, int swap_rb, uint8_t *out_hwc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,6 +193,24 @@ def codebook_gather(idx, codebook):
     return zq
 
 
+# ------------------------------------------------------------------ image pre / post (host glue of the reference)
+def image_u8_to_f32(img_hwc_u8, bgr=False):
+    """img2tensor(...)/255. (basicsr/utils/img_util.py:9-35; inference_femasr.py:55): uint8 HWC -> fp32 (1,3,H,W) RGB."""
+    img = np.asarray(img_hwc_u8)
+    assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+    if bgr:
+        img = img[:, :, ::-1]
+    return (img.transpose(2, 0, 1).astype(np.float32) / np.float32(255.0))[None]
+
+
+def image_f32_to_u8(x_nchw, bgr=False):
+    """tensor2img (img_util.py:38-94): clamp [0,1], CHW->HWC, optional RGB->BGR, (x*255).round() (half to even), uint8."""
+    x = np.clip(np.asarray(x_nchw, np.float32)[0], 0.0, 1.0).transpose(1, 2, 0)
+    if bgr:
+        x = x[:, :, ::-1]
+    return np.round(x * np.float32(255.0)).astype(np.uint8)
+
+
 # ------------------------------------------------------------------ network
 _CHANNELS = {8: 256, 16: 256, 32: 256, 64: 256, 128: 128, 256: 64, 512: 32}   # femasr_arch.py:244-252
 

@@ -150,3 +150,63 @@ def test_weight_updates_are_picked_up_and_errors_are_loud(cuda_device):
         net.test(torch.zeros(1, 3, 32, 32))            # CPU tensor: no fallback
     with pytest.raises(ValueError):
         net(torch.zeros(1, 3, 30, 32, device='cuda'))  # forward() needs /8 sizes (reference would crash in the decoder)
+
+
+def test_image_pre_post_kernels_exact(cuda_device):
+    from femasr_amd import imgproc
+    from oracle import oracle as orc
+    u8 = (synth.uniform01(1, 'img', 37 * 53 * 3) * 256).astype(np.uint8).reshape(37, 53, 3)
+    for bgr in (False, True):
+        x = imgproc.u8_to_input(torch.from_numpy(u8).cuda(), bgr=bgr).cpu().numpy()
+        assert np.array_equal(x, orc.image_u8_to_f32(u8, bgr=bgr))
+        y = synth.uniform(2, 'out', (1, 3, 41, 29), -0.3, 1.3)
+        y[0, 0, 0, :4] = np.array([0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255], np.float32)
+        got = imgproc.output_to_u8(torch.from_numpy(y).cuda(), bgr=bgr).cpu().numpy()
+        assert np.array_equal(got, orc.image_f32_to_u8(y, bgr=bgr))
+
+
+def test_cli_counterpart_end_to_end(cuda_device, tmp_path):
+    """femasr_amd/inference.py == inference_femasr.py:19-69 policy: sorted files, h*w < max_size^2 -> test(), else
+    test_tile(); uint8 PNG out.  Expected pixels = oracle pre -> oracle net -> oracle post (bit-exact chain)."""
+    from PIL import Image
+    from femasr_amd import inference
+    from oracle import oracle as orc
+    src, dst = tmp_path / 'in', tmp_path / 'out'
+    src.mkdir()
+    imgs = {}
+    for name, (h, w) in (('b_small.png', (24, 40)), ('a_large.png', (48, 40))):
+        u8 = (synth.synth_input(11, (1, 3, h, w), tag=name)[0].transpose(1, 2, 0) * 255).astype(np.uint8)
+        Image.fromarray(u8, 'RGB').save(src / name)
+        imgs[name] = u8
+    inference.main(['-i', str(src), '-o', str(dst), '-s', '4', '--synthetic-seed', '1', '--max_size', '40',
+                    '--tile_size', '24', '--tile_pad', '8'])
+    w = synth_weights('x4', 1, 'trained')
+    onet = oracle_net('x4', w)
+    for name, u8 in imgs.items():
+        x = orc.image_u8_to_f32(u8)
+        h, wd = u8.shape[:2]
+        y = onet.test(x) if h * wd < 40 ** 2 else onet.test_tile(x, 24, 8)
+        expect = orc.image_f32_to_u8(y)
+        got = np.asarray(Image.open(dst / name).convert('RGB'))
+        assert got.shape == (h * 4, wd * 4, 3)
+        assert np.array_equal(got, expect), name
+
+
+def test_other_configs_full_size_properties(cuda_device):
+    """BASELINE configs 4 and 5 at (reduced-batch) full geometry: x2 256x256 -> 512x512, HQ autoencode 512x512."""
+    import gpu_utils as G
+    net2 = G.build_net('x2', synth_weights('x2', 2, 'trained'))
+    x = torch.from_numpy(synth.synth_input(6, (4, 3, 256, 256))).cuda()
+    y, idx = net2.test_with_indices(x)
+    assert y.shape == (4, 3, 512, 512) and idx.shape == (4, 1, 72, 72) and torch.isfinite(y).all()
+    y1, i1 = net2.test_with_indices(x[2:3])
+    assert torch.equal(y1[0], y[2]) and torch.equal(i1[0], idx[2])
+    del net2
+    torch.cuda.empty_cache()
+    neth = G.build_net('hq', synth_weights('hq', 3, 'trained'))
+    xh = torch.from_numpy(synth.synth_input(7, (2, 3, 512, 512))).cuda()
+    out, _, _, il = neth(xh)
+    assert out.shape == (2, 3, 512, 512) and il[0].shape == (2, 1, 64, 64) and torch.isfinite(out).all()
+    o1 = neth(xh[1:2])[0]
+    assert torch.equal(o1[0], out[1])
+    assert (neth.decode_indices(il[0]) - out).abs().max() < 1e-5      # straight-through z+(e-z) vs e: rounding-level only

@@ -137,3 +137,16 @@ def test_pad_crop_geometry():
     assert np.array_equal(p, ref.permute(0, 2, 3, 1).numpy())
     c = orc.crop_nhwc_to_nchw(p, 5, 7)
     assert np.array_equal(c, x)
+
+
+def test_image_pre_post_semantics():
+    """Oracle pre/post == the reference's host code semantics (img_util.py:9-35,38-94) restated with torch/numpy."""
+    u8 = (synth.uniform01(1, 'img', 7 * 9 * 3) * 256).astype(np.uint8).reshape(7, 9, 3)
+    x = orc.image_u8_to_f32(u8, bgr=True)
+    ref = torch.from_numpy(u8[:, :, ::-1].copy().transpose(2, 0, 1)).float() / 255.
+    assert np.array_equal(x[0], ref.numpy())
+    y = synth.uniform(2, 'out', (1, 3, 5, 6), -0.3, 1.3)
+    y[0, 0, 0, :4] = np.array([0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255], np.float32)   # ties: half to even
+    got = orc.image_f32_to_u8(y, bgr=True)
+    t = torch.from_numpy(y)[0].clamp_(0, 1).numpy().transpose(1, 2, 0)[:, :, ::-1]
+    assert np.array_equal(got, (t * 255.0).round().astype(np.uint8))
