@@ -71,6 +71,7 @@ SIGNATURES = {
     'femasr_row_sqsum': (c_int, [vp, vp, c_i64, c_int, vp]),
     'femasr_codebook_gather': (c_int, [vp, vp, c_i64, c_int, vp, c_int, vp]),
     'femasr_repack_oihw': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
+    'femasr_packed_weight_floats': (szt, [c_int, c_int, c_int, c_int]),
     'femasr_image_u8_to_f32': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_image_f32_to_u8': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
 }

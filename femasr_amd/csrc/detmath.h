@@ -4,7 +4,7 @@
 // give the same bits on gfx950 as in the CPU oracle, so they are written out with
 // IEEE fp32 add / mul / fmaf only (no v_exp_f32 / v_rcp_f32 approximations):
 //   det_expf : Cody-Waite range reduction, degree-7 Taylor, Horner with fmaf
-//   det_erff : |x|<1  x*P(x^2) (deg 6);  1<=|x|<4  1-exp(Q(|x|-2.5)) (deg 8);  else 1
+//   det_erff : branch-free  sign(x) * (1 - exp(-a*Q(a))),  a = min(|x|,4),  Q = deg-9 fit of -ln(erfc(a))/a
 // Build with -ffp-contract=off and correctly-rounded fp32 divide/sqrt (hipcc default).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,33 +29,18 @@ __device__ __forceinline__ float det_expf(float x)
 
 __device__ __forceinline__ float det_erff(float x)
 {
-    const float ax = fabsf(x);
-    float r;
-    if (ax < 1.0f) {
-        const float t = ax * ax;
-        float p = 0x1.4fd5fap-14f;
-        p = __builtin_fmaf(p, t, -0x1.a63fe2p-11f);
-        p = __builtin_fmaf(p, t, 0x1.545368p-8f);
-        p = __builtin_fmaf(p, t, -0x1.b80286p-6f);
-        p = __builtin_fmaf(p, t, 0x1.ce2d7cp-4f);
-        p = __builtin_fmaf(p, t, -0x1.812740p-2f);
-        p = __builtin_fmaf(p, t, 0x1.20dd76p+0f);
-        r = p * ax;
-    } else if (ax < 4.0f) {
-        const float u = ax - 2.5f;
-        float q = 0x1.b49612p-20f;
-        q = __builtin_fmaf(q, u, -0x1.bdf536p-17f);
-        q = __builtin_fmaf(q, u, 0x1.4467eap-14f);
-        q = __builtin_fmaf(q, u, -0x1.b89f56p-12f);
-        q = __builtin_fmaf(q, u, 0x1.1bccd0p-9f);
-        q = __builtin_fmaf(q, u, -0x1.63cf4ep-7f);
-        q = __builtin_fmaf(q, u, -0x1.e34608p-1f);
-        q = __builtin_fmaf(q, u, -0x1.569252p+2f);
-        q = __builtin_fmaf(q, u, -0x1.f3a2dcp+2f);
-        r = 1.0f - det_expf(q);
-    } else {
-        r = 1.0f;
-    }
+    const float ax = fminf(fabsf(x), 4.0f);
+    float q = 0x1.19aba0p-21f;
+    q = __builtin_fmaf(q, ax, -0x1.7c9856p-17f);
+    q = __builtin_fmaf(q, ax, 0x1.b9a7a6p-14f);
+    q = __builtin_fmaf(q, ax, -0x1.1711a6p-11f);
+    q = __builtin_fmaf(q, ax, 0x1.6c55eep-10f);
+    q = __builtin_fmaf(q, ax, 0x1.d916f4p-13f);
+    q = __builtin_fmaf(q, ax, -0x1.3e7d62p-6f);
+    q = __builtin_fmaf(q, ax, 0x1.a569bap-4f);
+    q = __builtin_fmaf(q, ax, 0x1.45f0d6p-1f);
+    q = __builtin_fmaf(q, ax, 0x1.20dd80p+0f);
+    const float r = 1.0f - det_expf(-(ax * q));
     return copysignf(r, x);
 }
 

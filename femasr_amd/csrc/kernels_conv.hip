@@ -1,31 +1,34 @@
-// kernels_conv.hip — NHWC implicit-GEMM convolution / linear on the gfx950 fp32 matrix cores.
+// kernels_conv.hip — NHWC convolution / linear / VQ-distance kernels on the gfx950 fp32 matrix cores.
 //
-// One kernel family covers every dense contraction of the hot path:
-//   nn.Conv2d k1/k3/k4, stride 1/2, zero padding      femasr_arch.py:150,159,173,203,273,298;
-//                                                     fema_utils.py:75,78,90; network_swinir.py:465
-//   nn.Upsample(scale_factor=2) fused into the loader femasr_arch.py:172,202
-//   nn.Linear (ksz=1 on a (1,rows,1,Cin) tensor)      network_swinir.py:19-21,105-112
-//   GroupNorm-apply + SiLU on load (PRO_GN)           fema_utils.py:72-79
-//   LayerNorm-apply on load (PRO_LN)                  network_swinir.py:243,277
-//   bias, GELU(erf), up to two residual adds on store fema_utils.py:82-83; network_swinir.py:276-277,482;
-//                                                     femasr_arch.py:361-362
-//   VQ distance + per-tile first-min argmin epilogue  femasr_arch.py:35-38,63-66
+// Two kernel families cover every dense contraction of the hot path:
+//   conv3x3_halo  3x3 stride-1 pad-1 convs (753 of the 964 GFLOP per tile), optional fused nearest-x2
+//                 (nn.Upsample, femasr_arch.py:172,202) and fused GroupNorm-apply + SiLU (fema_utils.py:72-79)
+//   conv_igemm    everything else as an implicit GEMM: k4 in_conv, stride-2 convs, 1x1 convs and all nn.Linear
+//                 (network_swinir.py:19-21,105-112; ksz=1 on a (1,rows,1,Cin) tensor) with LayerNorm-apply on
+//                 load (network_swinir.py:243,277), and the VQ distance + per-tile first-min argmin
+//                 (femasr_arch.py:35-38,63-66)
+//   both          bias, exact-erf GELU, up to two residual adds on store (fema_utils.py:82-83;
+//                 network_swinir.py:276-277,482; femasr_arch.py:361-362)
 //
-// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = ksz*ksz*Cin in (ky,kx,cin) order.
-// Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32, and per output element ONE k-ascending fmaf
-// chain, which is the order the oracle specifies, so results are bit-identical to it.  That
-// fixes the schedule: no split-K, one accumulator per output, K walked in ascending order.
+// Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32, and per output element ONE fmaf chain in the oracle's K
+// order  k = ((ci/32)*ksz*ksz + ky*ksz + kx)*32 + ci%32  (plain (ky,kx,ci) when Cin % 32 != 0), so results are
+// bit-identical to oracle/femasr_oracle.c.  That fixes the schedule: no split-K, one accumulator per output.
 //
-// Tiling: 256 threads = 4 waves (one per SIMD), block tile BM x BN, BK = 32.
-//   A tile (BM x 32) staged global -> registers -> (prologue math) -> LDS [m][33] (pad: conflict-free
-//   ds_read_b32 of the MFMA A fragment A[i=lane&31][k=lane>>5] AND conflict-free scattered stores);
-//   B tile (32 x BN) = weights [k][n], stored as loaded ([k][n], ds_write_b128), fragment reads of
-//   B[k=lane>>5][j=lane&31] hit 32 consecutive banks.
-//   Double-buffered LDS, one __syncthreads per K-chunk: loads of chunk c+1 are issued before the
-//   16 k-pair MFMA steps of chunk c and written to the other buffer after them.
-//   fp32 MFMA is 64 cycles/instruction/SIMD, so LDS and the VALU prologue run in its shadow.
-// Grid: 1-D over (m-block, n-block), n fastest, with the bijective XCD remap so that the blocks
-//   sharing an A tile / neighbouring halo rows land on the same XCD's L2.
+// Operands:
+//   A (activations)  staged global -> registers -> (normalise / activate) -> LDS [pixel][33] (the pad makes both
+//                    the MFMA A-fragment read  A[i=lane&31][k=lane>>5]  and the scattered stores conflict-free).
+//                    conv3x3_halo stages ONE (8+2)x(16+2) halo patch per 32-channel block and sweeps all 9 taps
+//                    over it (6.4x fewer loads / activations / LDS stores than im2col staging).
+//   B (weights)      never touch LDS: femasr_repack_oihw stores them FRAGMENT-MAJOR,
+//                        [chunk q = k/32][n-tile = n/32][lane = (k&1)*32 + n%32][kk = (k%32)/2]      (zero padded)
+//                    so the 16 B-fragment values a lane needs for one 32-deep K chunk of one 32-column tile are 64
+//                    contiguous bytes and a wave reads 4 KiB contiguous with four global_load_dwordx4, straight
+//                    into the registers the MFMAs consume (weights are L2 / L1 resident: <= 9.4 MB per layer).
+//                    No weight staging, no B bank traffic, and the halo kernel needs ONE barrier per channel
+//                    block instead of one per tap.
+// Blocks: 512 threads = 8 waves (2 per SIMD; 2 blocks per CU), 128 output pixels x BN channels, BK = 32.
+// Grid: 1-D, n-blocks fastest, bijective XCD remap (block b runs on XCD b % 8) so tiles sharing activations /
+//   halo rows share an L2.
 #include "common.h"
 #include "detmath.h"
 
@@ -40,7 +43,7 @@ struct ConvParams {
     float *vq_part;
     int vq_nblk;
     int B, H, W, Cin, Cout, ksz, stride, pad, up2, act, Ho, Wo;
-    int M, K, nchunks, taps, MB, NB;
+    int M, K, nchunks, taps, MB, NB, NT32;
     int tilesX, tilesY;
 };
 
@@ -49,35 +52,39 @@ constexpr int ALD = BK + 1;
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ, bool WVEC>
+__device__ __forceinline__ float f4get(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk)
+{
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+}
+
+// C/D layout of a 32x32 MFMA tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+
+// =================================================================================================================
+// conv_igemm: implicit GEMM, M = B*Ho*Wo pixels, N = Cout, K chunks of 32
+// =================================================================================================================
+template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_igemm_kernel(const ConvParams p)
 {
+    constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int NT = WM * WN * 64;             // 256 (4 waves) or 512 (8 waves, 2 per SIMD inside the block)
     constexpr int RSTEP = NT / 8;                // A rows covered per unit round
     constexpr int AROWS = BM / RSTEP;            // A float4 units per thread
-    constexpr int BUNITS = (BK * BN / 4) / NT;   // B float4 units per thread
-    static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && BUNITS >= 1 && AROWS >= 1, "tile config");
+    static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && AROWS >= 1, "tile config");
     static_assert(CINVEC || PRO == FEMASR_PRO_NONE, "generic-Cin path has no prologue");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                  // [2][BM][ALD]
-    float *Bs = smem + 2 * BM * ALD;   // [2][BK][BN]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-
-    // ---- XCD-aware, bijective block -> tile remap (block b runs on XCD b % 8)
-    int L;
-    {
-        const int nblk = p.MB * p.NB, bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-    }
+    const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
     const int nb = L % p.NB, mb = L / p.NB;
     const int m0 = mb * BM, n0 = nb * BN;
 
-    // ---- per-thread A rows: (mrow + 32 j, k-quad kq)
+    // ---- per-thread A rows: (mrow + RSTEP j, k-quad kq)
     const int kq = t & 7, mrow = t >> 3;
     int rn[AROWS], riy[AROWS], rix[AROWS];
     float lmean[AROWS], lrstd[AROWS];
@@ -104,21 +111,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     }
     const int Hv = p.up2 ? 2 * p.H : p.H, Wv = p.up2 ? 2 * p.W : p.W;
 
-    float4 ra[AROWS], rga[AROWS], rgb[AROWS], rb[BUNITS];
+    float4 ra[AROWS], rga[AROWS], rgb[AROWS];
     float4 lng, lnb;
-    unsigned amask = 0, bmask = 0;
+    unsigned amask = 0;
 
-    // ---- global -> register staging of K-chunk c
+    // ---- global -> register staging of the A part of K-chunk c (branch-free: out-of-image taps / tail rows read
+    //      element 0 and are zeroed at store time, so the loads stay in flight across the MFMA steps)
     auto load_chunk = [&](int c) {
         amask = 0;
-        bmask = 0;
         if (CINVEC) {
-            const int cc = c / p.taps, tap = c - cc * p.taps, c0 = cc * BK + 4 * kq;   // K order: (cin/32, ky, kx, cin%32)
+            const int cc = c / p.taps, tap = c - cc * p.taps, c0 = cc * BK + 4 * kq;
             const int ky = tap / p.ksz, kx = tap - ky * p.ksz;
 #pragma unroll
             for (int j = 0; j < AROWS; ++j) {
-                // branch-free: out-of-image taps / tail rows read element 0 and are zeroed at store time,
-                // so all loads of a chunk issue back-to-back and stay in flight across the MFMA steps
                 const int iy = riy[j] + ky, ix = rix[j] + kx;
                 const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
                 const int sy = p.up2 ? (iy >> 1) : iy, sx = p.up2 ? (ix >> 1) : ix;
@@ -156,35 +161,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
                 amask |= 1u << j;
             }
         }
-#pragma unroll
-        for (int u = 0; u < BUNITS; ++u) {
-            const int unit = t + NT * u;
-            const int nq = unit % (BN / 4), kr = unit / (BN / 4);
-            const int k = c * BK + kr, n = n0 + 4 * nq;
-            float4 v;
-            if (WVEC) {
-                // Cout % 4 == 0: one 16-B load; rows past K / columns past Cout read row 0 and are zeroed
-                const bool ok = (k < p.K) & (n < p.Cout);
-                v = ld4(p.w + (ok ? ((size_t)k * p.Cout + n) : (size_t)0));
-                bmask |= (ok ? 1u : 0u) << u;          // zeroed at store time (keeps the load in flight)
-            } else {
-                v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < p.K) {
-                    const float *wp = p.w + (size_t)k * p.Cout + n;
-                    if (n + 0 < p.Cout) v.x = wp[0];
-                    if (n + 1 < p.Cout) v.y = wp[1];
-                    if (n + 2 < p.Cout) v.z = wp[2];
-                    if (n + 3 < p.Cout) v.w = wp[3];
-                }
-            }
-            rb[u] = v;
-        }
     };
 
     // ---- registers -> LDS (with the fused normalisation / activation prologue)
     auto store_chunk = [&](int buf) {
         float *Ab = As + buf * BM * ALD;
-        float *Bb = Bs + buf * BK * BN;
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
             float4 v = ra[j];
@@ -206,14 +187,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
             dst[2] = v.z;
             dst[3] = v.w;
         }
-#pragma unroll
-        for (int u = 0; u < BUNITS; ++u) {
-            const int unit = t + NT * u;
-            const int nq = unit % (BN / 4), kr = unit / (BN / 4);
-            float4 v = rb[u];
-            if (WVEC && !(bmask & (1u << u))) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(Bb + kr * BN + 4 * nq) = v;
-        }
     };
 
     f32x16 acc[TM][TN];
@@ -224,48 +197,62 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // B fragments: lane-contiguous 16 floats per (chunk, 32-column tile); chunk stride = NT32 * 1024 floats
+    const float *wl[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        wl[j] = p.w + ((((size_t)(n0 >> 5) + wn * TN + j) * 64 + lane) << 4);
+    const size_t wstride = (size_t)p.NT32 << 10;
+
     load_chunk(0);
+    float4 bc[TN], bn[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bc[j] = ld4(wl[j]);
     store_chunk(0);
     __syncthreads();
 
     const int arow = (wm * TM * 32 + (lane & 31)) * ALD + (lane >> 5);
-    const int bcol = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
 
     for (int c = 0; c < p.nchunks; ++c) {
         const int buf = c & 1;
         const bool more = (c + 1) < p.nchunks;
         if (more) load_chunk(c + 1);
         const float *Ab = As + buf * BM * ALD + arow;
-        const float *Bb = Bs + buf * BK * BN + bcol;
-        // fragments of k-pair kk+1 are fetched from LDS before the MFMAs of k-pair kk are issued, so one wave
-        // alone keeps its SIMD's matrix pipe fed (the LDS latency hides behind 4 x 64 cycles of MFMA)
-        float af[2][TM], bf[2][TN];
+        float af[2][TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = Ab[i * 32 * ALD];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = Bb[j * 32];
-#pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
+            const int cur = kk & 1, nxt = cur ^ 1, g = kk >> 2, e = kk & 3;
+            if (e == 0) {       // prefetch the next 4 k-pairs of weight fragments (next chunk's first 4 at the end)
+                if (g < 3) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)c * wstride + 4 * (g + 1));
+                } else if (more) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)(c + 1) * wstride);
+                }
+            }
             if (kk + 1 < BK / 2) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[nxt][i] = Ab[i * 32 * ALD + 2 * (kk + 1)];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[nxt][j] = Bb[2 * (kk + 1) * BN + j * 32];
             }
-            __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this k-pair's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], f4get(bc[j], e), acc[i][j], 0, 0, 0);
+            if (e == 3) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bc[j] = bn[j];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (!VQ) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -288,7 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
             }
     } else {
         // d = (|z|^2 + |e|^2) - 2 z.e ; first-min over this block's BN columns, per row.
-        float *red = smem;   // [WN][BM][2]  (A/B buffers are dead after the loop's last barrier)
+        float *red = smem;   // [WN][BM][2]  (the A buffers are dead after the loop's last barrier)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -318,7 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
                 }
             }
         __syncthreads();
-        if (t < BM && m0 + t < p.M) {   // (BM <= NT)
+        if (t < BM && m0 + t < p.M) {
             float bd = red[t * 2];
             int bi = __float_as_int(red[t * 2 + 1]);
 #pragma unroll
@@ -334,47 +321,29 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// 3x3 / stride-1 convolution with HALO RE-USE (the 753 of 964 GFLOP per tile that are 3x3 convs).
-// A block owns an 8 x 16 patch of output pixels of ONE image (BM = 128) and BN output channels.  For
-// each 32-channel block of the input it stages the (8+2) x (16+2) input halo patch (6 x 10 low-res
-// pixels when the nearest-x2 upsample is fused) ONCE — GroupNorm-apply + SiLU evaluated once per
-// staged element — and sweeps all 9 taps over it straight from LDS: the MFMA A-fragment of tap
-// (ky,kx) is the same LDS image read at a shifted pixel.  Versus the im2col kernel above this cuts
-// global loads, prologue VALU work and LDS stores per MFMA by 6.4x (9 x 128 -> 180 pixel-chunks).
-// K order = (cin/32, ky, kx, cin%32): exactly the oracle's blocked fmaf chain.
-// Pipeline: weights of the next (channel-block, tap) and — at tap 0 — the next channel block's
-// patch are loaded to registers before the 16 MFMA k-pair steps and written to the alternate LDS
-// buffers after them; one barrier per tap.
-// ------------------------------------------------------------------------------------------------
-template <int BN, int WM, int WN, int PRO, bool UP2, bool WVEC>
+// =================================================================================================================
+// conv3x3_halo: 8 x 16 output pixels of one image x BN channels per block, halo patch per 32-channel block
+// =================================================================================================================
+template <int BN, int WM, int WN, int PRO, bool UP2>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_halo_kernel(const ConvParams p)
 {
     constexpr int BM = 128, TW = 16;
-    constexpr int PH = UP2 ? 6 : 10, PW = UP2 ? 10 : 18, PP = PH * PW;
-    constexpr int NT = WM * WN * 64;              // 256 (4 waves) or 512 (8 waves: 2 per SIMD inside the block)
+    constexpr int PH = UP2 ? 6 : 10, PW = UP2 ? 10 : 18, PP = PH * PW;     // low-res halo patch when x2 is fused
+    constexpr int NT = WM * WN * 64;
     constexpr int PUNITS = (PP * 8 + NT - 1) / NT;
-    constexpr int PROWS = NT / 8;                 // patch pixels covered per unit round
+    constexpr int PROWS = NT / 8;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int BUNITS = (BK * BN / 4) / NT;
-    static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && BUNITS >= 1, "tile config");
+    static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "tile config");
     static_assert(PRO != FEMASR_PRO_LN, "no LayerNorm prologue on 3x3 convs");
+    static_assert(2 + PUNITS <= BK / 2, "patch slices must fit the 16 k-pair steps of one tap");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PSZ = ((PP * ALD + 3) / 4) * 4;
     float *Ps = smem;               // [2][PP][ALD]
-    float *Bs = smem + 2 * PSZ;     // [2][BK][BN]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-
-    int L;
-    {
-        const int nblk = p.MB * p.NB, bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-    }
+    const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
     const int nb = L % p.NB;
     int tile = L / p.NB;
     const int tx = tile % p.tilesX;
@@ -384,7 +353,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     const int oy0 = ty * 8, ox0 = tx * TW, n0 = nb * BN;
     const int sy0 = UP2 ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UP2 ? (ox0 >> 1) - 1 : ox0 - 1;
 
-    // ---- this thread's patch units: (pixel = (t>>3) + 32 i, channel quad kq)
+    // ---- this thread's patch units: (pixel = (t>>3) + PROWS i, channel quad kq)
     const int kq = t & 7;
     unsigned poff[PUNITS];
     unsigned pmask = 0;
@@ -398,8 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         pmask |= (ok ? 1u : 0u) << i;
     }
 
-    float4 rp[PUNITS], rb[BUNITS], ga, gb;
-    unsigned bmask = 0;
+    float4 rp[PUNITS], ga, gb;
 
     auto load_patch = [&](int cc) {
 #pragma unroll
@@ -427,45 +395,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         dst[2] = v.z;
         dst[3] = v.w;
     };
-    auto store_patch = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < PUNITS; ++i) store_patch_unit(buf, i);
-    };
-    auto load_w = [&](int q) {      // q = cc * 9 + tap : rows q*32 .. q*32+31 of the repacked weights
-        bmask = 0;
-#pragma unroll
-        for (int u = 0; u < BUNITS; ++u) {
-            const int unit = t + NT * u;
-            const int nq = unit % (BN / 4), kr = unit / (BN / 4);
-            const int k = q * BK + kr, nn = n0 + 4 * nq;
-            float4 v;
-            if (WVEC) {
-                const bool ok = nn < p.Cout;
-                v = ld4(p.w + (ok ? ((size_t)k * p.Cout + nn) : (size_t)0));
-                bmask |= (ok ? 1u : 0u) << u;
-            } else {
-                v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float *wp = p.w + (size_t)k * p.Cout + nn;
-                if (nn + 0 < p.Cout) v.x = wp[0];
-                if (nn + 1 < p.Cout) v.y = wp[1];
-                if (nn + 2 < p.Cout) v.z = wp[2];
-                if (nn + 3 < p.Cout) v.w = wp[3];
-            }
-            rb[u] = v;
-        }
-    };
-    auto store_w_unit = [&](int buf, int u) {
-        float *Bb = Bs + buf * BK * BN;
-        const int unit = t + NT * u;
-        const int nq = unit % (BN / 4), kr = unit / (BN / 4);
-        float4 v = rb[u];
-        if (WVEC && !(bmask & (1u << u))) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(Bb + kr * BN + 4 * nq) = v;
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < BUNITS; ++u) store_w_unit(buf, u);
-    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -475,11 +404,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const float *wl[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        wl[j] = p.w + ((((size_t)(n0 >> 5) + wn * TN + j) * 64 + lane) << 4);
+    const size_t wstride = (size_t)p.NT32 << 10;
+
     const int ncc = p.Cin / BK;
     load_patch(0);
-    load_w(0);
-    store_patch(0);
-    store_w(0);
+    float4 bc[TN], bn[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bc[j] = ld4(wl[j]);
+#pragma unroll
+    for (int i = 0; i < PUNITS; ++i) store_patch_unit(0, i);
     __syncthreads();
 
     // lane's output pixels: m_i = (wm*TM + i)*32 + (lane&31) -> (py, px) = (m >> 4, m & 15)
@@ -490,15 +427,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
         for (int i = 0; i < TM; ++i) py[i] = (m >> 4) + 2 * i;
     }
-    const int bcol = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
 
     for (int cc = 0; cc < ncc; ++cc) {
         const float *Pb = Ps + (cc & 1) * PSZ + (lane >> 5);
+        const bool more_p = cc + 1 < ncc;
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int q = cc * 9 + tap;
             const bool more_w = (q + 1) < ncc * 9;
-            const bool more_p = (tap == 0) && (cc + 1 < ncc);
             const int ky = tap / 3, kx = tap - ky * 3;
             int aidx[TM];
 #pragma unroll
@@ -507,47 +443,45 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
                 const int pcol = UP2 ? ((px + kx - 1) >> 1) + 1 : px + kx;
                 aidx[i] = (prow * PW + pcol) * ALD;
             }
-            const float *Bb = Bs + (q & 1) * BK * BN + bcol;
-            // The staging work of the NEXT tap (weights) / channel block (patch) is cut into slices that sit
-            // BETWEEN the 16 MFMA k-pair steps of this tap, so VALU / LDS-store / global-load issue overlaps
-            // the matrix pipe inside every wave instead of alternating with it in lock-step across the CU.
-            constexpr int KW0 = BK / 2 - BUNITS;          // weight-tile stores in the last BUNITS steps
-            constexpr int KP0 = KW0 - PUNITS;             // patch units just before them
-            static_assert(KP0 >= 2, "not enough k-pair steps to hide the staging slices");
-            float af[2][TM], bf[2][TN];
+            // the next channel block's patch is loaded at tap 0 and normalised / activated / stored at tap 1 in slices
+            // that sit between the MFMA k-pair steps (one unit per step), i.e. in the matrix pipe's shadow
+            const bool ld_p = more_p && tap == 0;
+            const bool st_p = more_p && tap == 1;
+            float af[2][TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[0][i] = Pb[aidx[i]];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = Bb[j * 32];
-#pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
-                const int cur = kk & 1, nxt = cur ^ 1;
-                if (kk + 1 < BK / 2) {     // prefetch the next k-pair's fragments before issuing this one's MFMAs
+                const int cur = kk & 1, nxt = cur ^ 1, g = kk >> 2, e = kk & 3;
+                if (e == 0) {
+                    if (g < 3) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)q * wstride + 4 * (g + 1));
+                    } else if (more_w) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)(q + 1) * wstride);
+                    }
+                }
+                if (kk + 1 < BK / 2) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[nxt][i] = Pb[aidx[i] + 2 * (kk + 1)];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[nxt][j] = Bb[2 * (kk + 1) * BN + j * 32];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                if (kk == 0) {
-                    if (more_w) load_w(q + 1);
-                    if (more_p) load_patch(cc + 1);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], f4get(bc[j], e), acc[i][j], 0, 0, 0);
+                if (e == 3) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bc[j] = bn[j];
                 }
-                if (kk >= KP0 && kk < KW0) {
-                    if (more_p) store_patch_unit((cc + 1) & 1, kk - KP0);
-                }
-                if (kk >= KW0) {
-                    if (more_w) store_w_unit((q + 1) & 1, kk - KW0);
-                }
+                if (kk == 1 && ld_p) load_patch(cc + 1);
+                if (kk >= 2 && kk < 2 + PUNITS && st_p) store_patch_unit((cc + 1) & 1, kk - 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
         }
+        __syncthreads();     // patch buffers swap: ONE barrier per 32-channel block (9 taps x 16 MFMA steps)
     }
 
 #pragma unroll
@@ -571,14 +505,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         }
 }
 
-template <int BN, bool UP2>
+template <bool UP2>
 constexpr size_t halo_lds_bytes()
 {
-    return (size_t)(2 * ((((UP2 ? 60 : 180) * ALD + 3) / 4) * 4) + 2 * BK * BN) * sizeof(float);
+    return (size_t)(2 * ((((UP2 ? 60 : 180) * ALD + 3) / 4) * 4)) * sizeof(float);
 }
 
-template <int BM, int BN>
-constexpr size_t conv_lds_bytes() { return (size_t)(2 * BM * ALD + 2 * BK * BN) * sizeof(float); }
+template <int BM>
+constexpr size_t conv_lds_bytes() { return (size_t)(2 * BM * ALD) * sizeof(float); }
 
 struct Variant {
     const char *name;
@@ -589,37 +523,36 @@ struct Variant {
     int threads;
 };
 
-#define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ, WVEC)                                             \
-    { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",wvec=" #WVEC ",waves=" #WM "x" #WN ">", BM, BN,        \
-      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ, WVEC>, conv_lds_bytes<BM, BN>(), false, WM * WN * 64 }
-
-#define FEMASR_HALO(BN, WM, WN, PRO, UP2, WVEC)                                                        \
-    { "conv3x3_halo<8x16x" #BN "," #PRO ",up2=" #UP2 ",wvec=" #WVEC ",waves=" #WM "x" #WN ">", 128, BN,                      \
-      conv3x3_halo_kernel<BN, WM, WN, PRO, UP2, WVEC>, halo_lds_bytes<BN, UP2>(), false, WM * WN * 64 }
+#define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ)                                                       \
+    { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",waves=" #WM "x" #WN ">", BM, BN,     \
+      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ>, conv_lds_bytes<BM>(), false, WM * WN * 64 }
+#define FEMASR_HALO(BN, WM, WN, PRO, UP2)                                                                  \
+    { "conv3x3_halo<8x16x" #BN "," #PRO ",up2=" #UP2 ",waves=" #WM "x" #WN ">", 128, BN,                   \
+      conv3x3_halo_kernel<BN, WM, WN, PRO, UP2>, halo_lds_bytes<UP2>(), false, WM * WN * 64 }
 
 Variant g_variants[] = {
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, false, true),     // 0 (8 waves)
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_GN_SILU, true, false, true),  // 1
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_LN, true, false, true),       // 2
-    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, true, false, true),      // 3
-    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_GN_SILU, true, false, true),   // 4
-    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_LN, true, false, true),        // 5
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false, false),     // 6  any Cout (out_conv: Cout = 3)
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_GN_SILU, true, false, false),  // 7
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false, false),       // 8
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, false, false, true),    // 9  generic Cin (in_conv)
-    FEMASR_VARIANT(128, 64, 4, 1, FEMASR_PRO_NONE, false, false, true),     // 10
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false, false, false),    // 11
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, true, true),      // 12 VQ distance + argmin
-    FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, false, true),                   // 13 3x3 s1 halo kernels
-    FEMASR_HALO(128, 4, 2, FEMASR_PRO_GN_SILU, false, true),                // 14 (8 waves)
-    FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, true, true),                    // 15 fused nearest-x2
-    FEMASR_HALO(64, 4, 2, FEMASR_PRO_NONE, false, true),                    // 16
-    FEMASR_HALO(64, 4, 2, FEMASR_PRO_GN_SILU, false, true),                 // 17 (8 waves)
-    FEMASR_HALO(64, 4, 2, FEMASR_PRO_NONE, true, true),                     // 18
-    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, false, false),                   // 19 any Cout (out_conv)
-    FEMASR_HALO(32, 4, 1, FEMASR_PRO_GN_SILU, false, false),                // 20
-    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, true, false),                    // 21
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, false),     // 0
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_GN_SILU, true, false),  // 1
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_LN, true, false),       // 2
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, true, false),      // 3
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_GN_SILU, true, false),   // 4
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_LN, true, false),        // 5
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false),      // 6
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_GN_SILU, true, false),   // 7
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false),        // 8
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, false, false),    // 9  generic Cin (in_conv)
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, false, false),     // 10
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false, false),     // 11
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, true),      // 12 VQ distance + argmin
+    FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, false),                   // 13 3x3 s1 halo kernels
+    FEMASR_HALO(128, 4, 2, FEMASR_PRO_GN_SILU, false),                // 14
+    FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, true),                    // 15 fused nearest-x2
+    FEMASR_HALO(64, 4, 2, FEMASR_PRO_NONE, false),                    // 16
+    FEMASR_HALO(64, 4, 2, FEMASR_PRO_GN_SILU, false),                 // 17
+    FEMASR_HALO(64, 4, 2, FEMASR_PRO_NONE, true),                     // 18
+    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, false),                    // 19 (out_conv, Cout = 3)
+    FEMASR_HALO(32, 4, 1, FEMASR_PRO_GN_SILU, false),                 // 20
+    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, true),                     // 21
 };
 constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
 
@@ -634,8 +567,7 @@ int pick_variant(const femasr_conv_args *a, bool vq)
 {
     const bool vec = (a->Cin % BK) == 0;
     if (vq) return 12;
-    // BN by Cout; the 16-byte weight loads need Cout % 4 == 0, anything else goes to the BN=32 scalar-load variants
-    const int cls = (a->Cout & 3) ? 2 : (a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2));
+    const int cls = a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2);     // BN = 128 / 64 / 32
     if (use_halo(a, vq)) return 13 + cls * 3 + (a->up2 ? 2 : a->prologue);
     if (!vec) return 9 + cls;
     return cls * 3 + a->prologue;
@@ -671,6 +603,7 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.ksz = a->ksz; p.stride = a->stride;
     p.pad = a->pad; p.up2 = a->up2; p.act = a->act; p.Ho = Ho; p.Wo = Wo;
     p.M = (int)M; p.K = a->ksz * a->ksz * a->Cin; p.nchunks = (p.K + BK - 1) / BK; p.taps = a->ksz * a->ksz;
+    p.NT32 = (a->Cout + 31) / 32;
     const int vi = pick_variant(a, vq != nullptr);
     Variant &v = g_variants[vi];
     p.MB = (p.M + v.bm - 1) / v.bm;

@@ -333,32 +333,40 @@ __global__ void codebook_gather_kernel(const long long *__restrict__ idx, long l
         *reinterpret_cast<float4 *>(zq + (size_t)row * D + c) = ld4(cb + (size_t)i * D + c);
 }
 
-// OIHW -> the library's K-major weight layout, rows = K index, O contiguous:
-//   I % 32 == 0:  k = ((ci/32)*kh*kw + y*kw + x)*32 + ci%32      (channel blocks outermost)
-//   otherwise  :  k = (y*kw + x)*I + ci
+// OIHW -> the FRAGMENT-MAJOR weight layout the conv kernels read straight into MFMA B operands:
+//   out[q][ntile][lane][kk],  q = k/32, kk = (k%32)/2, lane = (k&1)*32 + n%32, ntile = n/32,  zero padded
+//   K order:  I % 32 == 0:  k = ((ci/32)*kh*kw + y*kw + x)*32 + ci%32      (channel blocks outermost)
+//             otherwise  :  k = (y*kw + x)*I + ci
 // thread per OUTPUT element (coalesced stores)
 __global__ void repack_oihw_kernel(const float *__restrict__ in, int O, int I, int kh, int kw, float *__restrict__ out,
                                    size_t total)
 {
     const bool blocked = (I % 32) == 0;
+    const int K = I * kh * kw, NT32 = (O + 31) / 32;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int o = (int)(i % O);
-        size_t k = i / O;
-        int ci, x, y;
-        if (blocked) {
-            const int cl = (int)(k % 32);
-            k /= 32;
-            x = (int)(k % kw);
-            k /= kw;
-            y = (int)(k % kh);
-            ci = (int)(k / kh) * 32 + cl;
-        } else {
-            ci = (int)(k % I);
-            k /= I;
-            x = (int)(k % kw);
-            y = (int)(k / kw);
+        const int kk = (int)(i & 15), lane = (int)((i >> 4) & 63);
+        const size_t rest = i >> 10;
+        const int ntile = (int)(rest % NT32), q = (int)(rest / NT32);
+        const int k = q * 32 + kk * 2 + (lane >> 5), o = ntile * 32 + (lane & 31);
+        float v = 0.f;
+        if (k < K && o < O) {
+            int ci, x, y;
+            if (blocked) {
+                const int cl = k % 32;
+                int r = k / 32;
+                x = r % kw;
+                r /= kw;
+                y = r % kh;
+                ci = (r / kh) * 32 + cl;
+            } else {
+                ci = k % I;
+                const int r = k / I;
+                x = r % kw;
+                y = r / kw;
+            }
+            v = in[(((size_t)o * I + ci) * kh + y) * kw + x];
         }
-        out[i] = in[(((size_t)o * I + ci) * kh + y) * kw + x];
+        out[i] = v;
     }
 }
 
@@ -524,10 +532,17 @@ int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, c
     return FEMASR_OK;
 }
 
+size_t femasr_packed_weight_floats(int O, int I, int kh, int kw)
+{
+    if (O <= 0 || I <= 0 || kh <= 0 || kw <= 0) return 0;
+    const size_t K = (size_t)I * kh * kw;
+    return ((K + 31) / 32) * (size_t)((O + 31) / 32) * 1024;
+}
+
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out)
 {
     FEMASR_REQUIRE(in && out && O > 0 && I > 0 && kh > 0 && kw > 0, "repack: bad args");
-    const size_t total = (size_t)O * I * kh * kw;
+    const size_t total = femasr_packed_weight_floats(O, I, kh, kw);
     hipLaunchKernelGGL(repack_oihw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, O, I, kh, kw, out,
                        total);
     FEMASR_CHECK_HIP(hipGetLastError());

@@ -648,7 +648,10 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
     if (!same) return femasr_set_error(FEMASR_ERR_WEIGHT, "set_weight: shape mismatch for '%s'", key);
     FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
     const size_t n = w.numel();
-    if (!w.dev) FEMASR_CHECK_HIP(hipMalloc((void **)&w.dev, n * sizeof(float)));
+    size_t alloc = n;
+    if (w.kind == W_CONV) alloc = femasr_packed_weight_floats((int)w.shape[0], (int)w.shape[1], (int)w.shape[2], (int)w.shape[3]);
+    if (w.kind == W_LINEAR) alloc = femasr_packed_weight_floats((int)w.shape[0], (int)w.shape[1], 1, 1);
+    if (!w.dev) FEMASR_CHECK_HIP(hipMalloc((void **)&w.dev, alloc * sizeof(float)));
     int rc = FEMASR_OK;
     if (w.kind == W_CONV)
         rc = femasr_repack_oihw(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], (int)w.shape[2], (int)w.shape[3], w.dev);
@@ -670,10 +673,10 @@ int femasr_finalize_weights(femasr_handle *h)
         if (!w.set) return femasr_set_error(FEMASR_ERR_WEIGHT, "finalize: weight '%s' was never set", w.key.c_str());
     FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
     const int n_e = h->cfg.n_e, D = h->cfg.e_dim;
-    if (!h->cbT) FEMASR_CHECK_HIP(hipMalloc((void **)&h->cbT, (size_t)n_e * D * sizeof(float)));
+    if (!h->cbT) FEMASR_CHECK_HIP(hipMalloc((void **)&h->cbT, femasr_packed_weight_floats(n_e, D, 1, 1) * sizeof(float)));
     if (!h->ee) FEMASR_CHECK_HIP(hipMalloc((void **)&h->ee, (size_t)n_e * sizeof(float)));
     const float *cb = h->specs[h->index["quantize_group.0.embedding.weight"]].dev;
-    int rc = femasr_repack_oihw(nullptr, cb, n_e, D, 1, 1, h->cbT);     // [D][n_e]
+    int rc = femasr_repack_oihw(nullptr, cb, n_e, D, 1, 1, h->cbT);     // packed z.e^T operand
     if (rc) return rc;
     rc = femasr_row_sqsum(nullptr, cb, n_e, D, h->ee);
     if (rc) return rc;

@@ -123,8 +123,7 @@ enum { FEMASR_ACT_NONE = 0, FEMASR_ACT_GELU = 1 };
 typedef struct {
     const float *in;      /* (B,H,W,Cin) NHWC, pre-upsample size */
     int32_t B, H, W, Cin;
-    const float *w;       /* K-major rows x Cout: k = ((ci/32)*ksz*ksz + ky*ksz + kx)*32 + ci%32 when
-                             Cin % 32 == 0, else k = (ky*ksz + kx)*Cin + ci  (what femasr_repack_oihw emits) */
+    const float *w;       /* packed weights as emitted by femasr_repack_oihw (fragment-major, see there) */
     const float *bias;    /* [Cout] */
     int32_t Cout, ksz, stride, pad, up2;
     int32_t prologue;     /* FEMASR_PRO_* */
@@ -156,8 +155,12 @@ int femasr_vq(void *stream, const float *z, int64_t M, int D, const float *cb, c
               const float *ee, int n_e, int64_t *idx, float *zq, void *scratch);
 int femasr_row_sqsum(void *stream, const float *x, int64_t rows, int D, float *out);
 int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, const float *cb, int n_e, float *zq);
-/* OIHW -> the K-major weight layout of femasr_conv_args.w (also (out,in)->(in,out) with kh=kw=1, and
- * codebook^T). */
+/* OIHW -> the packed FRAGMENT-MAJOR weight layout of femasr_conv_args.w (also nn.Linear (out,in) with kh=kw=1
+ * and the codebook for femasr_vq):  out[q][ntile][lane][kk], zero padded, with
+ *   K index k = ((ci/32)*kh*kw + ky*kw + kx)*32 + ci%32 when I % 32 == 0, else (ky*kw + kx)*I + ci;
+ *   q = k/32, kk = (k%32)/2, lane = (k&1)*32 + o%32, ntile = o/32.
+ * `out` must hold femasr_packed_weight_floats(O,I,kh,kw) floats. */
+size_t femasr_packed_weight_floats(int O, int I, int kh, int kw);
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out);
 
 /* ---- image pre / post-processing (the steps either side of the path) ---- */

@@ -12,21 +12,29 @@ def dev(a, device='cuda'):
 
 
 def lib_weight_layout(w_khwc):
-    """Oracle layout [kh][kw][Cin][Cout] -> the library's K-major rows (include/femasr_hip.h, femasr_conv_args.w):
-    channel blocks of 32 outermost when Cin % 32 == 0, plain (ky,kx,cin) otherwise."""
+    """Oracle layout [kh][kw][Cin][Cout] -> the library's packed FRAGMENT-MAJOR layout (numpy restatement of
+    femasr_repack_oihw, include/femasr_hip.h): out[q][ntile][lane][kk], zero padded."""
     kh, kw, cin, cout = w_khwc.shape
-    if cin % 32:
-        return np.ascontiguousarray(w_khwc)
-    return np.ascontiguousarray(w_khwc.reshape(kh, kw, cin // 32, 32, cout).transpose(2, 0, 1, 3, 4))
+    if cin % 32 == 0:       # K order: channel blocks of 32 outermost
+        rows = w_khwc.reshape(kh, kw, cin // 32, 32, cout).transpose(2, 0, 1, 3, 4).reshape(-1, cout)
+    else:
+        rows = w_khwc.reshape(-1, cout)
+    k = rows.shape[0]
+    kp, npad = (k + 31) // 32 * 32, (cout + 31) // 32 * 32
+    full = np.zeros((kp, npad), np.float32)
+    full[:k, :cout] = rows
+    # [q][kk][kslot][ntile][col] -> [q][ntile][kslot][col][kk]
+    t = full.reshape(kp // 32, 16, 2, npad // 32, 32).transpose(0, 3, 2, 4, 1)
+    return np.ascontiguousarray(t).reshape(-1)
 
 
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
            res1=None, res2=None):
     """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout)."""
     lib = _lib.load()
+    cout = np.asarray(w_khwc).shape[-1]
     w_khwc = lib_weight_layout(np.asarray(w_khwc))
     b, h, w, cin = x.shape
-    cout = w_khwc.shape[-1]
     hv, wv = (2 * h, 2 * w) if up2 else (h, w)
     ho, wo = (hv + 2 * pad - ksz) // stride + 1, (wv + 2 * pad - ksz) // stride + 1
     tx, tw, tb = dev(x), dev(w_khwc), dev(bias)
@@ -87,7 +95,7 @@ def vq(z_rows, codebook):
     m, d = z_rows.shape
     n_e = codebook.shape[0]
     tz, tcb = dev(z_rows), dev(codebook)
-    cbt = torch.empty((d, n_e), dtype=torch.float32, device='cuda')
+    cbt = torch.empty(int(lib.femasr_packed_weight_floats(n_e, d, 1, 1)), dtype=torch.float32, device='cuda')
     ee = torch.empty((n_e,), dtype=torch.float32, device='cuda')
     _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(tcb), n_e, d, 1, 1, _lib.ptr(cbt)))
     _lib.check(lib.femasr_row_sqsum(None, _lib.ptr(tcb), n_e, d, _lib.ptr(ee)))

@@ -157,7 +157,7 @@ def test_vq_bit_exact_and_first_min_tie(cuda_device):
     idx_ref, zq_ref = orc.vq(z, cb)
     idx, zq, cbt, ee = G.vq(z, cb)
     assert idx[0] == 13 and idx[200] == 13
-    assert np.array_equal(cbt, cb.T)
+    assert np.array_equal(cbt, G.lib_weight_layout(cb.T.reshape(1, 1, 512, 1024)))
     _same(idx, idx_ref, 'vq indices')
     _same(zq, zq_ref, 'vq z_q')
     # reference init regime: codes tiny against |z|^2 -> distances quantised to the ulp of |z|^2, many exact ties
@@ -176,7 +176,7 @@ def test_repack_oihw_layout(cuda_device):
     for (o, i, k) in ((40, 64, 3), (8, 3, 4), (16, 96, 1)):
         w = synth.uniform(9, f'rw{o}{i}{k}', (o, i, k, k), -1, 1)
         tw = G.dev(w)
-        out = torch.empty(o * i * k * k, dtype=torch.float32, device='cuda')
+        out = torch.empty(int(lib.femasr_packed_weight_floats(o, i, k, k)), dtype=torch.float32, device='cuda')
         _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(tw), o, i, k, k, _lib.ptr(out)))
         ref = G.lib_weight_layout(orc.repack_conv_weight(w)).reshape(-1)
         _same(out.cpu().numpy(), ref, f'repack {o}x{i}x{k}')
