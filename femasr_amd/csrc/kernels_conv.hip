@@ -65,7 +65,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk)
 // =================================================================================================================
 // conv_igemm: implicit GEMM, M = B*Ho*Wo pixels, N = Cout, K chunks of 32
 // =================================================================================================================
-template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ>
+template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ, bool K1>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_igemm_kernel(const ConvParams p)
 {
     constexpr int NT = WM * WN * 64;
@@ -74,11 +74,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     constexpr int AROWS = BM / RSTEP;            // A float4 units per thread
     static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && AROWS >= 1, "tile config");
     static_assert(CINVEC || PRO == FEMASR_PRO_NONE, "generic-Cin path has no prologue");
+    static_assert(!K1 || CINVEC, "K1 (1x1 / linear fast addressing) needs Cin % 32 == 0");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                  // [2][BM][ALD]
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform -> SGPR arithmetic
     const int wm = wave / WN, wn = wave % WN;
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
     const int nb = L % p.NB, mb = L / p.NB;
@@ -92,7 +94,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
 #pragma unroll
     for (int j = 0; j < AROWS; ++j) {
         const int r = m0 + mrow + RSTEP * j;
-        if (r < p.M) {
+        if (K1) {
+            rn[j] = 0; riy[j] = 0; rix[j] = 0;
+            if (PRO == FEMASR_PRO_LN) {
+                lmean[j] = r < p.M ? p.pro_a[2 * (size_t)r] : 0.f;
+                lrstd[j] = r < p.M ? p.pro_a[2 * (size_t)r + 1] : 0.f;
+            }
+        } else if (r < p.M) {
             const int n = r / HoWo, rem = r - n * HoWo;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             rn[j] = n;
@@ -110,6 +118,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
         }
     }
     const int Hv = p.up2 ? 2 * p.H : p.H, Wv = p.up2 ? 2 * p.W : p.W;
+    // K1 (1x1 conv / nn.Linear): row r of the GEMM is row r of the input -> per-lane offsets are fixed per tile and
+    // only a scalar base moves with the K chunk (no per-chunk VALU address math)
+    unsigned aoff[AROWS];
+    unsigned k1mask = 0;
+    if (K1) {
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j) {
+            const bool ok = (m0 + mrow + RSTEP * j) < p.M;
+            aoff[j] = ok ? (unsigned)((mrow + RSTEP * j) * p.Cin + 4 * kq) : (unsigned)(4 * kq);
+            k1mask |= (ok ? 1u : 0u) << j;
+        }
+    }
 
     float4 ra[AROWS], rga[AROWS], rgb[AROWS];
     float4 lng, lnb;
@@ -119,7 +139,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     //      element 0 and are zeroed at store time, so the loads stay in flight across the MFMA steps)
     auto load_chunk = [&](int c) {
         amask = 0;
-        if (CINVEC) {
+        if (K1) {
+            const float *base = p.in + (size_t)m0 * p.Cin + c * BK;
+#pragma unroll
+            for (int j = 0; j < AROWS; ++j) ra[j] = ld4(base + aoff[j]);
+            amask = k1mask;
+            if (PRO == FEMASR_PRO_LN) {
+                lng = ld4(p.pro_b + c * BK + 4 * kq);
+                lnb = ld4(p.pro_c + c * BK + 4 * kq);
+            }
+        } else if (CINVEC) {
             const int cc = c / p.taps, tap = c - cc * p.taps, c0 = cc * BK + 4 * kq;
             const int ky = tap / p.ksz, kx = tap - ky * p.ksz;
 #pragma unroll
@@ -254,22 +283,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     }
 
     if (!VQ) {
+        // store: address = uniform (tile, wave, i, j, r) part in SGPRs + one per-lane offset, no per-element VALU
+        // address math; full tiles skip the bounds checks
+        const unsigned loff = (unsigned)((lane >> 5) * 4) * (unsigned)p.Cout + (unsigned)(lane & 31);
+        const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+                const int colu = n0 + (wn * TN + j) * 32;              // uniform
+                const int col = colu + (lane & 31);
                 const float bv = col < p.Cout ? p.bias[col] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < p.M && col < p.Cout) {
+                    const int rowu = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2);     // uniform
+                    const size_t ou = (size_t)rowu * p.Cout + colu;                         // uniform
+                    if (full || ((rowu + 4 * (lane >> 5)) < p.M && col < p.Cout)) {
                         float v = acc[i][j][r] + bv;
                         if (p.act == FEMASR_ACT_GELU) v = det_gelu(v);
-                        const size_t o = (size_t)row * p.Cout + col;
-                        if (p.res1) v = v + p.res1[o];
-                        if (p.res2) v = v + p.res2[o];
-                        p.out[o] = v;
+                        if (p.res1) v = v + (p.res1 + ou)[loff];
+                        if (p.res2) v = v + (p.res2 + ou)[loff];
+                        (p.out + ou)[loff] = v;
                     }
                 }
             }
@@ -523,27 +557,27 @@ struct Variant {
     int threads;
 };
 
-#define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ)                                                       \
-    { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",waves=" #WM "x" #WN ">", BM, BN,     \
-      conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ>, conv_lds_bytes<BM>(), false, WM * WN * 64 }
+#define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ, K1)                                                   \
+    { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",k1=" #K1 ",waves=" #WM "x" #WN ">",  \
+      BM, BN, conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ, K1>, conv_lds_bytes<BM>(), false, WM * WN * 64 }
 #define FEMASR_HALO(BN, WM, WN, PRO, UP2)                                                                  \
     { "conv3x3_halo<8x16x" #BN "," #PRO ",up2=" #UP2 ",waves=" #WM "x" #WN ">", 128, BN,                   \
       conv3x3_halo_kernel<BN, WM, WN, PRO, UP2>, halo_lds_bytes<UP2>(), false, WM * WN * 64 }
 
 Variant g_variants[] = {
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, false),     // 0
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_GN_SILU, true, false),  // 1
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_LN, true, false),       // 2
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, true, false),      // 3
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_GN_SILU, true, false),   // 4
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_LN, true, false),        // 5
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false),      // 6
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_GN_SILU, true, false),   // 7
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false),        // 8
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, false, false),    // 9  generic Cin (in_conv)
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, false, false),     // 10
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false, false),     // 11
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, true),      // 12 VQ distance + argmin
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, false, false),     // 0
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_GN_SILU, true, false, false),  // 1
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_LN, true, false, false),       // 2
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, true, false, false),      // 3
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_GN_SILU, true, false, false),   // 4
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_LN, true, false, false),        // 5
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false, false),      // 6
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_GN_SILU, true, false, false),   // 7
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false, false),        // 8
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, false, false, false),    // 9  generic Cin (in_conv)
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, false, false, false),     // 10
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false, false, false),     // 11
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, true, true),       // 12 VQ distance + argmin (K1 addressing)
     FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, false),                   // 13 3x3 s1 halo kernels
     FEMASR_HALO(128, 4, 2, FEMASR_PRO_GN_SILU, false),                // 14
     FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, true),                    // 15 fused nearest-x2
@@ -553,6 +587,12 @@ Variant g_variants[] = {
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, false),                    // 19 (out_conv, Cout = 3)
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_GN_SILU, false),                 // 20
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, true),                     // 21
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, false, true),     // 22 1x1 conv / nn.Linear fast addressing
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_LN, true, false, true),       // 23
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, true, false, true),      // 24
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_LN, true, false, true),        // 25
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false, true),      // 26
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false, true),        // 27
 };
 constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
 
@@ -570,6 +610,8 @@ int pick_variant(const femasr_conv_args *a, bool vq)
     const int cls = a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2);     // BN = 128 / 64 / 32
     if (use_halo(a, vq)) return 13 + cls * 3 + (a->up2 ? 2 : a->prologue);
     if (!vec) return 9 + cls;
+    const bool k1 = a->ksz == 1 && a->stride == 1 && a->pad == 0 && !a->up2 && a->prologue != FEMASR_PRO_GN_SILU;
+    if (k1) return 22 + cls * 2 + (a->prologue == FEMASR_PRO_LN ? 1 : 0);
     return cls * 3 + a->prologue;
 }
 
@@ -608,7 +650,7 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     Variant &v = g_variants[vi];
     p.MB = (p.M + v.bm - 1) / v.bm;
     p.NB = (p.Cout + v.bn - 1) / v.bn;
-    if (vi >= 13) {   // halo kernels: 2-D tiles of 8 x 16 output pixels per image
+    if (vi >= 13 && vi <= 21) {   // halo kernels: 2-D tiles of 8 x 16 output pixels per image
         p.tilesX = (Wo + 15) / 16;
         p.tilesY = (Ho + 7) / 8;
         p.MB = a->B * p.tilesX * p.tilesY;
