@@ -21,8 +21,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
+PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')   # from tools/rocpd_pmc_summary.py (rocprofv3 --pmc passes)
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 TILE_GFLOP = 964.47                  # algorithmic GFLOP per x4 128^2 tile (SURVEY 8d / BASELINE.md 3)
+
+
+def rocprof_kernel_name(bench_name):
+    """'conv3x3_halo<8x16x128,FEMASR_PRO_GN_SILU,up2=false,waves=4x2>' -> 'conv3x3_halo_kernel<128, 4, 2, 1, false>'."""
+    import re
+    pro = {'FEMASR_PRO_NONE': 0, 'FEMASR_PRO_GN_SILU': 1, 'FEMASR_PRO_LN': 2}
+    m = re.match(r'conv3x3_halo<8x16x(\d+),(\w+),up2=(\w+),waves=(\d)x(\d)>', bench_name)
+    if m:
+        return f'conv3x3_halo_kernel<{m.group(1)}, {m.group(4)}, {m.group(5)}, {pro[m.group(2)]}, {m.group(3)}>'
+    m = re.match(r'conv_igemm<(\d+)x(\d+),(\w+),cinvec=(\w+),vq=(\w+),k1=(\w+),waves=(\d)x(\d)>', bench_name)
+    if m:
+        return (f'conv_igemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(7)}, {m.group(8)}, {pro[m.group(3)]}, '
+                f'{m.group(4)}, {m.group(5)}, {m.group(6)}>')
+    return bench_name
 
 
 def main():
@@ -122,9 +137,16 @@ def main():
             tot_fl = sum(v[2] for v in convs.values())
             ach = fl / (ms * 1e-3) / 1e12
             psteps = args.profile_steps
+            traffic, traffic_src = None, None
+            if os.path.exists(PMC_TRAFFIC_JSON):
+                rec = json.load(open(PMC_TRAFFIC_JSON)).get(rocprof_kernel_name(dom))
+                if rec:
+                    traffic = round((rec['fetch_bytes_corrected'] + rec['write_bytes']) / 1e9, 4)
+                    traffic_src = ('GB per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
+                                   '(profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section)')
             res['roofline'] = {
                 'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                 'launches': n, 'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
                 'all_mfma_conv_kernels': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                    'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -103,31 +103,45 @@ __global__ void gn_rows_generic_kernel(const float *__restrict__ x, int B, int H
     part[tid * 2 + 1] = ss;
 }
 
-// level 2: thread (n, g) sums rows y ascending, then folds into a[n,c], b[n,c].
-__global__ void gn_finalize_kernel(const double *__restrict__ part, int B, int H, int W, int C, int G,
-                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                   float *__restrict__ a, float *__restrict__ b)
+// level 2: one block per sample; the (H x G x 2) fp64 row partials are streamed through LDS in coalesced
+// 64-row slabs and thread g adds its group's rows in ascending y (the specified order), then folds the moments
+// into a[n,c], b[n,c].
+constexpr int GN_SLAB = 64;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ part, int B, int H, int W, int C, int G,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float eps, float *__restrict__ a, float *__restrict__ b)
 {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= B * G) return;
-    const int n = tid / G, g = tid % G, cg = C / G;
+    extern __shared__ __attribute__((aligned(16))) double slab[];      // [GN_SLAB][G][2]
+    const int n = blockIdx.x, t = threadIdx.x, cg = C / G;
+    const double *src = part + (size_t)n * H * G * 2;
     double S = 0.0, SS = 0.0;
-    for (int y = 0; y < H; ++y) {
-        const size_t o = (((size_t)n * H + y) * G + g) * 2;
-        S = S + part[o];
-        SS = SS + part[o + 1];
+    for (int y0 = 0; y0 < H; y0 += GN_SLAB) {
+        const int rows = (H - y0) < GN_SLAB ? (H - y0) : GN_SLAB;
+        const int cnt = rows * G * 2;
+        for (int i = t; i < cnt; i += blockDim.x) slab[i] = src[(size_t)y0 * G * 2 + i];
+        __syncthreads();
+        if (t < G) {
+            for (int y = 0; y < rows; ++y) {
+                S = S + slab[(y * G + t) * 2];
+                SS = SS + slab[(y * G + t) * 2 + 1];
+            }
+        }
+        __syncthreads();
     }
-    const double N = (double)H * (double)W * (double)cg;
-    const double mean = S / N;
-    double var = SS / N - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = 1.0f / sqrtf((float)var + eps);
-    const float meanf = (float)mean;
-    for (int j = 0; j < cg; ++j) {
-        const int c = g * cg + j;
-        const float ac = rstd * gamma[c];
-        a[n * C + c] = ac;
-        b[n * C + c] = __builtin_fmaf(-meanf, ac, beta[c]);
+    if (t < G) {
+        const int g = t;
+        const double N = (double)H * (double)W * (double)cg;
+        const double mean = S / N;
+        double var = SS / N - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = 1.0f / sqrtf((float)var + eps);
+        const float meanf = (float)mean;
+        for (int j = 0; j < cg; ++j) {
+            const int c = g * cg + j;
+            const float ac = rstd * gamma[c];
+            a[n * C + c] = ac;
+            b[n * C + c] = __builtin_fmaf(-meanf, ac, beta[c]);
+        }
     }
 }
 
@@ -459,8 +473,9 @@ int femasr_gn_coeffs(void *stream, const float *x, int B, int H, int W, int C, i
     else
         hipLaunchKernelGGL(gn_rows_generic_kernel, grid, blk, 0, s, x, B, H, W, C, G, cg, part);
     FEMASR_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((B * G + 63) / 64)), dim3(64), 0, s, part, B, H, W, C, G, gamma,
-                       beta, eps, a, b);
+    FEMASR_REQUIRE(G <= 256, "gn_coeffs: at most 256 groups");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), (size_t)GN_SLAB * G * 2 * sizeof(double), s, part, B, H,
+                       W, C, G, gamma, beta, eps, a, b);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

@@ -42,6 +42,14 @@ def main(out, dbs):
     txt = '\n'.join(lines) + '\n'
     open(out, 'w').write(txt)
     print(txt)
+    # machine-readable HBM traffic per launch (bytes): corrected fetch (x2, see header) + write
+    import json
+    traffic = {}
+    for name, d in data.items():
+        if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+            traffic[name] = {'fetch_bytes_corrected': 2 * d['FETCH_SIZE'][1] * 1024, 'write_bytes': d['WRITE_SIZE'][1] * 1024,
+                             'launches': max(v[0] for kk, v in d.items() if not kk.startswith('_'))}
+    json.dump(traffic, open(out.replace('.txt', '.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':
