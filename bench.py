@@ -48,6 +48,8 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='128x128 LR tiles per GPU per step')
     ap.add_argument('--streams', type=int, default=2, help='sub-batch streams inside one forward (femasr_set_streams)')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra serialized steps (streams=1) for the roofline object')
+    ap.add_argument('--decoder-math', choices=['fp32', 'bf16x3'], default='fp32',
+                    help="'bf16x3': convs behind the VQ lookup on the bf16 matrix cores (3-term split, within 1e-3)")
     ap.add_argument('--no-gather', action='store_true', help='N>1: skip the all-gather of upscaled tiles')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='do not record per-kernel HIP events')
@@ -69,6 +71,7 @@ def main():
     weights = synth_weights('x4', 0, 'trained')
     net = G.build_net('x4', weights, dev)
     net.num_streams = args.streams
+    net.decoder_math = args.decoder_math
     B = args.batch
     x = torch.from_numpy(synth.synth_input(1000 + rank, (B, 3, 128, 128))).to(dev)
     gathered = [torch.empty((B, 3, 512, 512), dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
@@ -113,6 +116,7 @@ def main():
         prof = net.profile()
         net.enable_profile(False)
         net.num_streams = args.streams
+    net.decoder_math = args.decoder_math
     assert torch.isfinite(y).all()
 
     out_mpix = world * B * 512 * 512 / 1e6
@@ -124,7 +128,7 @@ def main():
         'config': {'workload': f'x4 SR FeMaSRNet.test, batch {B} of 128x128 LR tiles per GPU -> 512x512 (padded 144->576 '
                                'inside, reference geometry), synthetic random-init weights (seed 0), inputs resident in HBM',
                    'global_batch': B * world, 'tile': '128x128->512x512', 'parallelism': f'tile-parallel x{world}',
-                   'gather': bool(world > 1 and not args.no_gather), 'streams': args.streams,
+                   'gather': bool(world > 1 and not args.no_gather), 'streams': args.streams, 'decoder_math': args.decoder_math,
                    'algorithmic_gflop_per_tile': TILE_GFLOP,
                    'end_to_end_tflops': round(TILE_GFLOP * B * world * args.steps / dt / 1e3, 2)},
     }

@@ -34,6 +34,7 @@ class ConvArgs(ctypes.Structure):
         ('act', ctypes.c_int32),
         ('res1', vp), ('res2', vp), ('out', vp),
         ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32),
+        ('w_bf16x3', vp),
     ]
 
 
@@ -72,6 +73,9 @@ SIGNATURES = {
     'femasr_codebook_gather': (c_int, [vp, vp, c_i64, c_int, vp, c_int, vp]),
     'femasr_repack_oihw': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'femasr_packed_weight_floats': (szt, [c_int, c_int, c_int, c_int]),
+    'femasr_packed_weight_bf16x3_bytes': (szt, [c_int, c_int, c_int, c_int]),
+    'femasr_repack_oihw_bf16x3': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
+    'femasr_set_decoder_math': (c_int, [vp, c_int]),
     'femasr_image_u8_to_f32': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_image_f32_to_u8': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
 }

@@ -178,6 +178,9 @@ class FeMaSRNet(nn.Module):
         self.max_tile_batch = 16        # tiles per batched test() call inside test_tile
         self.num_streams = 1            # sub-batch streams inside one forward (femasr_set_streams)
         self._streams_set = None
+        # 'fp32': every layer exact fp32 (bit-identical to the oracle).  'bf16x3': the convs BEHIND the codebook lookup
+        # run on the bf16 matrix cores with a 3-term hi/lo split (output within the 1e-3 bound, indices unaffected)
+        self.decoder_math = 'fp32'
 
     # ------------------------------------------------------------------ native handle
     def _native(self, device):
@@ -213,9 +216,12 @@ class FeMaSRNet(nn.Module):
             self._pushed[key] = stamp
         if dirty:
             _lib.check(lib.femasr_finalize_weights(self._handle))
-        if self._streams_set != (self._handle.value, self.num_streams):
+        if self._streams_set != (self._handle.value, self.num_streams, self.decoder_math):
+            if self.decoder_math not in ('fp32', 'bf16x3'):
+                raise ValueError(f"decoder_math must be 'fp32' or 'bf16x3', got {self.decoder_math!r}")
             _lib.check(lib.femasr_set_streams(self._handle, int(self.num_streams)))
-            self._streams_set = (self._handle.value, self.num_streams)
+            _lib.check(lib.femasr_set_decoder_math(self._handle, 1 if self.decoder_math == 'bf16x3' else 0))
+            self._streams_set = (self._handle.value, self.num_streams, self.decoder_math)
         return lib, self._handle
 
     def _release(self):

@@ -33,3 +33,9 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
                          int *variant_out, double *flops_out);
 int femasr_conv_variant_count();
 const char *femasr_conv_variant_name(int v);
+
+// bf16x3 3x3 halo convs (kernels_conv_bf16.hip)
+bool femasr_conv_bf16x3_eligible(const femasr_conv_args *a);
+int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out);
+int femasr_conv_bf16x3_variant_count();
+const char *femasr_conv_bf16x3_variant_name(int v);

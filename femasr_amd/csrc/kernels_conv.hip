@@ -29,36 +29,12 @@
 // Blocks: 512 threads = 8 waves (2 per SIMD; 2 blocks per CU), 128 output pixels x BN channels, BK = 32.
 // Grid: 1-D, n-blocks fastest, bijective XCD remap (block b runs on XCD b % 8) so tiles sharing activations /
 //   halo rows share an L2.
-#include "common.h"
+#include "conv_common.h"
 #include "detmath.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
-
-struct ConvParams {
-    const float *in, *w, *bias, *pro_a, *pro_b, *pro_c, *res1, *res2;
-    float *out;
-    const float *vq_zz, *vq_ee;
-    float *vq_part;
-    int vq_nblk;
-    int B, H, W, Cin, Cout, ksz, stride, pad, up2, act, Ho, Wo;
-    int M, K, nchunks, taps, MB, NB, NT32;
-    int tilesX, tilesY;
-};
-
-constexpr int BK = 32;
-constexpr int ALD = BK + 1;
-
-__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-
-__device__ __forceinline__ float f4get(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
-
-__device__ __forceinline__ int xcd_remap(int bid, int nblk)
-{
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-}
 
 // C/D layout of a 32x32 MFMA tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 

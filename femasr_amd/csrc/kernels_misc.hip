@@ -586,6 +586,10 @@ int femasr_image_f32_to_u8(void *stream, const float *in_chw, int H, int W, int 
 
 int femasr_conv2d(void *stream, const femasr_conv_args *a)
 {
+    if (a && a->w_bf16x3) {
+        FEMASR_REQUIRE(femasr_conv_bf16x3_eligible(a), "conv2d: w_bf16x3 given but the layer is not eligible for the bf16x3 path");
+        return femasr_conv_bf16x3_launch((hipStream_t)stream, a, nullptr, nullptr);
+    }
     return femasr_conv2d_launch((hipStream_t)stream, a, nullptr, nullptr, nullptr);
 }
 

@@ -64,6 +64,7 @@ struct WSpec {
     int64_t shape[4];
     int ndim;
     float *dev = nullptr;   // repacked, owned
+    void *split = nullptr;  // bf16x3 hi/lo fragments (decoder-side 3x3 convs only), owned
     bool set = false;
     size_t numel() const { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i]; return n; }
 };
@@ -142,6 +143,7 @@ struct femasr_handle {
     std::vector<std::string> slot_names;
     // sub-batch streams (femasr_set_streams): independent samples run on separate streams so that
     // one sub-batch's kernels fill the tail / HBM-bound phases of the other's
+    int decoder_math = 0;   // femasr_set_decoder_math
     int nsub = 1;
     std::vector<hipStream_t> sub_streams;
     std::vector<hipEvent_t> sub_done;
@@ -317,6 +319,7 @@ struct Ctx {
         int pro = FEMASR_PRO_NONE;
         const float *pa = nullptr, *pb = nullptr, *pc = nullptr;
         const float *res1 = nullptr, *res2 = nullptr;
+        bool lowp = false;       // behind the VQ lookup: may use the bf16x3 path when the handle opts in
     };
     T conv(const T &x, const std::string &prefix, int cout, const ConvOpt &o)
     {
@@ -330,10 +333,21 @@ struct Ctx {
         a.ksz = o.ksz; a.stride = o.stride; a.pad = o.pad; a.up2 = o.up2;
         a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
         a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
+        if (o.lowp && h->decoder_math) {
+            auto it = h->index.find(prefix + ".weight");
+            if (it != h->index.end()) a.w_bf16x3 = h->specs[it->second].split;
+        }
         if (rc) return y;
         Scope sc(h, s(), dry(), 0, 0.0, 0.0);
         int variant = 0; double flops = 0;
-        const int r = femasr_conv2d_launch(s(), &a, nullptr, &variant, &flops);
+        int r;
+        if (a.w_bf16x3 && femasr_conv_bf16x3_eligible(&a)) {
+            r = femasr_conv_bf16x3_launch(s(), &a, &variant, &flops);
+            variant += femasr_conv_variant_count();
+        } else {
+            a.w_bf16x3 = nullptr;
+            r = femasr_conv2d_launch(s(), &a, nullptr, &variant, &flops);
+        }
         sc.set_slot(SLOT_SMALL_COUNT + variant);
         sc.set_flops(flops);
         if (r && !rc) rc = r;
@@ -357,16 +371,16 @@ struct Ctx {
     }
 
     // fema_utils.py:65-84 (+ optional fused `x + enc_feats[i]`, femasr_arch.py:361-362)
-    T resblock(T x, const std::string &p, const float *res2, bool free_x)
+    T resblock(T x, const std::string &p, const float *res2, bool free_x, bool lowp = false)
     {
         const size_t bc = (size_t)x.B * x.C;
         float *ab = gn(x, p + ".conv.0.norm");
-        ConvOpt o1; o1.pro = FEMASR_PRO_GN_SILU; o1.pa = ab; o1.pb = ab ? ab + bc : nullptr;
+        ConvOpt o1; o1.pro = FEMASR_PRO_GN_SILU; o1.pa = ab; o1.pb = ab ? ab + bc : nullptr; o1.lowp = lowp;
         T u = conv(x, p + ".conv.2", x.C, o1);
         release(ab);
         float *ab2 = gn(u, p + ".conv.3.norm");
         ConvOpt o2; o2.pro = FEMASR_PRO_GN_SILU; o2.pa = ab2; o2.pb = ab2 ? ab2 + bc : nullptr;
-        o2.res1 = x.p; o2.res2 = res2;
+        o2.res1 = x.p; o2.res2 = res2; o2.lowp = lowp;
         T y = conv(u, p + ".conv.5", x.C, o2);
         release(ab2);
         release(u);
@@ -432,12 +446,12 @@ struct Ctx {
         return x;
     }
 
-    T up_block(const T &x, const std::string &p, int cout, const float *res2_last)   // Upsample x2 -> conv -> RB -> RB
+    T up_block(const T &x, const std::string &p, int cout, const float *res2_last, bool lowp = false)   // Upsample x2 -> conv -> RB -> RB
     {
-        ConvOpt o; o.up2 = 1;
+        ConvOpt o; o.up2 = 1; o.lowp = lowp;
         T c = conv(x, p + ".1", cout, o);
-        T r1 = resblock(c, p + ".2", nullptr, true);
-        return resblock(r1, p + ".3", res2_last, true);
+        T r1 = resblock(c, p + ".2", nullptr, true, lowp);
+        return resblock(r1, p + ".3", res2_last, true, lowp);
     }
 };
 
@@ -448,12 +462,12 @@ int run_decoder(Ctx &c, T x, T feats[3], bool fuse_skip, float *out_nchw, int cr
     for (int i = 0; i < h->max_depth; ++i) {
         const int r = cfg.gt_resolution / (1 << h->max_depth) * (1 << i);
         const float *skip = (fuse_skip && i + 1 < h->max_depth) ? feats[i + 1].p : nullptr;
-        T y = c.up_block(x, "decoder_group." + std::to_string(i) + ".block", channels_at(r * 2), skip);
+        T y = c.up_block(x, "decoder_group." + std::to_string(i) + ".block", channels_at(r * 2), skip, true);
         c.release(x);
         if (skip) c.release(feats[i + 1]);
         x = y;
     }
-    Ctx::ConvOpt oo;
+    Ctx::ConvOpt oo; oo.lowp = true;
     T img = c.conv(x, "out_conv", 3, oo);
     c.release(x);
     if (!c.rc && !c.dry()) {
@@ -538,7 +552,7 @@ int run_forward(femasr_handle *h, Arena *arena, hipStream_t stream, const float 
     }
     if (idx_tmp) c.release(idx_tmp);
     T q = cfg.use_quantize ? zq : z;
-    Ctx::ConvOpt oa;
+    Ctx::ConvOpt oa; oa.lowp = true;
     T x = c.conv(q, "after_quant_group.0.conv", channels_at(cfg.codebook_scale), oa);
     c.release(z);
     c.release(zq);
@@ -559,7 +573,7 @@ int run_decode_indices(femasr_handle *h, Arena *arena, hipStream_t stream, const
         const int r = femasr_codebook_gather(c.s(), indices, (int64_t)B * hq * wq, cfg.e_dim, c.Wt("quantize_group.0.embedding.weight"), cfg.n_e, zq.p);
         if (r) c.rc = r;
     }
-    Ctx::ConvOpt oa;
+    Ctx::ConvOpt oa; oa.lowp = true;
     T x = c.conv(zq, "after_quant_group.0.conv", channels_at(cfg.codebook_scale), oa);
     c.release(zq);
     T feats[3];
@@ -600,10 +614,11 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
     if (e != hipSuccess) { delete h; return femasr_set_error(FEMASR_ERR_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e)); }
     const int rc = build_specs(h);
     if (rc) { delete h; return rc; }
-    const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count();
+    const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count();
     h->acc_ms.assign(nslots, 0.0); h->acc_flops.assign(nslots, 0.0); h->acc_bytes.assign(nslots, 0.0); h->acc_n.assign(nslots, 0);
     for (int i = 0; i < SLOT_SMALL_COUNT; ++i) h->slot_names.push_back(kSmallNames[i]);
     for (int i = 0; i < femasr_conv_variant_count(); ++i) h->slot_names.push_back(femasr_conv_variant_name(i));
+    for (int i = 0; i < femasr_conv_bf16x3_variant_count(); ++i) h->slot_names.push_back(femasr_conv_bf16x3_variant_name(i));
     *out = h;
     return FEMASR_OK;
 }
@@ -611,7 +626,7 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
 void femasr_destroy(femasr_handle *h)
 {
     if (!h) return;
-    for (auto &w : h->specs) if (w.dev) (void)hipFree(w.dev);
+    for (auto &w : h->specs) { if (w.dev) (void)hipFree(w.dev); if (w.split) (void)hipFree(w.split); }
     if (h->cbT) (void)hipFree(h->cbT);
     if (h->ee) (void)hipFree(h->ee);
     for (auto e : h->pool) (void)hipEventDestroy(e);
@@ -660,6 +675,13 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
     else
         FEMASR_CHECK_HIP(hipMemcpyAsync(w.dev, dev_ptr, n * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
     if (rc) return rc;
+    const bool dec_side = k.rfind("decoder_group.", 0) == 0 || k.rfind("after_quant_group.", 0) == 0 || k.rfind("out_conv.", 0) == 0;
+    if (w.kind == W_CONV && dec_side && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {
+        const size_t nb = femasr_packed_weight_bf16x3_bytes((int)w.shape[0], (int)w.shape[1], 3, 3);
+        if (!w.split) FEMASR_CHECK_HIP(hipMalloc(&w.split, nb));
+        rc = femasr_repack_oihw_bf16x3(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], 3, 3, w.split);
+        if (rc) return rc;
+    }
     FEMASR_CHECK_HIP(hipStreamSynchronize(nullptr));
     w.set = true;
     h->finalized = false;
@@ -805,6 +827,13 @@ int femasr_decode_indices(femasr_handle *h, void *stream, const int64_t *indices
     Arena a;
     a.reset(ws, ws_bytes, false);
     return run_decode_indices(h, &a, (hipStream_t)stream, indices, B, hq, wq, out_nchw);
+}
+
+int femasr_set_decoder_math(femasr_handle *h, int mode)
+{
+    FEMASR_REQUIRE(h && (mode == 0 || mode == 1), "set_decoder_math: mode must be 0 (fp32) or 1 (bf16x3)");
+    h->decoder_math = mode;
+    return FEMASR_OK;
 }
 
 int femasr_profile_enable(femasr_handle *h, int on)

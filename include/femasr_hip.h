@@ -135,6 +135,10 @@ typedef struct {
     const float *res2;    /* optional second residual                   */
     float *out;           /* (B,Ho,Wo,Cout) */
     int32_t Ho, Wo;
+    const void *w_bf16x3; /* optional: femasr_repack_oihw_bf16x3 weights.  When non-NULL and the layer is a 3x3
+                             stride-1 pad-1 conv with Cin % 32 == 0 (no LN prologue / GELU) it runs on the bf16
+                             matrix cores with the 3-term hi/lo split (~1e-5 relative, NOT bit-exact); NULL =
+                             exact fp32 */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 
@@ -162,6 +166,14 @@ int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, c
  * `out` must hold femasr_packed_weight_floats(O,I,kh,kw) floats. */
 size_t femasr_packed_weight_floats(int O, int I, int kh, int kw);
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out);
+
+/* Split-bf16 (hi/lo) fragment-major weights for the opt-in bf16x3 conv path (3x3 convs behind the VQ lookup). */
+size_t femasr_packed_weight_bf16x3_bytes(int O, int I, int kh, int kw);
+int femasr_repack_oihw_bf16x3(void *stream, const float *in, int O, int I, int kh, int kw, void *out);
+/* 0 (default): every layer exact fp32, bit-identical to the oracle.  1: the convs AFTER the codebook lookup
+ * (after_quant, DecoderBlocks, out_conv) use the bf16x3 path: output within the north-star 1e-3 bound of the
+ * fp32 result (measured ~1e-4), VQ indices unaffected (everything feeding the argmin stays fp32). */
+int femasr_set_decoder_math(femasr_handle *h, int mode);
 
 /* ---- image pre / post-processing (the steps either side of the path) ---- */
 /* uint8 HWC (3 channels; swap_rb=1 for cv2-style BGR input) -> fp32 CHW RGB in [0,1]: (float)u8 / 255.0f.

@@ -29,10 +29,16 @@ def lib_weight_layout(w_khwc):
 
 
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
-           res1=None, res2=None):
+           res1=None, res2=None, bf16x3=False):
     """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout)."""
     lib = _lib.load()
     cout = np.asarray(w_khwc).shape[-1]
+    wsplit = None
+    if bf16x3:      # opt-in split-bf16 path: weights repacked on the GPU from OIHW
+        w_oihw = dev(np.ascontiguousarray(np.asarray(w_khwc).transpose(3, 2, 0, 1)))
+        o_, i_, kh_, kw_ = w_oihw.shape
+        wsplit = torch.empty(int(lib.femasr_packed_weight_bf16x3_bytes(o_, i_, kh_, kw_)), dtype=torch.uint8, device='cuda')
+        _lib.check(lib.femasr_repack_oihw_bf16x3(None, _lib.ptr(w_oihw), o_, i_, kh_, kw_, _lib.ptr(wsplit)))
     w_khwc = lib_weight_layout(np.asarray(w_khwc))
     b, h, w, cin = x.shape
     hv, wv = (2 * h, 2 * w) if up2 else (h, w)
@@ -53,6 +59,7 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     a.res1 = None if t1 is None else t1.data_ptr()
     a.res2 = None if t2 is None else t2.data_ptr()
     a.out = out.data_ptr(); a.Ho, a.Wo = ho, wo
+    a.w_bf16x3 = None if wsplit is None else wsplit.data_ptr()
     _lib.check(lib.femasr_conv2d(None, ctypes.byref(a)))
     torch.cuda.synchronize()
     return out.cpu().numpy()

@@ -169,6 +169,43 @@ def test_vq_bit_exact_and_first_min_tie(cuda_device):
     _same(zq2, zq_ref2, 'vq z_q (init codebook)')
 
 
+BF16_CASES = [
+    # name, (B,H,W,Cin), Cout, up2, gn
+    ('b16_256_256', (1, 16, 24, 256), 256, False, False),
+    ('b16_up2_256_128', (2, 9, 12, 256), 128, True, False),
+    ('b16_gn_64_64', (1, 20, 33, 64), 64, False, True),
+    ('b16_gn_128_128_edges', (2, 13, 10, 128), 128, False, True),
+    ('b16_cout3', (1, 24, 20, 64), 3, False, False),
+    ('b16_up2_128_64', (1, 7, 9, 128), 64, True, False),
+]
+
+
+@pytest.mark.parametrize('case', BF16_CASES, ids=[c[0] for c in BF16_CASES])
+def test_conv_bf16x3_within_tolerance(cuda_device, case):
+    """Opt-in split-bf16 3x3 conv (decoder side): NOT bit-exact by design; bound 1e-4 of the output scale
+    (the network-level bar is the north-star's 1e-3 max-abs)."""
+    import gpu_utils as G
+    name, shp, cout, up, gn = case
+    x = synth.uniform(3, name + 'x', shp, -2.0, 3.0)
+    w = synth.uniform(3, name + 'w', (3, 3, shp[3], cout), -0.1, 0.1)
+    b = synth.uniform(3, name + 'b', (cout,), -0.5, 0.5)
+    ho, wo = (2 * shp[1], 2 * shp[2]) if up else (shp[1], shp[2])
+    r1 = synth.uniform(3, name + 'r', (shp[0], ho, wo, cout), -1, 1)
+    if gn:
+        gamma = synth.uniform(3, name + 'g', (shp[3],), 0.5, 1.5)
+        beta = synth.uniform(3, name + 'be', (shp[3],), -0.5, 0.5)
+        a_, b_ = orc.gn_coeffs(x, gamma, beta)
+        ref = orc.conv2d(orc.scale_shift_silu(x, a_, b_), w, b, 3, 1, 1, up, res1=r1)
+        got = G.conv2d(x, w, b, 3, 1, 1, up, prologue=_lib.PRO_GN_SILU, pro=(a_, b_, None), res1=r1, bf16x3=True)
+    else:
+        ref = orc.conv2d(x, w, b, 3, 1, 1, up, res1=r1)
+        got = G.conv2d(x, w, b, 3, 1, 1, up, res1=r1, bf16x3=True)
+    assert got.shape == ref.shape and not np.isnan(got).any()
+    err = float(np.abs(got - ref).max())
+    scale = float(np.abs(ref).max())
+    assert err <= 1e-4 * scale, f'{name}: max-abs {err:.3e} vs scale {scale:.3e}'
+
+
 def test_repack_oihw_layout(cuda_device):
     """femasr_repack_oihw (what set_weight runs) == the documented K-major layout."""
     import gpu_utils as G

@@ -210,3 +210,29 @@ def test_other_configs_full_size_properties(cuda_device):
     o1 = neth(xh[1:2])[0]
     assert torch.equal(o1[0], out[1])
     assert (neth.decode_indices(il[0]) - out).abs().max() < 1e-5      # straight-through z+(e-z) vs e: rounding-level only
+
+
+def test_decoder_bf16x3_mode(cuda_device):
+    """Opt-in decoder_math='bf16x3': the convs behind the codebook lookup run on the bf16 matrix cores (3-term split).
+    VQ indices must be IDENTICAL to the exact mode (everything feeding the argmin stays fp32); outputs must stay
+    within the north-star bound 1e-3 max-abs of the reference golden and of the oracle."""
+    for name in ('x4_small_trained', 'x4_tile128_trained'):
+        g, cn, w, x, net = _case(name)
+        xt = torch.from_numpy(x).cuda()
+        y32, i32 = net.test_with_indices(xt)
+        net.decoder_math = 'bf16x3'
+        y16, i16 = net.test_with_indices(xt)
+        assert torch.equal(i16, i32)
+        assert not torch.equal(y16, y32)                 # the other kernels really ran
+        err_exact = float((y16 - y32).abs().max())
+        st = int(g['out_stride'])
+        err_ref = float(np.abs(y16.cpu().numpy()[:, :, ::st, ::st] - g['output']).max())
+        print(f'{name}: bf16x3 vs fp32 path {err_exact:.3e}, vs reference golden {err_ref:.3e}')
+        assert err_exact < TOL and err_ref < TOL
+        nbad, _ = check_indices_near_tie(i16.cpu().numpy(), g)
+        assert nbad == 0
+        net.decoder_math = 'fp32'
+        y32b, _ = net.test_with_indices(xt)
+        assert torch.equal(y32b, y32)
+        del net
+        torch.cuda.empty_cache()
