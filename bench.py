@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')   # from tools/rocpd_pmc_summary.py (rocprofv3 --pmc passes)
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: bf16 MFMA dense peak (the 5 PF headline includes 2:1 sparsity)
 TILE_GFLOP = 964.47                  # algorithmic GFLOP per x4 128^2 tile (SURVEY 8d / BASELINE.md 3)
 
 
@@ -33,6 +34,10 @@ def rocprof_kernel_name(bench_name):
     m = re.match(r'conv3x3_halo<8x16x(\d+),(\w+),up2=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
         return f'conv3x3_halo_kernel<{m.group(1)}, {m.group(4)}, {m.group(5)}, {pro[m.group(2)]}, {m.group(3)}>'
+    m = re.match(r'conv3x3_halo_bf16x3<8x16x(\d+),(\w+),up2=(\w+)>', bench_name)
+    if m:
+        wm, wn = (2, 2) if m.group(1) == '128' else (4, 1)
+        return f'conv3x3_halo_bf16x3_kernel<{m.group(1)}, {wm}, {wn}, {pro[m.group(2)]}, {m.group(3)}>'
     m = re.match(r'conv_igemm<(\d+)x(\d+),(\w+),cinvec=(\w+),vq=(\w+),k1=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
         return (f'conv_igemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(7)}, {m.group(8)}, {pro[m.group(3)]}, '
@@ -48,10 +53,11 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='128x128 LR tiles per GPU per step')
     ap.add_argument('--streams', type=int, default=2, help='sub-batch streams inside one forward (femasr_set_streams)')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra serialized steps (streams=1) for the roofline object')
-    ap.add_argument('--decoder-math', choices=['fp32', 'bf16x3'], default='fp32',
+    ap.add_argument('--decoder-math', choices=['fp32', 'bf16x3'], default='bf16x3',
                     help="'bf16x3': convs behind the VQ lookup on the bf16 matrix cores (3-term split, within 1e-3)")
     ap.add_argument('--no-gather', action='store_true', help='N>1: skip the all-gather of upscaled tiles')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-exact-leg', action='store_true', help='skip the extra all-fp32 (bit-exact mode) timing')
     ap.add_argument('--no-profile', action='store_true', help='do not record per-kernel HIP events')
     args = ap.parse_args()
 
@@ -124,7 +130,9 @@ def main():
     res = {
         'metric': 'SR output megapixels/sec at x4 (128->512)', 'value': round(value, 4), 'unit': 'MPix/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.decoder_math == 'fp32' else 'f32 for everything feeding the VQ argmin + bf16x3 (3-pass split-bf16 MFMA, fp32 accumulate) for the 3x3 convs that do not',
+        'data': 'synthetic',
         'config': {'workload': f'x4 SR FeMaSRNet.test, batch {B} of 128x128 LR tiles per GPU -> 512x512 (padded 144->576 '
                                'inside, reference geometry), synthetic random-init weights (seed 0), inputs resident in HBM',
                    'global_batch': B * world, 'tile': '128x128->512x512', 'parallelism': f'tile-parallel x{world}',
@@ -134,30 +142,56 @@ def main():
     }
     if rank == 0:
         if prof:
-            convs = {k: v for k, v in prof.items() if k.startswith('conv')}      # conv_igemm<..> and conv3x3_halo<..>: the MFMA kernels
+            convs = {k: v for k, v in prof.items() if k.startswith('conv')}      # the MFMA kernels
+            psteps = args.profile_steps
+            pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
+
+            def roof(name):
+                ms, n, fl, _ = convs[name]
+                split = name.startswith('conv3x3_halo_bf16x3')
+                peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+                ach = fl / (ms * 1e-3) / 1e12
+                rec = pmc.get(rocprof_kernel_name(name))
+                out = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                       'frac': round(ach / peak, 4),
+                       'traffic': round((rec['fetch_bytes_corrected'] + rec['write_bytes']) / 1e9, 4) if rec else None,
+                       'launches': n, 'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
+                       'peak_basis': ('bf16 dense MFMA peak; ALGORITHMIC flops: each multiply-add costs 3 MFMA passes '
+                                      '(hi*hi + hi*lo + lo*hi), so MFMA issue fraction = 3 x frac') if split else
+                                     'fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)'}
+                if split:
+                    out['mfma_issue_frac'] = round(3 * ach / peak, 4)
+                if rec:
+                    out['traffic_source'] = ('GB per launch, rocprofv3 --pmc FETCH_SIZE (doubled per MI355X_MICROARCH.md HBM '
+                                             'section) + WRITE_SIZE passes of this command (profiles/pmc_traffic.json)')
+                return out
             dom = max(convs, key=lambda k: convs[k][0])
-            ms, n, fl, _ = convs[dom]
+            res['roofline'] = roof(dom)
+            fp32k = [k for k in convs if not k.startswith('conv3x3_halo_bf16x3')]
+            if fp32k and dom not in fp32k:
+                res['roofline']['largest_fp32_kernel'] = roof(max(fp32k, key=lambda k: convs[k][0]))
             tot_ms = sum(v[0] for v in convs.values())
             tot_fl = sum(v[2] for v in convs.values())
-            ach = fl / (ms * 1e-3) / 1e12
-            psteps = args.profile_steps
-            traffic, traffic_src = None, None
-            if os.path.exists(PMC_TRAFFIC_JSON):
-                rec = json.load(open(PMC_TRAFFIC_JSON)).get(rocprof_kernel_name(dom))
-                if rec:
-                    traffic = round((rec['fetch_bytes_corrected'] + rec['write_bytes']) / 1e9, 4)
-                    traffic_src = ('GB per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
-                                   '(profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section)')
-            res['roofline'] = {
-                'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-                'launches': n, 'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
-                'all_mfma_conv_kernels': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                   'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                   'share_of_serialized_step_time': round(tot_ms / psteps / prof_ms_per_step, 4)},
-                'measured_in': f'{psteps} serialized steps (streams=1, {prof_ms_per_step:.1f} ms/step) right after the timed region',
-                'per_kernel_ms_per_step': {k: round(v[0] / psteps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-            }
+            res['roofline']['all_mfma_conv_kernels'] = {
+                'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                'share_of_serialized_step_time': round(tot_ms / psteps / prof_ms_per_step, 4)}
+            res['roofline']['measured_in'] = (f'{psteps} serialized steps (streams=1, {prof_ms_per_step:.1f} ms/step) right after '
+                                              'the timed region')
+            res['roofline']['per_kernel_ms_per_step'] = {k: round(v[0] / psteps, 3)
+                                                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        if world == 1 and args.decoder_math != 'fp32' and not args.no_exact_leg:
+            # the same workload with EVERY layer in exact fp32 (the mode the parity tests check bit-for-bit)
+            net.decoder_math = 'fp32'
+            net.test(x)
+            torch.cuda.synchronize(dev)
+            te0 = time.perf_counter()
+            for _ in range(args.steps):
+                ye = net.test(x)
+            torch.cuda.synchronize(dev)
+            te = (time.perf_counter() - te0) / args.steps
+            res['exact_fp32_mode'] = {'value': round(B * 512 * 512 / 1e6 / te, 4), 'unit': 'MPix/s', 'ms_per_step': round(te * 1e3, 3),
+                                      'max_abs_vs_timed_mode': float((ye - y).abs().max())}
+            net.decoder_math = args.decoder_math
         if world == 1 and not args.no_cpu_baseline:
             from helpers import oracle_net
             onet = oracle_net('x4', weights)

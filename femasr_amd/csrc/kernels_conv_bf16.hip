@@ -34,6 +34,13 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, uns
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
 }
 
+// SiLU with the hardware exp2 / rcp approximations (1 ulp each): this path is tolerance-based (1e-3 contract, ~1e-5
+// measured), so the 28-instruction bit-reproducible det_silu of the fp32 kernels is not needed here.
+__device__ __forceinline__ float fast_silu(float t)
+{
+    return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.44269504088896341f));
+}
+
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 &v) { return __builtin_bit_cast(bf16x8, v); }
 
 template <int BN, int WM, int WN, int PRO, bool UP2>
@@ -91,10 +98,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16x3_kernel(const ConvP
         if (PP % PROWS != 0 && i == PUNITS - 1 && pix >= PP) return;
         float4 v = rp[i];
         if (PRO == FEMASR_PRO_GN_SILU) {
-            v.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
-            v.y = det_silu(__builtin_fmaf(v.y, ga.y, gb.y));
-            v.z = det_silu(__builtin_fmaf(v.z, ga.z, gb.z));
-            v.w = det_silu(__builtin_fmaf(v.w, ga.w, gb.w));
+            v.x = fast_silu(__builtin_fmaf(v.x, ga.x, gb.x));
+            v.y = fast_silu(__builtin_fmaf(v.y, ga.y, gb.y));
+            v.z = fast_silu(__builtin_fmaf(v.z, ga.z, gb.z));
+            v.w = fast_silu(__builtin_fmaf(v.w, ga.w, gb.w));
         }
         if (!(pmask & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned h01, l01, h23, l23;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16x3_kernel(const ConvP
 
     const int ncc = p.Cin / BK;
     load_patch(0);
-    uint4 bc[TN][4], bn[TN][4];
+    uint4 bc[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -147,45 +154,60 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16x3_kernel(const ConvP
             const int q = cc * 9 + tap;
             const bool more_w = (q + 1) < ncc * 9;
             const int ky = tap / 3, kx = tap - ky * 3;
-            if (more_w) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bn[j][e] = (wl[j] + (size_t)(q + 1) * wstride)[e];
-            }
             if (more_p && tap == 0) load_patch(cc + 1);
+            int aidx[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int prow = UP2 ? ((py[i] + ky - 1) >> 1) + 1 : py[i] + ky;
+                const int pcol = UP2 ? ((px + kx - 1) >> 1) + 1 : px + kx;
+                aidx[i] = (prow * PW + pcol) * PPITCH;
+            }
+            // A fragments are fetched one k-step ahead (s=1 while s=0 multiplies; the next tap's s=0 is fetched by the
+            // next iteration's prologue read below), pinned with sched_barrier so the LDS latency hides behind MFMAs
+            uint4 a_hi[2][TM], a_lo[2][TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a_hi[0][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i]);
+                a_lo[0][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + HALF);
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 ah[TM], al[TM];
+                if (s == 0) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int prow = UP2 ? ((py[i] + ky - 1) >> 1) + 1 : py[i] + ky;
-                    const int pcol = UP2 ? ((px + kx - 1) >> 1) + 1 : px + kx;
-                    const unsigned short *src = Pb + (prow * PW + pcol) * PPITCH + 16 * s;
-                    ah[i] = as_bf16x8(*reinterpret_cast<const uint4 *>(src));
-                    al[i] = as_bf16x8(*reinterpret_cast<const uint4 *>(src + HALF));
+                    for (int i = 0; i < TM; ++i) {
+                        a_hi[1][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + 16);
+                        a_lo[1][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + 16 + HALF);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                // term-major order: consecutive MFMAs hit DIFFERENT accumulator tiles, so the dependent-accumulator
+                // latency of the 32x32x16 bf16 MFMA (longer than its issue interval) is hidden
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const bf16x8 a = as_bf16x8(term == 2 ? a_lo[s][i] : a_hi[s][i]);
+                            const bf16x8 b = as_bf16x8(term == 1 ? bc[j][2 * s + 1] : bc[j][2 * s]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+                        }
+                // this k-step's weight registers are free now: refill them with the NEXT tap's fragments (half a tap of
+                // MFMAs ahead of their use), no register copies
+                if (more_w) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const bf16x8 bh = as_bf16x8(bc[j][2 * s]), bl = as_bf16x8(bc[j][2 * s + 1]);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                        bc[j][2 * s] = (wl[j] + (size_t)(q + 1) * wstride)[2 * s];
+                        bc[j][2 * s + 1] = (wl[j] + (size_t)(q + 1) * wstride)[2 * s + 1];
                     }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // next channel block's patch: one unit per tap (taps 1..PUNITS), in the shadow of the other waves' MFMAs
             if (more_p && tap >= 1 && tap <= PUNITS) {
 #pragma unroll
                 for (int i = 0; i < PUNITS; ++i)
                     if (tap == i + 1) store_patch_unit((cc + 1) & 1, i);
-            }
-            if (more_w) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bc[j][e] = bn[j][e];
             }
         }
         __syncthreads();

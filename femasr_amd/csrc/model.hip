@@ -13,6 +13,7 @@
 // all on the caller's stream, no host synchronisation.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -525,7 +526,7 @@ int run_forward(femasr_handle *h, Arena *arena, hipStream_t stream, const float 
         t = c.swin_layers(t, enc + ".blocks." + std::to_string(bi++));
         feats[0] = t;
         for (int u = 0; u < 2; ++u, ++bi) {
-            feats[u + 1] = c.up_block(feats[u], enc + ".blocks." + std::to_string(bi), channels_at(res * 2), nullptr);
+            feats[u + 1] = c.up_block(feats[u], enc + ".blocks." + std::to_string(bi), channels_at(res * 2), nullptr, true);
             res *= 2;
         }
     } else {
@@ -675,7 +676,12 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
     else
         FEMASR_CHECK_HIP(hipMemcpyAsync(w.dev, dev_ptr, n * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
     if (rc) return rc;
-    const bool dec_side = k.rfind("decoder_group.", 0) == 0 || k.rfind("after_quant_group.", 0) == 0 || k.rfind("out_conv.", 0) == 0;
+    bool dec_side = k.rfind("decoder_group.", 0) == 0 || k.rfind("after_quant_group.", 0) == 0 || k.rfind("out_conv.", 0) == 0;
+    {   // the encoder's two up-blocks only produce the decoder's skip features (femasr_arch.py:314,361-362): they do not
+        // feed the codebook lookup either
+        const std::string pre = "multiscale_encoder.blocks.";
+        if (h->cfg.lq_stage && k.rfind(pre, 0) == 0 && atoi(k.c_str() + pre.size()) > h->encode_depth) dec_side = true;
+    }
     if (w.kind == W_CONV && dec_side && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {
         const size_t nb = femasr_packed_weight_bf16x3_bytes((int)w.shape[0], (int)w.shape[1], 3, 3);
         if (!w.split) FEMASR_CHECK_HIP(hipMalloc(&w.split, nb));

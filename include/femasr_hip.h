@@ -170,8 +170,9 @@ int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int 
 /* Split-bf16 (hi/lo) fragment-major weights for the opt-in bf16x3 conv path (3x3 convs behind the VQ lookup). */
 size_t femasr_packed_weight_bf16x3_bytes(int O, int I, int kh, int kw);
 int femasr_repack_oihw_bf16x3(void *stream, const float *in, int O, int I, int kh, int kw, void *out);
-/* 0 (default): every layer exact fp32, bit-identical to the oracle.  1: the convs AFTER the codebook lookup
- * (after_quant, DecoderBlocks, out_conv) use the bf16x3 path: output within the north-star 1e-3 bound of the
+/* 0 (default): every layer exact fp32, bit-identical to the oracle.  1: the 3x3 convs that do NOT feed the codebook
+ * lookup (after_quant, DecoderBlocks, out_conv, and the encoder's two up-blocks, whose outputs are only the decoder's
+ * skip features) use the bf16x3 path: output within the north-star 1e-3 bound of the
  * fp32 result (measured ~1e-4), VQ indices unaffected (everything feeding the argmin stays fp32). */
 int femasr_set_decoder_math(femasr_handle *h, int mode);
 
