@@ -34,10 +34,9 @@ def rocprof_kernel_name(bench_name):
     m = re.match(r'conv3x3_halo<8x16x(\d+),(\w+),up2=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
         return f'conv3x3_halo_kernel<{m.group(1)}, {m.group(4)}, {m.group(5)}, {pro[m.group(2)]}, {m.group(3)}>'
-    m = re.match(r'conv3x3_halo_bf16x3<8x16x(\d+),(\w+),up2=(\w+)>', bench_name)
+    m = re.match(r'conv3x3_halo_bf16x3<8x16x(\d+),(\w+),up2=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
-        wm, wn = (2, 2) if m.group(1) == '128' else (4, 1)
-        return f'conv3x3_halo_bf16x3_kernel<{m.group(1)}, {wm}, {wn}, {pro[m.group(2)]}, {m.group(3)}>'
+        return f'conv3x3_halo_bf16x3_kernel<{m.group(1)}, {m.group(4)}, {m.group(5)}, {pro[m.group(2)]}, {m.group(3)}>'
     m = re.match(r'conv_igemm<(\d+)x(\d+),(\w+),cinvec=(\w+),vq=(\w+),k1=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
         return (f'conv_igemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(7)}, {m.group(8)}, {pro[m.group(3)]}, '

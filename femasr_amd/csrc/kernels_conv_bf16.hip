@@ -44,13 +44,13 @@ __device__ __forceinline__ float fast_silu(float t)
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 &v) { return __builtin_bit_cast(bf16x8, v); }
 
 template <int BN, int WM, int WN, int PRO, bool UP2>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16x3_kernel(const ConvParams p, const uint4 *__restrict__ wsplit)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_halo_bf16x3_kernel(const ConvParams p, const uint4 *__restrict__ wsplit)
 {
-    constexpr int BM = 128, TW = 16, NT = 256;
+    constexpr int BM = 128, TW = 16, NT = WM * WN * 64;
     constexpr int PH = UP2 ? 6 : 10, PW = UP2 ? 10 : 18, PP = PH * PW;
     constexpr int PUNITS = (PP * 8 + NT - 1) / NT, PROWS = NT / 8;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile config");
+    static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "tile config");
     static_assert(PRO != FEMASR_PRO_LN, "no LayerNorm prologue on 3x3 convs");
     static_assert(1 + PUNITS <= 9, "patch slices are spread over taps 1..");
 
@@ -273,22 +273,22 @@ constexpr size_t bf16_lds_bytes() { return (size_t)2 * 2 * (UP2 ? 60 : 180) * PP
 
 struct Variant16 {
     const char *name;
-    int bn;
+    int bn, threads;
     void (*kern)(const ConvParams, const uint4 *);
     size_t lds;
     bool attr_set;
 };
 #define FEMASR_H16(BN, WM, WN, PRO, UP2)                                                        \
-    { "conv3x3_halo_bf16x3<8x16x" #BN "," #PRO ",up2=" #UP2 ">", BN,                            \
+    { "conv3x3_halo_bf16x3<8x16x" #BN "," #PRO ",up2=" #UP2 ",waves=" #WM "x" #WN ">", BN, WM * WN * 64,   \
       conv3x3_halo_bf16x3_kernel<BN, WM, WN, PRO, UP2>, bf16_lds_bytes<UP2>(), false }
 
 Variant16 g_v16[] = {
-    FEMASR_H16(128, 2, 2, FEMASR_PRO_NONE, false),     // 0
+    FEMASR_H16(128, 2, 2, FEMASR_PRO_NONE, false),     // 0   (4 waves: 64 px x 64 ch per wave)
     FEMASR_H16(128, 2, 2, FEMASR_PRO_GN_SILU, false),  // 1
     FEMASR_H16(128, 2, 2, FEMASR_PRO_NONE, true),      // 2
-    FEMASR_H16(64, 4, 1, FEMASR_PRO_NONE, false),      // 3
-    FEMASR_H16(64, 4, 1, FEMASR_PRO_GN_SILU, false),   // 4
-    FEMASR_H16(64, 4, 1, FEMASR_PRO_NONE, true),       // 5
+    FEMASR_H16(64, 4, 2, FEMASR_PRO_NONE, false),      // 3   (8 waves: 32 px x 32 ch per wave)
+    FEMASR_H16(64, 4, 2, FEMASR_PRO_GN_SILU, false),   // 4
+    FEMASR_H16(64, 4, 1, FEMASR_PRO_NONE, true),       // 5   (4 waves)
     FEMASR_H16(32, 4, 1, FEMASR_PRO_NONE, false),      // 6
     FEMASR_H16(32, 4, 1, FEMASR_PRO_GN_SILU, false),   // 7
     FEMASR_H16(32, 4, 1, FEMASR_PRO_NONE, true),       // 8
@@ -328,7 +328,7 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
         v.attr_set = true;
     }
-    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(256), v.lds, s, p, (const uint4 *)a->w_bf16x3);
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), v.lds, s, p, (const uint4 *)a->w_bf16x3);
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
     if (flops_out) *flops_out = 2.0 * (double)a->B * p.Ho * p.Wo * (double)a->Cout * 9.0 * a->Cin;
