@@ -112,13 +112,28 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         *reinterpret_cast<uint2 *>(dst + HALF) = make_uint2(l01, l23);
     };
 
+    // accumulators start from bias + residuals (this path is tolerance-based, so the order of the final additions is
+    // free): the residual loads overlap the first patch load instead of serialising in the epilogue
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const float bv = col < p.Cout ? p.bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+                float v = bv;
+                if (oy < p.Ho && ox < p.Wo && col < p.Cout) {
+                    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
+                    if (p.res1) v = v + p.res1[o];
+                    if (p.res2) v = v + p.res2[o];
+                }
+                acc[i][j][r] = v;
+            }
+        }
 
     // split weights, fragment-major: [q][ntile][lane][kstep(2)][hi8|lo8] bf16 = 4 x uint4 per (q, ntile, lane)
     const uint4 *wl[TN];
@@ -203,11 +218,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // next channel block's patch: one unit per tap (taps 1..PUNITS), in the shadow of the other waves' MFMAs
-            if (more_p && tap >= 1 && tap <= PUNITS) {
+            // next channel block's patch: loaded at tap 0, one unit normalised / split / stored per tap over the LAST
+            // PUNITS taps (bf16 taps are ~5x shorter than fp32 ones: the HBM latency needs the distance)
+            if (more_p && tap >= 9 - PUNITS) {
 #pragma unroll
                 for (int i = 0; i < PUNITS; ++i)
-                    if (tap == i + 1) store_patch_unit((cc + 1) & 1, i);
+                    if (tap == i + 9 - PUNITS) store_patch_unit((cc + 1) & 1, i);
             }
         }
         __syncthreads();
@@ -218,18 +234,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-            const float bv = col < p.Cout ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (oy < p.Ho && ox < p.Wo && col < p.Cout) {
-                    float v = acc[i][j][r] + bv;
-                    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
-                    if (p.res1) v = v + p.res1[o];
-                    if (p.res2) v = v + p.res2[o];
-                    p.out[o] = v;
-                }
+                if (oy < p.Ho && ox < p.Wo && col < p.Cout)
+                    p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + col] = acc[i][j][r];
             }
         }
 }
