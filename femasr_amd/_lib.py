@@ -34,7 +34,7 @@ class ConvArgs(ctypes.Structure):
         ('act', ctypes.c_int32),
         ('res1', vp), ('res2', vp), ('out', vp),
         ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32),
-        ('w_bf16x3', vp),
+        ('w_bf16x3', vp), ('gn_part', vp),
     ]
 
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     'femasr_crop_nhwc_to_nchw': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'femasr_conv2d': (c_int, [vp, ctypes.POINTER(ConvArgs)]),
     'femasr_gn_coeffs': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, c_f32, vp, vp, vp]),
+    'femasr_gn_coeffs_from_partials': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, c_f32, vp, vp]),
     'femasr_ln_stats': (c_int, [vp, vp, c_i64, c_int, c_f32, vp]),
     'femasr_window_attention': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp]),
     'femasr_vq': (c_int, [vp, vp, c_i64, c_int, vp, vp, vp, c_int, vp, vp, vp]),

@@ -44,7 +44,8 @@ __device__ __forceinline__ float fast_silu(float t)
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 &v) { return __builtin_bit_cast(bf16x8, v); }
 
 template <int BN, int WM, int WN, int PRO, bool UP2>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_halo_bf16x3_kernel(const ConvParams p, const uint4 *__restrict__ wsplit)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_halo_bf16x3_kernel(const ConvParams p, const uint4 *__restrict__ wsplit,
+                                                                                          double *__restrict__ stats_part)
 {
     constexpr int BM = 128, TW = 16, NT = WM * WN * 64;
     constexpr int PH = UP2 ? 6 : 10, PW = UP2 ? 10 : 18, PP = PH * PW;
@@ -229,19 +230,65 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         __syncthreads();
     }
 
+    float colsum[TM][TN], colsq[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+            float ps = 0.f, pss = 0.f;      // this lane's share of the GroupNorm moments of the OUTPUT (column `col`)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (oy < p.Ho && ox < p.Wo && col < p.Cout)
-                    p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + col] = acc[i][j][r];
+                if (oy < p.Ho && ox < p.Wo && col < p.Cout) {
+                    const float v = acc[i][j][r];
+                    p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + col] = v;
+                    ps += v;
+                    pss = __builtin_fmaf(v, v, pss);
+                }
+            }
+            if (stats_part) { colsum[i][j] = ps; colsq[i][j] = pss; }
+        }
+
+    // Optional fused GroupNorm moments of the output (consumed by the NEXT conv's GN prologue): per (tile, group)
+    // partial sums, reduced lane -> group (xor shuffles over the cg lanes of a group, then the two row halves) -> waves
+    // (LDS) and written as doubles to stats_part[((n*tiles + tile)*32 + g)*2]; a fixed order, so runs are reproducible.
+    if (stats_part) {
+        const int cg = p.Cout >> 5;                       // channels per group (32 groups): 8 / 4 / 2
+        double *red = reinterpret_cast<double *>(smem_u16);   // [WM][BN/2][2] (patch buffers are dead after the last barrier)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            double s_ = 0.0, q_ = 0.0;      // cross-lane / cross-wave part in fp64 (per-lane partials are <= 32 fp32 terms)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { s_ += (double)colsum[i][j]; q_ += (double)colsq[i][j]; }
+            for (int sft = 1; sft < cg; sft <<= 1) {
+                s_ += __shfl_xor(s_, sft, 64);
+                q_ += __shfl_xor(q_, sft, 64);
+            }
+            s_ += __shfl_xor(s_, 32, 64);
+            q_ += __shfl_xor(q_, 32, 64);
+            if (lane < 32 && (lane % cg) == 0) {
+                const int gl = ((wn * TN + j) * 32 + lane) / cg;        // group index inside this block's BN columns
+                red[(wm * (BN / 2) + gl) * 2] = s_;
+                red[(wm * (BN / 2) + gl) * 2 + 1] = q_;
             }
         }
+        __syncthreads();
+        const int ngl = BN / cg;                                         // groups covered by this block
+        if (t < ngl && n0 + t * cg < p.Cout) {
+            double S = 0.0, Q = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < WM; ++w2) {
+                S += red[(w2 * (BN / 2) + t) * 2];
+                Q += red[(w2 * (BN / 2) + t) * 2 + 1];
+            }
+            const int g = n0 / cg + t;
+            const size_t tile_id = (size_t)n * p.tilesX * p.tilesY + (size_t)ty * p.tilesX + tx;
+            stats_part[(tile_id * 32 + g) * 2] = S;
+            stats_part[(tile_id * 32 + g) * 2 + 1] = Q;
+        }
+    }
 }
 
 // OIHW fp32 -> split bf16 fragment-major: out ushort index = (((((q*NT32 + ntile)*64 + lane)*2 + s)*2 + h)*8 + e)
@@ -284,7 +331,7 @@ constexpr size_t bf16_lds_bytes() { return (size_t)2 * 2 * (UP2 ? 60 : 180) * PP
 struct Variant16 {
     const char *name;
     int bn, threads;
-    void (*kern)(const ConvParams, const uint4 *);
+    void (*kern)(const ConvParams, const uint4 *, double *);
     size_t lds;
     bool attr_set;
 };
@@ -338,7 +385,10 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
         v.attr_set = true;
     }
-    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), v.lds, s, p, (const uint4 *)a->w_bf16x3);
+    FEMASR_REQUIRE(!a->gn_part || (a->Cout % 32 == 0 && (a->Cout / 32) <= 8 && v.bn % (a->Cout / 32) == 0),
+                   "conv bf16x3: fused GN moments need Cout %% 32 == 0 and <= 8 channels per group");
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), v.lds, s, p, (const uint4 *)a->w_bf16x3,
+                       (double *)a->gn_part);
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
     if (flops_out) *flops_out = 2.0 * (double)a->B * p.Ho * p.Wo * (double)a->Cout * 9.0 * a->Cin;

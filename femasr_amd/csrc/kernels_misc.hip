@@ -107,16 +107,16 @@ __global__ void gn_rows_generic_kernel(const float *__restrict__ x, int B, int H
 // 64-row slabs and thread g adds its group's rows in ascending y (the specified order), then folds the moments
 // into a[n,c], b[n,c].
 constexpr int GN_SLAB = 64;
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ part, int B, int H, int W, int C, int G,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ part, int B, int rows_total, int H, int W, int C, int G,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           float eps, float *__restrict__ a, float *__restrict__ b)
 {
     extern __shared__ __attribute__((aligned(16))) double slab[];      // [GN_SLAB][G][2]
     const int n = blockIdx.x, t = threadIdx.x, cg = C / G;
-    const double *src = part + (size_t)n * H * G * 2;
+    const double *src = part + (size_t)n * rows_total * G * 2;
     double S = 0.0, SS = 0.0;
-    for (int y0 = 0; y0 < H; y0 += GN_SLAB) {
-        const int rows = (H - y0) < GN_SLAB ? (H - y0) : GN_SLAB;
+    for (int y0 = 0; y0 < rows_total; y0 += GN_SLAB) {
+        const int rows = (rows_total - y0) < GN_SLAB ? (rows_total - y0) : GN_SLAB;
         const int cnt = rows * G * 2;
         for (int i = t; i < cnt; i += blockDim.x) slab[i] = src[(size_t)y0 * G * 2 + i];
         __syncthreads();
@@ -474,8 +474,19 @@ int femasr_gn_coeffs(void *stream, const float *x, int B, int H, int W, int C, i
         hipLaunchKernelGGL(gn_rows_generic_kernel, grid, blk, 0, s, x, B, H, W, C, G, cg, part);
     FEMASR_CHECK_HIP(hipGetLastError());
     FEMASR_REQUIRE(G <= 256, "gn_coeffs: at most 256 groups");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), (size_t)GN_SLAB * G * 2 * sizeof(double), s, part, B, H,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), (size_t)GN_SLAB * G * 2 * sizeof(double), s, part, B, H, H,
                        W, C, G, gamma, beta, eps, a, b);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_gn_coeffs_from_partials(void *stream, const double *part, int B, int tiles, int H, int W, int C, int G,
+                                   const float *gamma, const float *beta, float eps, float *a, float *b)
+{
+    FEMASR_REQUIRE(part && gamma && beta && a && b && B > 0 && tiles > 0 && H > 0 && W > 0, "gn_coeffs_from_partials: bad args");
+    FEMASR_REQUIRE(G == 32 && C % G == 0, "gn_coeffs_from_partials: 32 groups");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), (size_t)GN_SLAB * G * 2 * sizeof(double),
+                       (hipStream_t)stream, part, B, tiles, H, W, C, G, gamma, beta, eps, a, b);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

@@ -73,6 +73,8 @@ struct WSpec {
 struct T {          // NHWC activation view
     float *p = nullptr;
     int B = 0, H = 0, W = 0, C = 0;
+    double *gn_part = nullptr;   // fused GroupNorm partial moments written by the producing bf16x3 conv (or null)
+    int gn_tiles = 0;
     size_t numel() const { return (size_t)B * H * W * C; }
 };
 
@@ -321,12 +323,21 @@ struct Ctx {
         const float *pa = nullptr, *pb = nullptr, *pc = nullptr;
         const float *res1 = nullptr, *res2 = nullptr;
         bool lowp = false;       // behind the VQ lookup: may use the bf16x3 path when the handle opts in
+        bool want_gn = false;    // the output feeds a GroupNorm: let a bf16x3 conv emit its partial moments
     };
     T conv(const T &x, const std::string &prefix, int cout, const ConvOpt &o)
     {
         const int Hv = o.up2 ? 2 * x.H : x.H, Wv = o.up2 ? 2 * x.W : x.W;
         const int Ho = (Hv + 2 * o.pad - o.ksz) / o.stride + 1, Wo = (Wv + 2 * o.pad - o.ksz) / o.stride + 1;
         T y = alloc_t(x.B, Ho, Wo, cout);
+        // bf16x3 eligibility by shape (same rule as femasr_conv_bf16x3_eligible) so that the dry run plans the same buffers
+        const bool lowp_on = o.lowp && h->decoder_math && o.ksz == 3 && o.stride == 1 && o.pad == 1 && (x.C % 32) == 0 &&
+                             o.pro != FEMASR_PRO_LN && o.act == FEMASR_ACT_NONE && !(o.up2 && o.pro != FEMASR_PRO_NONE);
+        if (o.want_gn && lowp_on && cout % 32 == 0 && cout / 32 <= 8) {
+            y.gn_tiles = ((Ho + 7) / 8) * ((Wo + 15) / 16);
+            y.gn_part = (double *)arena->alloc((size_t)x.B * y.gn_tiles * 32 * 2 * sizeof(double));
+            if (!y.gn_part && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
+        }
         if (rc || dry()) return y;
         femasr_conv_args a{};
         a.in = x.p; a.B = x.B; a.H = x.H; a.W = x.W; a.Cin = x.C;
@@ -334,11 +345,17 @@ struct Ctx {
         a.ksz = o.ksz; a.stride = o.stride; a.pad = o.pad; a.up2 = o.up2;
         a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
         a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
-        if (o.lowp && h->decoder_math) {
+        if (lowp_on) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) a.w_bf16x3 = h->specs[it->second].split;
         }
         if (rc) return y;
+        if (a.w_bf16x3 && femasr_conv_bf16x3_eligible(&a)) {
+            a.gn_part = y.gn_part;
+        } else if (y.gn_part) {      // fell back to the fp32 kernel: nobody writes the partials
+            release(y.gn_part);
+            y.gn_part = nullptr;
+        }
         Scope sc(h, s(), dry(), 0, 0.0, 0.0);
         int variant = 0; double flops = 0;
         int r;
@@ -356,9 +373,20 @@ struct Ctx {
     }
 
     // GroupNorm moments -> (a,b); returns a pointer pair inside one allocation
-    float *gn(const T &x, const std::string &norm_prefix)
+    float *gn(T &x, const std::string &norm_prefix)
     {
         float *ab = alloc_f((size_t)2 * x.B * x.C);
+        if (x.gn_part) {         // moments were accumulated by the producing bf16x3 conv: finalize only
+            if (!rc && !dry()) {
+                Scope sc(h, s(), dry(), SLOT_GN, 0.0, (double)x.B * x.gn_tiles * 32 * 16.0);
+                const int r = femasr_gn_coeffs_from_partials(s(), x.gn_part, x.B, x.gn_tiles, x.H, x.W, x.C, 32, Wt(norm_prefix + ".weight"),
+                                                             Wt(norm_prefix + ".bias"), 1e-6f, ab, ab + (size_t)x.B * x.C);
+                if (r && !rc) rc = r;
+            }
+            release(x.gn_part);
+            x.gn_part = nullptr;
+            return ab;
+        }
         double *scratch = (double *)arena->alloc((size_t)x.B * x.H * 32 * 2 * sizeof(double));
         if (!scratch && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
         if (!rc && !dry()) {
@@ -372,16 +400,16 @@ struct Ctx {
     }
 
     // fema_utils.py:65-84 (+ optional fused `x + enc_feats[i]`, femasr_arch.py:361-362)
-    T resblock(T x, const std::string &p, const float *res2, bool free_x, bool lowp = false)
+    T resblock(T x, const std::string &p, const float *res2, bool free_x, bool lowp = false, bool out_gn = false)
     {
         const size_t bc = (size_t)x.B * x.C;
         float *ab = gn(x, p + ".conv.0.norm");
-        ConvOpt o1; o1.pro = FEMASR_PRO_GN_SILU; o1.pa = ab; o1.pb = ab ? ab + bc : nullptr; o1.lowp = lowp;
+        ConvOpt o1; o1.pro = FEMASR_PRO_GN_SILU; o1.pa = ab; o1.pb = ab ? ab + bc : nullptr; o1.lowp = lowp; o1.want_gn = lowp;
         T u = conv(x, p + ".conv.2", x.C, o1);
         release(ab);
         float *ab2 = gn(u, p + ".conv.3.norm");
         ConvOpt o2; o2.pro = FEMASR_PRO_GN_SILU; o2.pa = ab2; o2.pb = ab2 ? ab2 + bc : nullptr;
-        o2.res1 = x.p; o2.res2 = res2; o2.lowp = lowp;
+        o2.res1 = x.p; o2.res2 = res2; o2.lowp = lowp; o2.want_gn = out_gn;
         T y = conv(u, p + ".conv.5", x.C, o2);
         release(ab2);
         release(u);
@@ -449,10 +477,10 @@ struct Ctx {
 
     T up_block(const T &x, const std::string &p, int cout, const float *res2_last, bool lowp = false)   // Upsample x2 -> conv -> RB -> RB
     {
-        ConvOpt o; o.up2 = 1; o.lowp = lowp;
+        ConvOpt o; o.up2 = 1; o.lowp = lowp; o.want_gn = lowp;
         T c = conv(x, p + ".1", cout, o);
-        T r1 = resblock(c, p + ".2", nullptr, true, lowp);
-        return resblock(r1, p + ".3", res2_last, true, lowp);
+        T r1 = resblock(c, p + ".2", nullptr, true, lowp, lowp);
+        return resblock(r1, p + ".3", res2_last, true, lowp, false);
     }
 };
 

@@ -139,6 +139,9 @@ typedef struct {
                              stride-1 pad-1 conv with Cin % 32 == 0 (no LN prologue / GELU) it runs on the bf16
                              matrix cores with the 3-term hi/lo split (~1e-5 relative, NOT bit-exact); NULL =
                              exact fp32 */
+    double *gn_part;      /* optional, bf16x3 path only: per-(sample, 8x16 tile, group) partial GroupNorm moments
+                             (sum, sum of squares) of the OUTPUT, [B][tilesY*tilesX][32][2] doubles, for
+                             femasr_gn_coeffs_from_partials (saves the separate moments pass over the tensor) */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 
@@ -146,6 +149,10 @@ int femasr_conv2d(void *stream, const femasr_conv_args *a);
  * scratch: >= B*H*G*2 doubles. */
 int femasr_gn_coeffs(void *stream, const float *x, int B, int H, int W, int C, int G,
                      const float *gamma, const float *beta, float eps, float *a, float *b, void *scratch);
+/* Same as femasr_gn_coeffs, from the partial moments a bf16x3 conv wrote with femasr_conv_args.gn_part
+ * (tiles = ceil(H/8)*ceil(W/16) of the producing conv's output). */
+int femasr_gn_coeffs_from_partials(void *stream, const double *part, int B, int tiles, int H, int W, int C, int G,
+                                   const float *gamma, const float *beta, float eps, float *a, float *b);
 /* LayerNorm(C=256) row moments -> stats[rows][2] = (mean, rstd) (network_swinir.py:199,205). */
 int femasr_ln_stats(void *stream, const float *x, int64_t rows, int C, float eps, float *stats);
 /* 8x8 (shifted-)window multi-head attention incl. rel-pos bias and shift mask

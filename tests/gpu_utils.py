@@ -29,7 +29,7 @@ def lib_weight_layout(w_khwc):
 
 
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
-           res1=None, res2=None, bf16x3=False):
+           res1=None, res2=None, bf16x3=False, gn_part=False):
     """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout)."""
     lib = _lib.load()
     cout = np.asarray(w_khwc).shape[-1]
@@ -60,8 +60,15 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     a.res2 = None if t2 is None else t2.data_ptr()
     a.out = out.data_ptr(); a.Ho, a.Wo = ho, wo
     a.w_bf16x3 = None if wsplit is None else wsplit.data_ptr()
+    part = None
+    if gn_part:
+        tiles = ((ho + 7) // 8) * ((wo + 15) // 16)
+        part = torch.full((b, tiles, 32, 2), float('nan'), dtype=torch.float64, device='cuda')
+        a.gn_part = part.data_ptr()
     _lib.check(lib.femasr_conv2d(None, ctypes.byref(a)))
     torch.cuda.synchronize()
+    if gn_part:
+        return out.cpu().numpy(), part
     return out.cpu().numpy()
 
 
@@ -74,6 +81,18 @@ def gn_coeffs(x, gamma, beta, eps=1e-6, groups=32):
     scratch = torch.empty(b * h * groups * 2, dtype=torch.float64, device='cuda')
     _lib.check(lib.femasr_gn_coeffs(None, _lib.ptr(tx), b, h, w, c, groups, _lib.ptr(tg), _lib.ptr(tb), eps,
                                     _lib.ptr(a), _lib.ptr(bb), _lib.ptr(scratch)))
+    torch.cuda.synchronize()
+    return a.cpu().numpy(), bb.cpu().numpy()
+
+
+def gn_coeffs_from_partials(part, h, w, c, gamma, beta, eps=1e-6):
+    lib = _lib.load()
+    b, tiles = part.shape[0], part.shape[1]
+    tg, tb = dev(gamma), dev(beta)
+    a = torch.empty((b, c), dtype=torch.float32, device='cuda')
+    bb = torch.empty((b, c), dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_gn_coeffs_from_partials(None, _lib.ptr(part), b, tiles, h, w, c, 32, _lib.ptr(tg), _lib.ptr(tb), eps,
+                                                  _lib.ptr(a), _lib.ptr(bb)))
     torch.cuda.synchronize()
     return a.cpu().numpy(), bb.cpu().numpy()
 

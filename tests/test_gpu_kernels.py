@@ -206,6 +206,26 @@ def test_conv_bf16x3_within_tolerance(cuda_device, case):
     assert err <= 1e-4 * scale, f'{name}: max-abs {err:.3e} vs scale {scale:.3e}'
 
 
+@pytest.mark.parametrize('cin,cout,shape,up', [(64, 64, (2, 20, 33), False), (128, 128, (1, 13, 10), False),
+                                               (256, 256, (1, 9, 12), True), (128, 64, (1, 7, 9), True)])
+def test_conv_bf16x3_fused_gn_moments(cuda_device, cin, cout, shape, up):
+    """bf16x3 conv epilogue emits per-tile GroupNorm partial moments of its output; finalising them must give the same
+    (a, b) as the oracle's moments of that output (tolerance: fp32 partials, 1e-5 relative)."""
+    import gpu_utils as G
+    b, h, w = shape
+    x = synth.uniform(8, 'fgx', (b, h, w, cin), -2.0, 3.0)
+    wt = synth.uniform(8, 'fgw', (3, 3, cin, cout), -0.1, 0.1)
+    bias = synth.uniform(8, 'fgb', (cout,), 0.5, 1.5)          # non-zero mean: exercises the cancellation in var
+    gamma = synth.uniform(8, 'fgg', (cout,), 0.5, 1.5)
+    beta = synth.uniform(8, 'fgbe', (cout,), -0.5, 0.5)
+    y, part = G.conv2d(x, wt, bias, 3, 1, 1, up, bf16x3=True, gn_part=True)
+    assert not torch.isnan(part).any()
+    a, bb = G.gn_coeffs_from_partials(part, y.shape[1], y.shape[2], cout, gamma, beta)
+    a_ref, b_ref = orc.gn_coeffs(y, gamma, beta)
+    assert np.abs(a - a_ref).max() <= 1e-5 * np.abs(a_ref).max()
+    assert np.abs(bb - b_ref).max() <= 2e-5 * max(1.0, np.abs(b_ref).max())
+
+
 def test_repack_oihw_layout(cuda_device):
     """femasr_repack_oihw (what set_weight runs) == the documented K-major layout."""
     import gpu_utils as G

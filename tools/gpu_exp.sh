@@ -1,2 +1,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for a in 0 1; do FEMASR_BN256=$a timeout 300 python bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > gpurun_out/ex_$a.log 2>&1; echo "bn256=$a"; tail -1 gpurun_out/ex_$a.log | python tools/bench_summary.py | grep -E "MPix|halo"; done
+for s in 1 2 3 4; do timeout 300 python bench.py --steps 4 --warmup 2 --streams $s --no-cpu-baseline --no-profile --no-exact-leg 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('streams', d['config']['streams'], 'MPix/s', d['value'], 'ms', d['ms_per_step'])
+"; done
