@@ -20,6 +20,28 @@ constexpr int ALD = BK + 1;
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// Uniform base (SGPR pair) + 32-bit unsigned per-lane BYTE offset: the global_load/store "saddr + voffset" form.  The
+// readfirstlane on both halves pins the (truly uniform) pointer into SGPRs and stops LLVM re-associating
+// (base + lane offset) + uniform offset into per-element 64-bit VALU adds (which then stay live across batched loads).
+typedef __attribute__((address_space(1))) const float *gcptr_f32;
+typedef __attribute__((address_space(1))) float *gptr_f32;
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long a)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ float ldg_u32(const float *ubase, unsigned byteoff)
+{
+    const unsigned long long a = uniform_u64(reinterpret_cast<unsigned long long>(ubase));
+    return *reinterpret_cast<gcptr_f32>(a + byteoff);
+}
+__device__ __forceinline__ void stg_u32(float *ubase, unsigned byteoff, float v)
+{
+    const unsigned long long a = uniform_u64(reinterpret_cast<unsigned long long>(ubase));
+    *reinterpret_cast<gptr_f32>(a + byteoff) = v;
+}
+
 __device__ __forceinline__ float f4get(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk)

@@ -30,6 +30,7 @@
 // Grid: 1-D, n-blocks fastest, bijective XCD remap (block b runs on XCD b % 8) so tiles sharing activations /
 //   halo rows share an L2.
 #include "conv_common.h"
+#include <type_traits>
 #include "detmath.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -259,30 +260,65 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     }
 
     if (!VQ) {
-        // store: address = uniform (tile, wave, i, j, r) part in SGPRs + one per-lane offset, no per-element VALU
-        // address math; full tiles skip the bounds checks
+        // store: out = act(acc + bias) + res1 + res2, in that order (the bit-exact contract).  Address = uniform (tile,
+        // wave, i, j, r) part in SGPRs + one per-lane offset.  On full tiles the residuals are loaded as branch-free batches
+        // of one 32x32 tile (16 values per lane), ONE TILE AHEAD of the tile being stored: a per-element `load; add; store`
+        // chain costs one HBM round trip per element (16*TM*TN per block - more than the K = 256 main loop of the Swin
+        // linears).
         const unsigned loff = (unsigned)((lane >> 5) * 4) * (unsigned)p.Cout + (unsigned)(lane & 31);
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int colu = n0 + (wn * TN + j) * 32;              // uniform
-                const int col = colu + (lane & 31);
-                const float bv = col < p.Cout ? p.bias[col] : 0.f;
+        const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
+        auto uoff = [&](int i, int j, int r) -> size_t {       // uniform
+            return (size_t)(m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2)) * p.Cout + (n0 + (wn * TN + j) * 32);
+        };
+        // edge tiles: the same code with clamped addresses (uniform part -> this tile's first element, lane part -> 0) for
+        // the loads and masked stores, so the address stays "SGPR base + one VGPR" everywhere
+        auto epilogue = [&](auto nres_c, auto full_c) {
+            constexpr int NRES = decltype(nres_c)::value;
+            constexpr bool FULL = decltype(full_c)::value;
+            constexpr int DEPTH = NRES == 1 ? 2 : 1;     // one residual: loads run a tile ahead; two: per-tile batches
+            float rbuf[DEPTH][NRES > 0 ? NRES : 1][16];
+            auto ok_u = [&](int i, int j, int r) -> bool {    // uniform: row / column-tile start inside the matrix
+                return FULL || ((m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2)) < p.M && (n0 + (wn * TN + j) * 32) < p.Cout);
+            };
+            auto ok_l = [&](int i, int j, int r) -> bool {
+                return FULL || ((m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) < p.M &&
+                                (n0 + (wn * TN + j) * 32 + (lane & 31)) < p.Cout);
+            };
+            auto issue = [&](int tl, int slot) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rowu = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2);     // uniform
-                    const size_t ou = (size_t)rowu * p.Cout + colu;                         // uniform
-                    if (full || ((rowu + 4 * (lane >> 5)) < p.M && col < p.Cout)) {
-                        float v = acc[i][j][r] + bv;
-                        if (p.act == FEMASR_ACT_GELU) v = det_gelu(v);
-                        if (p.res1) v = v + (p.res1 + ou)[loff];
-                        if (p.res2) v = v + (p.res2 + ou)[loff];
-                        (p.out + ou)[loff] = v;
-                    }
+                    const int i = tl / TN, j = tl % TN;
+                    const size_t ou = ok_u(i, j, r) ? uoff(i, j, r) : (size_t)m0 * p.Cout + n0;
+                    const unsigned lo = ok_l(i, j, r) ? 4u * loff : 0u;
+                    if (NRES >= 1) rbuf[slot][0][r] = ldg_u32(ra + ou, lo);
+                    if (NRES >= 2) rbuf[slot][NRES >= 2 ? 1 : 0][r] = ldg_u32(rb + ou, lo);
                 }
+            };
+            if (NRES > 0) issue(0, 0);
+#pragma unroll
+            for (int tl = 0; tl < TM * TN; ++tl) {
+                const int i = tl / TN, j = tl % TN;
+                if (DEPTH == 2 && tl + 1 < TM * TN) issue(tl + 1, (tl + 1) & 1);
+                const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+                const float bv = (FULL || col < p.Cout) ? p.bias[FULL ? col : (col < p.Cout ? col : 0)] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bv;
+                    if (p.act == FEMASR_ACT_GELU) v = det_gelu(v);
+                    if (NRES >= 1) v = v + rbuf[tl % DEPTH][0][r];
+                    if (NRES >= 2) v = v + rbuf[tl % DEPTH][NRES >= 2 ? 1 : 0][r];
+                    if (ok_l(i, j, r)) stg_u32(p.out + uoff(i, j, r), 4u * loff, v);
+                }
+                if (NRES > 0 && DEPTH == 1 && tl + 1 < TM * TN) issue(tl + 1, 0);
             }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (rb) { if (full) epilogue(I2{}, std::true_type{}); else epilogue(I2{}, std::false_type{}); }
+        else if (ra) { if (full) epilogue(I1{}, std::true_type{}); else epilogue(I1{}, std::false_type{}); }
+        else { if (full) epilogue(I0{}, std::true_type{}); else epilogue(I0{}, std::false_type{}); }
     } else {
         // d = (|z|^2 + |e|^2) - 2 z.e ; first-min over this block's BN columns, per row.
         float *red = smem;   // [WN][BM][2]  (the A buffers are dead after the loop's last barrier)
@@ -494,25 +530,67 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         __syncthreads();     // patch buffers swap: ONE barrier per 32-channel block (9 taps x 16 MFMA steps)
     }
 
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-            const float bv = col < p.Cout ? p.bias[col] : 0.f;
+    // out = (acc + bias) + res1 + res2, in that order (bit-exact contract).  Address = uniform part (SGPRs) + one per-lane
+    // offset: element r of row tile i sits at pixel row 2*(wm*TM+i) + (r>>3), pixel column (r&3) + 8*((r>>2)&1) +
+    // 4*(lane>>5) of the 8x16 tile.  Full tiles: residual loads are branch-free batches of one 32x32 tile issued one tile
+    // ahead of the stores (see conv_igemm_kernel's epilogue for why).
+    const bool full = (oy0 + 8 <= p.Ho) && (ox0 + TW <= p.Wo) && (n0 + BN <= p.Cout);
+    const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
+    const size_t obase = (((size_t)n * p.Ho + oy0) * p.Wo + ox0) * p.Cout + n0;             // uniform
+    const unsigned loff = (unsigned)(4 * (lane >> 5)) * (unsigned)p.Cout + (unsigned)(lane & 31);
+    const int wmu = __builtin_amdgcn_readfirstlane(wm), wnu = __builtin_amdgcn_readfirstlane(wn);    // provably uniform copies
+    auto uoff = [&](int i, int j, int r) -> size_t {            // uniform
+        return obase + (size_t)((2 * (wmu * TM + i) + (r >> 3)) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1)) * p.Cout + (wnu * TN + j) * 32;
+    };
+    // edge tiles: the same code with clamped addresses (uniform part -> this tile's first element, lane part -> 0) for the
+    // loads and masked stores
+    auto epilogue = [&](auto nres_c, auto full_c) {
+        constexpr int NRES = decltype(nres_c)::value;
+        constexpr bool FULL = decltype(full_c)::value;
+        constexpr int DEPTH = NRES == 1 ? 2 : 1;         // one residual: loads run a tile ahead; two: per-tile batches
+        float rbuf[DEPTH][NRES > 0 ? NRES : 1][16];
+        auto ok_u = [&](int i, int j, int r) -> bool {
+            return FULL || ((oy0 + 2 * (wmu * TM + i) + (r >> 3)) < p.Ho && (ox0 + (r & 3) + 8 * ((r >> 2) & 1)) < p.Wo &&
+                            (n0 + (wnu * TN + j) * 32) < p.Cout);
+        };
+        auto ok_l = [&](int i, int j, int r) -> bool {
+            return FULL || ((oy0 + 2 * (wmu * TM + i) + (r >> 3)) < p.Ho &&
+                            (ox0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) < p.Wo &&
+                            (n0 + (wnu * TN + j) * 32 + (lane & 31)) < p.Cout);
+        };
+        auto issue = [&](int tl, int slot) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (oy < p.Ho && ox < p.Wo && col < p.Cout) {
-                    float v = acc[i][j][r] + bv;
-                    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
-                    if (p.res1) v = v + p.res1[o];
-                    if (p.res2) v = v + p.res2[o];
-                    p.out[o] = v;
-                }
+                const int i = tl / TN, j = tl % TN;
+                const size_t ou = ok_u(i, j, r) ? uoff(i, j, r) : obase;
+                const unsigned lo = ok_l(i, j, r) ? 4u * loff : 0u;
+                if (NRES >= 1) rbuf[slot][0][r] = ldg_u32(ra + ou, lo);
+                if (NRES >= 2) rbuf[slot][NRES >= 2 ? 1 : 0][r] = ldg_u32(rb + ou, lo);
             }
+        };
+        if (NRES > 0) issue(0, 0);
+#pragma unroll
+        for (int tl = 0; tl < TM * TN; ++tl) {
+            const int i = tl / TN, j = tl % TN;
+            if (DEPTH == 2 && tl + 1 < TM * TN) issue(tl + 1, (tl + 1) & 1);
+            const int col = n0 + (wnu * TN + j) * 32 + (lane & 31);
+            const float bv = (FULL || col < p.Cout) ? p.bias[FULL ? col : (col < p.Cout ? col : 0)] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + bv;
+                if (NRES >= 1) v = v + rbuf[tl % DEPTH][0][r];
+                if (NRES >= 2) v = v + rbuf[tl % DEPTH][NRES >= 2 ? 1 : 0][r];
+                if (ok_l(i, j, r)) stg_u32(p.out + uoff(i, j, r), 4u * loff, v);
+            }
+            if (NRES > 0 && DEPTH == 1 && tl + 1 < TM * TN) issue(tl + 1, 0);
         }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if (rb) { if (full) epilogue(I2{}, std::true_type{}); else epilogue(I2{}, std::false_type{}); }
+    else if (ra) { if (full) epilogue(I1{}, std::true_type{}); else epilogue(I1{}, std::false_type{}); }
+    else { if (full) epilogue(I0{}, std::true_type{}); else epilogue(I0{}, std::false_type{}); }
 }
 
 template <bool UP2>

@@ -19,9 +19,22 @@
 // Blocks: 256 threads = 4 waves, 64x64 (BN=128) / 32x64 (BN=64) / 32x32 (BN=32) outputs per wave.
 #include "conv_common.h"
 #include "detmath.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifdef FEMASR_TAPTIME
+__device__ unsigned long long g_taptime[16];     // debug build only: per-wave cycle sums (tap 0..8, barrier, total, prologue, epilogue)
+#define TT_STAMP(slot)                                              \
+    {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        tt[slot] += now_ - tprev;                                    \
+        tprev = now_;                                                \
+    }
+#else
+#define TT_STAMP(slot) {}
+#endif
 
 namespace {
 
@@ -54,12 +67,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "tile config");
     static_assert(PRO != FEMASR_PRO_LN, "no LayerNorm prologue on 3x3 convs");
     static_assert(1 + PUNITS <= 9, "patch slices are spread over taps 1..");
+    // ROT: the 128 px x 64 ch wave tile (8 accumulator tiles = 128 registers) leaves no room for the two-deep A-fragment
+    // and whole-patch staging registers of the smaller tiles: A fragments rotate through ONE hi and ONE lo set (lo(s)
+    // is fetched under the two hi terms, hi(s+1) under the lo term) and the next patch is staged in two halves.
+    constexpr bool ROT = TM * TN >= 8;
+    constexpr int NG = ROT ? 3 : 1, GS = (PUNITS + NG - 1) / NG;      // patch units are loaded / stored in NG groups of GS
 
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_u16[];
-    constexpr int HALF = PP * PPITCH;            // ushorts per (buffer, hi|lo) image
+    constexpr int HALF = (PP + 1) * PPITCH;      // ushorts per (buffer, hi|lo) image; pixel PP is a write-only dummy slot
     unsigned short *Ps = smem_u16;               // [2][2][PP][PPITCH]
 
     const int t = threadIdx.x, lane = t & 63;
+#ifdef FEMASR_TAPTIME
+    unsigned long long tt[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
@@ -85,20 +108,28 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         pmask |= (ok ? 1u : 0u) << i;
     }
 
-    float4 rp[PUNITS], ga, gb;
-    auto load_patch = [&](int cc) {
-#pragma unroll
-        for (int i = 0; i < PUNITS; ++i) rp[i] = ld4(p.in + (size_t)poff[i] + (size_t)cc * BK);
-        if (PRO == FEMASR_PRO_GN_SILU) {
-            ga = ld4(p.pro_a + (size_t)n * p.Cin + cc * BK + 4 * kq);
-            gb = ld4(p.pro_b + (size_t)n * p.Cin + cc * BK + 4 * kq);
+    // GroupNorm coefficients of this sample: staged once in LDS behind the patch buffers ([2][Cin] floats), read back per
+    // unit at store time (no per-channel-block global loads in the main loop, no registers held across taps)
+    float *gco = reinterpret_cast<float *>(smem_u16 + 4 * HALF);
+    if (PRO == FEMASR_PRO_GN_SILU) {
+        for (int c = t; c < p.Cin; c += NT) {
+            gco[c] = p.pro_a[(size_t)n * p.Cin + c];
+            gco[p.Cin + c] = p.pro_b[(size_t)n * p.Cin + c];
         }
+    }
+    float4 rp[GS];
+    auto load_patch = [&](int cc, int g) {          // group g: units [g*GS, min((g+1)*GS, PUNITS))
+#pragma unroll
+        for (int i = 0; i < GS; ++i)
+            if (g * GS + i < PUNITS) rp[i] = ld4(p.in + (size_t)poff[g * GS + i] + (size_t)cc * BK);
     };
-    auto store_patch_unit = [&](int buf, int i) {
-        const int pix = (t >> 3) + PROWS * i;
-        if (PP % PROWS != 0 && i == PUNITS - 1 && pix >= PP) return;
-        float4 v = rp[i];
+    auto store_patch_unit = [&](int buf, int i, int cc) {
+        int pix = (t >> 3) + PROWS * i;
+        if (PP % PROWS != 0 && i == PUNITS - 1) pix = pix < PP ? pix : PP;     // no branch: keeps the wait counters exact
+        float4 v = rp[i % GS];
         if (PRO == FEMASR_PRO_GN_SILU) {
+            const float4 ga = *reinterpret_cast<const float4 *>(gco + cc * BK + 4 * kq);
+            const float4 gb = *reinterpret_cast<const float4 *>(gco + p.Cin + cc * BK + 4 * kq);
             v.x = fast_silu(__builtin_fmaf(v.x, ga.x, gb.x));
             v.y = fast_silu(__builtin_fmaf(v.y, ga.y, gb.y));
             v.z = fast_silu(__builtin_fmaf(v.z, ga.z, gb.z));
@@ -113,44 +144,67 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         *reinterpret_cast<uint2 *>(dst + HALF) = make_uint2(l01, l23);
     };
 
-    // accumulators start from bias + residuals (this path is tolerance-based, so the order of the final additions is
-    // free): the residual loads overlap the first patch load instead of serialising in the epilogue
+    // accumulators start from the residuals (this path is tolerance-based, so the order of the final additions is free);
+    // the bias is added right before the main loop.  The loads are issued as ONE branch-free batch (out-of-range elements
+    // read element 0 and are never stored): a per-element `if (in range) v += res[o]` makes the compiler wait for each
+    // load before issuing the next, i.e. TM*TN*16 serialised HBM round trips per block (measured: 44 % of the block's
+    // lifetime before this change).
+    // Output addressing = uniform part (SGPRs) + one per-lane offset: element r of row tile i sits at pixel row
+    // 2*(wm*TM+i) + (r>>3), pixel column (r&3) + 8*((r>>2)&1) + 4*(lane>>5) of the 8x16 tile (conv3x3_halo_kernel's scheme).
+    const size_t obase = (((size_t)n * p.Ho + oy0) * p.Wo + ox0) * p.Cout + n0;             // uniform
+    const unsigned loff4 = 4u * ((unsigned)(4 * (lane >> 5)) * (unsigned)p.Cout + (unsigned)(lane & 31));      // bytes
+    auto uoff = [&](int i, int j, int r) -> size_t {            // uniform
+        return obase + (size_t)((2 * (wm * TM + i) + (r >> 3)) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1)) * p.Cout + (wn * TN + j) * 32;
+    };
+    auto ok_u = [&](int i, int j, int r) -> bool {
+        return (oy0 + 2 * (wm * TM + i) + (r >> 3)) < p.Ho && (ox0 + (r & 3) + 8 * ((r >> 2) & 1)) < p.Wo && (n0 + (wn * TN + j) * 32) < p.Cout;
+    };
+    auto ok_l = [&](int i, int j, int r) -> bool {
+        return (oy0 + 2 * (wm * TM + i) + (r >> 3)) < p.Ho && (ox0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) < p.Wo &&
+               (n0 + (wn * TN + j) * 32 + (lane & 31)) < p.Cout;
+    };
+    auto ld_res = [&](const float *res, int i, int j, int r) -> float {     // clamped: out-of-range elements read the tile origin
+        return ldg_u32(res + (ok_u(i, j, r) ? uoff(i, j, r) : obase), ok_l(i, j, r) ? loff4 : 0u);
+    };
     f32x16 acc[TM][TN];
+    const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
+    if (ra) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-            const float bv = col < p.Cout ? p.bias[col] : 0.f;
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                float v = bv;
-                if (oy < p.Ho && ox < p.Wo && col < p.Cout) {
-                    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
-                    if (p.res1) v = v + p.res1[o];
-                    if (p.res2) v = v + p.res2[o];
-                }
-                acc[i][j][r] = v;
-            }
-        }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = ld_res(ra, i, j, r);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
-    // split weights, fragment-major: [q][ntile][lane][kstep(2)][hi8|lo8] bf16 = 4 x uint4 per (q, ntile, lane)
+    // split weights, fragment-major: [q][ntile][kstep(2)][hi|lo][lane] x 8 bf16: every wave-level load is one contiguous KiB
     const uint4 *wl[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) wl[j] = wsplit + ((((size_t)(n0 >> 5) + wn * TN + j) * 64 + lane) << 2);
+    for (int j = 0; j < TN; ++j) wl[j] = wsplit + (((size_t)(n0 >> 5) + wn * TN + j) * 256 + lane);
     const size_t wstride = (size_t)p.NT32 << 8;     // uint4 per K chunk
 
     const int ncc = p.Cin / BK;
-    load_patch(0);
+    load_patch(0, 0);
     uint4 bc[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bc[j][e] = wl[j][e];
+        for (int e = 0; e < 4; ++e) bc[j][e] = wl[j][e * 64];
+    if (PRO == FEMASR_PRO_GN_SILU) __syncthreads();     // gco visible
 #pragma unroll
-    for (int i = 0; i < PUNITS; ++i) store_patch_unit(0, i);
+    for (int g = 0; g < NG; ++g) {
+        if (g > 0) load_patch(0, g);
+#pragma unroll
+        for (int i = 0; i < GS; ++i)
+            if (g * GS + i < PUNITS) store_patch_unit(0, g * GS + i, 0);
+    }
     __syncthreads();
 
     int py[TM], px;
@@ -162,72 +216,174 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     }
     const int koff = 8 * (lane >> 5);                // this lane's k sub-block inside a 16-deep k-step
 
+    // LDS index of this lane's A-fragment pixel for (tap, row tile i).  Without the fused x2 upsample it is ONE per-lane
+    // base plus a compile-time constant (folded into the ds_read offset field); with it the halving depends on the lane.
+    const int abase = (py[0] * PW + px) * PPITCH;
+    auto patch_idx = [&](int tap, int (&idx)[TM]) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (UP2) {
+                const int prow = ((py[i] + ky - 1) >> 1) + 1, pcol = ((px + kx - 1) >> 1) + 1;
+                idx[i] = (prow * PW + pcol) * PPITCH;
+            } else {
+                idx[i] = abase + ((2 * i + ky) * PW + kx) * PPITCH;
+            }
+        }
+    };
+
+    // Main loop.  Everything inside is UNCONDITIONAL straight-line code (9 taps unrolled; the last channel block
+    // re-stages itself into the idle LDS buffer and re-reads the last weight chunk) so that the compiler knows exactly
+    // how many loads are in flight and emits exact s_waitcnt values; a conditional load costs a vmcnt(0) per k-step.
+    const int nq = ncc * 9;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const float bv = col < p.Cout ? p.bias[col] : 0.f;
+            if (rb) {           // second residual (rare: last ResBlock of an up block): one batch per 32x32 tile
+                float tmp[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmp[r] = ld_res(rb, i, j, r);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += tmp[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+        }
+    TT_STAMP(11)
     for (int cc = 0; cc < ncc; ++cc) {
         const unsigned short *Pb = Ps + ((cc & 1) * 2) * HALF + koff;
-        const bool more_p = cc + 1 < ncc;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int q = cc * 9 + tap;
-            const bool more_w = (q + 1) < ncc * 9;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            if (more_p && tap == 0) load_patch(cc + 1);
-            int aidx[TM];
+        const int ccn = cc + 1 < ncc ? cc + 1 : cc;
+        const int nbuf = (cc + 1) & 1;
+        if constexpr (ROT) {
+            uint4 a_hi[TM], a_lo[TM];
+            int aidx[TM], nidx[TM];
+            patch_idx(0, aidx);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int prow = UP2 ? ((py[i] + ky - 1) >> 1) + 1 : py[i] + ky;
-                const int pcol = UP2 ? ((px + kx - 1) >> 1) + 1 : px + kx;
-                aidx[i] = (prow * PW + pcol) * PPITCH;
+            for (int i = 0; i < TM; ++i) a_hi[i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap > 0) TT_STAMP(tap - 1)
+                const int q1 = cc * 9 + tap + 1;
+                const size_t qn = (size_t)(q1 < nq ? q1 : nq - 1);
+                if (tap == 0) load_patch(ccn, 0);
+                patch_idx(tap < 8 ? tap + 1 : 8, nidx);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a_lo[i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + 16 * s + HALF);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int term = 0; term < 2; ++term)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi[i]), as_bf16x8(bc[j][2 * s + term]),
+                                                                                    acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the hi registers are free: fetch the next k-step's (or next tap's) hi fragments under the lo term
+                    if (s == 0) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) a_hi[i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + 16);
+                    } else if (tap < 8) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) a_hi[i] = *reinterpret_cast<const uint4 *>(Pb + nidx[i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo[i]), as_bf16x8(bc[j][2 * s]), acc[i][j],
+                                                                                0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        bc[j][2 * s] = (wl[j] + qn * wstride)[(2 * s) * 64];
+                        bc[j][2 * s + 1] = (wl[j] + qn * wstride)[(2 * s + 1) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) aidx[i] = nidx[i];
+                // next channel block's patch in three groups (registers for one group only): group g is loaded at tap
+                // 3g (right after the previous group's store) and normalised / split / stored at tap 3g + 2
+                if (tap % 3 == 2) {
+                    const int g = tap / 3;
+#pragma unroll
+                    for (int i = 0; i < GS; ++i)
+                        if (g * GS + i < PUNITS) store_patch_unit(nbuf, g * GS + i, ccn);
+                    if (g + 1 < NG && (g + 1) * GS < PUNITS) load_patch(ccn, g + 1);
+                }
             }
-            // A fragments are fetched one k-step ahead (s=1 while s=0 multiplies; the next tap's s=0 is fetched by the
-            // next iteration's prologue read below), pinned with sched_barrier so the LDS latency hides behind MFMAs
+        } else {
             uint4 a_hi[2][TM], a_lo[2][TM];
+            int aidx[TM];
+            patch_idx(0, aidx);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 a_hi[0][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i]);
                 a_lo[0][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + HALF);
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (s == 0) {
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap > 0) TT_STAMP(tap - 1)
+                const int q1 = cc * 9 + tap + 1;
+                const size_t qn = (size_t)(q1 < nq ? q1 : nq - 1);
+                if (tap == 0) load_patch(ccn, 0);
+                int nidx[TM];
+                patch_idx(tap < 8 ? tap + 1 : 8, nidx);
+                // A fragments are fetched one k-step ahead (s=1 while s=0 multiplies, the next tap's s=0 while s=1
+                // multiplies), pinned with sched_barrier so the LDS latency hides behind MFMAs
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        a_hi[1][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + 16);
-                        a_lo[1][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + 16 + HALF);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // term-major order: consecutive MFMAs hit DIFFERENT accumulator tiles, so the dependent-accumulator
-                // latency of the 32x32x16 bf16 MFMA (longer than its issue interval) is hidden
+                for (int s = 0; s < 2; ++s) {
+                    if (s == 0) {
 #pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            const bf16x8 a = as_bf16x8(term == 2 ? a_lo[s][i] : a_hi[s][i]);
-                            const bf16x8 b = as_bf16x8(term == 1 ? bc[j][2 * s + 1] : bc[j][2 * s]);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+                        for (int i = 0; i < TM; ++i) {
+                            a_hi[1][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + 16);
+                            a_lo[1][i] = *reinterpret_cast<const uint4 *>(Pb + aidx[i] + 16 + HALF);
                         }
-                // this k-step's weight registers are free now: refill them with the NEXT tap's fragments (half a tap of
-                // MFMAs ahead of their use), no register copies
-                if (more_w) {
+                    } else if (tap < 8) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            a_hi[0][i] = *reinterpret_cast<const uint4 *>(Pb + nidx[i]);
+                            a_lo[0][i] = *reinterpret_cast<const uint4 *>(Pb + nidx[i] + HALF);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // term-major order: consecutive MFMAs hit DIFFERENT accumulator tiles, so the dependent-accumulator
+                    // latency of the 32x32x16 bf16 MFMA (longer than its issue interval) is hidden
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                const bf16x8 a = as_bf16x8(term == 2 ? a_lo[s][i] : a_hi[s][i]);
+                                const bf16x8 b = as_bf16x8(term == 1 ? bc[j][2 * s + 1] : bc[j][2 * s]);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+                            }
+                    // this k-step's weight registers are free now: refill them with the NEXT tap's fragments (one tap of
+                    // MFMAs ahead of their use), no register copies
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        bc[j][2 * s] = (wl[j] + (size_t)(q + 1) * wstride)[2 * s];
-                        bc[j][2 * s + 1] = (wl[j] + (size_t)(q + 1) * wstride)[2 * s + 1];
+                        bc[j][2 * s] = (wl[j] + qn * wstride)[(2 * s) * 64];
+                        bc[j][2 * s + 1] = (wl[j] + qn * wstride)[(2 * s + 1) * 64];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // next channel block's patch: loaded at tap 0, one unit normalised / split / stored per tap over the LAST
-            // PUNITS taps (bf16 taps are ~5x shorter than fp32 ones: the HBM latency needs the distance)
-            if (more_p && tap >= 9 - PUNITS) {
 #pragma unroll
-                for (int i = 0; i < PUNITS; ++i)
-                    if (tap == i + 9 - PUNITS) store_patch_unit((cc + 1) & 1, i);
+                for (int i = 0; i < TM; ++i) aidx[i] = nidx[i];
+                // next channel block's patch: loaded at tap 0, one unit normalised / split / stored per tap over the LAST
+                // PUNITS taps (bf16 taps are ~5x shorter than fp32 ones: the HBM latency needs the distance)
+                if (tap >= 9 - PUNITS) store_patch_unit(nbuf, tap - (9 - PUNITS), ccn);
             }
         }
+        TT_STAMP(8)
         __syncthreads();
+        TT_STAMP(9)
     }
 
     float colsum[TM][TN], colsq[TM][TN];
@@ -235,15 +391,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
             float ps = 0.f, pss = 0.f;      // this lane's share of the GroupNorm moments of the OUTPUT (column `col`)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (oy < p.Ho && ox < p.Wo && col < p.Cout) {
+                if (ok_l(i, j, r)) {
                     const float v = acc[i][j][r];
-                    p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + col] = v;
+                    stg_u32(p.out + uoff(i, j, r), loff4, v);
                     ps += v;
                     pss = __builtin_fmaf(v, v, pss);
                 }
@@ -254,6 +407,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     // Optional fused GroupNorm moments of the output (consumed by the NEXT conv's GN prologue): per (tile, group)
     // partial sums, reduced lane -> group (xor shuffles over the cg lanes of a group, then the two row halves) -> waves
     // (LDS) and written as doubles to stats_part[((n*tiles + tile)*32 + g)*2]; a fixed order, so runs are reproducible.
+#ifdef FEMASR_TAPTIME
+    TT_STAMP(12)
+    tt[10] = tprev - tstart;
+    if (lane == 0)
+        for (int i = 0; i < 13; ++i) atomicAdd(&g_taptime[i], tt[i]);
+#endif
     if (stats_part) {
         const int cg = p.Cout >> 5;                       // channels per group (32 groups): 8 / 4 / 2
         double *red = reinterpret_cast<double *>(smem_u16);   // [WM][BN/2][2] (patch buffers are dead after the last barrier)
@@ -291,7 +450,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     }
 }
 
-// OIHW fp32 -> split bf16 fragment-major: out ushort index = (((((q*NT32 + ntile)*64 + lane)*2 + s)*2 + h)*8 + e)
+// OIHW fp32 -> split bf16 fragment-major: out ushort index = (((((q*NT32 + ntile)*2 + s)*2 + h)*64 + lane)*8 + e)
 //   k = q*32 + 16 s + 8 (lane>>5) + e  in the blocked K order, n = ntile*32 + (lane&31), h: 0 = hi, 1 = lo
 __device__ __forceinline__ unsigned short bf16_rne(float x)
 {
@@ -305,7 +464,7 @@ __global__ void repack_oihw_bf16x3_kernel(const float *__restrict__ in, int O, i
 {
     const int K = I * kh * kw, NT32 = (O + 31) / 32;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), h = (int)((i >> 3) & 1), s = (int)((i >> 4) & 1), lane = (int)((i >> 5) & 63);
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), h = (int)((i >> 9) & 1), s = (int)((i >> 10) & 1);
         const size_t rest = i >> 11;
         const int ntile = (int)(rest % NT32), q = (int)(rest / NT32);
         const int k = q * 32 + 16 * s + 8 * (lane >> 5) + e, o = ntile * 32 + (lane & 31);
@@ -326,7 +485,7 @@ __global__ void repack_oihw_bf16x3_kernel(const float *__restrict__ in, int O, i
 }
 
 template <bool UP2>
-constexpr size_t bf16_lds_bytes() { return (size_t)2 * 2 * (UP2 ? 60 : 180) * PPITCH * sizeof(unsigned short); }
+constexpr size_t bf16_lds_bytes() { return (size_t)2 * 2 * ((UP2 ? 60 : 180) + 1) * PPITCH * sizeof(unsigned short); }   // + 2*Cin floats (GN)
 
 struct Variant16 {
     const char *name;
@@ -349,6 +508,9 @@ Variant16 g_v16[] = {
     FEMASR_H16(32, 4, 1, FEMASR_PRO_NONE, false),      // 6
     FEMASR_H16(32, 4, 1, FEMASR_PRO_GN_SILU, false),   // 7
     FEMASR_H16(32, 4, 1, FEMASR_PRO_NONE, true),       // 8
+    FEMASR_H16(256, 1, 4, FEMASR_PRO_NONE, false),     // 9   (4 waves: 128 px x 64 ch per wave, one column block for Cout = 256)
+    FEMASR_H16(256, 1, 4, FEMASR_PRO_GN_SILU, false),  // 10
+    FEMASR_H16(256, 1, 4, FEMASR_PRO_NONE, true),      // 11
 };
 constexpr int kNum16 = sizeof(g_v16) / sizeof(g_v16[0]);
 
@@ -361,7 +523,8 @@ bool femasr_conv_bf16x3_eligible(const femasr_conv_args *a)
 {
     return a->w_bf16x3 && a->ksz == 3 && a->stride == 1 && a->pad == 1 && (a->Cin % BK) == 0 &&
            a->prologue != FEMASR_PRO_LN && a->act == FEMASR_ACT_NONE && !(a->up2 && a->prologue != FEMASR_PRO_NONE) &&
-           (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31);
+           a->Cin <= 1024 && (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31) &&
+           (size_t)a->B * a->H * a->W * (a->up2 ? 4 : 1) * a->Cout < ((size_t)1 << 31);
 }
 
 int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out)
@@ -374,7 +537,8 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
     p.in = a->in; p.bias = a->bias; p.pro_a = a->pro_a; p.pro_b = a->pro_b; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.ksz = 3; p.stride = 1; p.pad = 1; p.up2 = a->up2;
     p.Ho = Hv; p.Wo = Wv; p.NT32 = (a->Cout + 31) / 32;
-    const int cls = a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2);
+    int cls = a->Cout > 128 ? 3 : (a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2));
+    if (getenv("FEMASR_BF16_CLS")) cls = atoi(getenv("FEMASR_BF16_CLS"));
     const int vi = cls * 3 + (a->up2 ? 2 : a->prologue);
     Variant16 &v = g_v16[vi];
     p.tilesX = (p.Wo + 15) / 16;
@@ -382,18 +546,31 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
     p.MB = a->B * p.tilesX * p.tilesY;
     p.NB = (a->Cout + v.bn - 1) / v.bn;
     if (!v.attr_set) {
-        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds + 8 * 1024));
         v.attr_set = true;
     }
+    const size_t lds = v.lds + (a->prologue == FEMASR_PRO_GN_SILU ? (size_t)2 * a->Cin * sizeof(float) : 0);
     FEMASR_REQUIRE(!a->gn_part || (a->Cout % 32 == 0 && (a->Cout / 32) <= 8 && v.bn % (a->Cout / 32) == 0),
                    "conv bf16x3: fused GN moments need Cout %% 32 == 0 and <= 8 channels per group");
-    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), v.lds, s, p, (const uint4 *)a->w_bf16x3,
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), lds, s, p, (const uint4 *)a->w_bf16x3,
                        (double *)a->gn_part);
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
     if (flops_out) *flops_out = 2.0 * (double)a->B * p.Ho * p.Wo * (double)a->Cout * 9.0 * a->Cin;
     return FEMASR_OK;
 }
+
+#ifdef FEMASR_TAPTIME
+extern "C" int femasr_debug_taptime(unsigned long long *out16, int reset)
+{
+    if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_taptime), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_taptime), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 extern "C" {
 

@@ -177,6 +177,9 @@ BF16_CASES = [
     ('b16_gn_128_128_edges', (2, 13, 10, 128), 128, False, True),
     ('b16_cout3', (1, 24, 20, 64), 3, False, False),
     ('b16_up2_128_64', (1, 7, 9, 128), 64, True, False),
+    ('b16_gn_256_256_edges', (2, 13, 21, 256), 256, False, True),     # 256-wide block: 128 px x 64 ch per wave
+    ('b16_up2_256_256', (1, 9, 12, 256), 256, True, False),
+    ('b16_gn_64_256', (1, 17, 16, 64), 256, False, True),
 ]
 
 

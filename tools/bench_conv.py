@@ -1,0 +1,87 @@
+"""Micro-benchmark of ONE conv through the C ABI (femasr_conv2d) with device-resident synthetic tensors.
+Usage: python tools/bench_conv.py B H W Cin Cout [--up2] [--gn] [--res] [--fp32] [--iters N] [--gn-part]
+Prints ms per launch and algorithmic TFLOP/s.  Used for kernel experiments (FEMASR_ABL / FEMASR_BF16_CLS env)."""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+from femasr_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('dims', type=int, nargs=5)
+    ap.add_argument('--up2', action='store_true')
+    ap.add_argument('--gn', action='store_true')
+    ap.add_argument('--res', action='store_true')
+    ap.add_argument('--fp32', action='store_true')
+    ap.add_argument('--gn-part', action='store_true')
+    ap.add_argument('--iters', type=int, default=10)
+    a_ = ap.parse_args()
+    b, h, w, cin, cout = a_.dims
+    if os.environ.get('FEMASR_SO'):          # debug builds (tools/build_debug.sh)
+        _lib.SO_PATH = os.environ['FEMASR_SO']
+    lib = _lib.load()
+    torch.manual_seed(0)
+    dev = 'cuda'
+    x = torch.randn(b, h, w, cin, device=dev)
+    w_oihw = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    bias = torch.randn(cout, device=dev)
+    ho, wo = (2 * h, 2 * w) if a_.up2 else (h, w)
+    out = torch.empty(b, ho, wo, cout, device=dev)
+    wp = torch.empty(int(lib.femasr_packed_weight_floats(cout, cin, 3, 3)), device=dev)
+    _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(w_oihw), cout, cin, 3, 3, _lib.ptr(wp)))
+    args = _lib.ConvArgs()
+    args.in_ = x.data_ptr(); args.B, args.H, args.W, args.Cin = b, h, w, cin
+    args.w = wp.data_ptr(); args.bias = bias.data_ptr()
+    args.Cout, args.ksz, args.stride, args.pad, args.up2 = cout, 3, 1, 1, int(a_.up2)
+    args.out = out.data_ptr(); args.Ho, args.Wo = ho, wo
+    keep = []
+    if a_.gn:
+        pa = torch.rand(b, cin, device=dev) + 0.5
+        pb = torch.randn(b, cin, device=dev) * 0.1
+        args.prologue = _lib.PRO_GN_SILU; args.pro_a = pa.data_ptr(); args.pro_b = pb.data_ptr()
+        keep += [pa, pb]
+    if a_.res:
+        r = torch.randn(b, ho, wo, cout, device=dev)
+        args.res1 = r.data_ptr(); keep.append(r)
+    if not a_.fp32:
+        ws = torch.empty(int(lib.femasr_packed_weight_bf16x3_bytes(cout, cin, 3, 3)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.femasr_repack_oihw_bf16x3(None, _lib.ptr(w_oihw), cout, cin, 3, 3, _lib.ptr(ws)))
+        args.w_bf16x3 = ws.data_ptr(); keep.append(ws)
+    if a_.gn_part:
+        tiles = ((ho + 7) // 8) * ((wo + 15) // 16)
+        part = torch.empty(b, tiles, 32, 2, dtype=torch.float64, device=dev)
+        args.gn_part = part.data_ptr(); keep.append(part)
+    for _ in range(2):
+        _lib.check(lib.femasr_conv2d(None, ctypes.byref(args)))
+    torch.cuda.synchronize()
+    tt = os.environ.get('FEMASR_SO') and hasattr(lib._lib if hasattr(lib, '_lib') else lib, 'femasr_debug_taptime')
+    if tt:
+        raw = lib._lib if hasattr(lib, '_lib') else lib
+        raw.femasr_debug_taptime(None, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a_.iters):
+        _lib.check(lib.femasr_conv2d(None, ctypes.byref(args)))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a_.iters
+    fl = 2.0 * b * ho * wo * cout * 9 * cin
+    if tt:
+        buf = (ctypes.c_ulonglong * 16)()
+        raw.femasr_debug_taptime(buf, 0)
+        tot = float(buf[10]) or 1.0
+        names = ['tap%d' % i for i in range(9)] + ['barrier', 'total', 'prologue', 'epilogue']
+        print('  per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(names) if n != 'total'))
+        print('  total wave-cycles per launch: %.3e' % (tot / a_.iters))
+    print('conv %s abl=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_ABL', '0'),
+                                                                    os.environ.get('FEMASR_BF16_CLS', '-'), ms, fl / ms / 1e9))
+
+
+if __name__ == '__main__':
+    main()
