@@ -39,6 +39,24 @@ namespace {
 
 // C/D layout of a 32x32 MFMA tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 
+#ifdef FEMASR_TAPTIME
+__device__ unsigned long long g_igemm_time[8 * 65536];     // debug build only: per-wave cycle sums (mfma, store, barrier, prologue, epilogue, total)
+#define IT_STAMP_ALWAYS(slot)                                       \
+    {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        tt[slot] += now_ - tprev;                                    \
+        tprev = now_;                                                \
+    }
+#if FEMASR_TAPTIME >= 2
+#define IT_STAMP(slot) IT_STAMP_ALWAYS(slot)
+#else
+#define IT_STAMP(slot) {}
+#endif
+#else
+#define IT_STAMP(slot) {}
+#define IT_STAMP_ALWAYS(slot) {}
+#endif
+
 // =================================================================================================================
 // conv_igemm: implicit GEMM, M = B*Ho*Wo pixels, N = Cout, K chunks of 32
 // =================================================================================================================
@@ -58,6 +76,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform -> SGPR arithmetic
+#ifdef FEMASR_TAPTIME
+    unsigned long long tt[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
     const int wm = wave / WN, wn = wave % WN;
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
     const int nb = L % p.NB, mb = L / p.NB;
@@ -174,6 +197,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
         float *Ab = As + buf * BM * ALD;
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
+            // opaque use: pins the prologue arithmetic HERE (after the chunk's MFMAs); without it the optimizer hoists part
+            // of it to just behind the loads and the wave stalls on the HBM latency at the top of every chunk
+            asm volatile("" : "+v"(ra[j].x), "+v"(ra[j].y), "+v"(ra[j].z), "+v"(ra[j].w));
             float4 v = ra[j];
             if (PRO == FEMASR_PRO_GN_SILU) {
                 v.x = det_silu(__builtin_fmaf(v.x, rga[j].x, rgb[j].x));
@@ -218,11 +244,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     __syncthreads();
 
     const int arow = (wm * TM * 32 + (lane & 31)) * ALD + (lane >> 5);
+    IT_STAMP(3)
 
+    // The loop body is unconditional straight-line code: the last chunk re-loads itself and re-stages it into the idle
+    // LDS buffer, so the compiler knows exactly how many loads are in flight at every wait (a conditional load forces a
+    // conservative s_waitcnt vmcnt(0) at the next use of ANY loaded value).
     for (int c = 0; c < p.nchunks; ++c) {
         const int buf = c & 1;
-        const bool more = (c + 1) < p.nchunks;
-        if (more) load_chunk(c + 1);
+        const int cn = (c + 1) < p.nchunks ? c + 1 : c;
         const float *Ab = As + buf * BM * ALD + arow;
         float af[2][TM];
 #pragma unroll
@@ -234,10 +263,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
                 if (g < 3) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)c * wstride + 4 * (g + 1));
-                } else if (more) {
+                } else {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)(c + 1) * wstride);
+                    for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)cn * wstride);
                 }
+                // next chunk's A rows: issued right AFTER a weight prefetch.  Loads complete in order, so the first
+                // younger weight load that is waited for (two prefetch groups = 16 MFMAs later) also waits for these
+                // HBM loads; issued before the prefetch they would only get 8 MFMAs of cover.
+                if (kk == 0) load_chunk(cn);
             }
             if (kk + 1 < BK / 2) {
 #pragma unroll
@@ -255,9 +288,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_chunk(buf ^ 1);
+        IT_STAMP(0)
+        store_chunk(buf ^ 1);
+        IT_STAMP(1)
         __syncthreads();
+        IT_STAMP(2)
     }
+#if defined(FEMASR_TAPTIME) && FEMASR_TAPTIME < 2
+    IT_STAMP_ALWAYS(0)
+#endif
 
     if (!VQ) {
         // store: out = act(acc + bias) + res1 + res2, in that order (the bit-exact contract).  Address = uniform (tile,
@@ -365,6 +404,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
             dst[1] = __int_as_float(bi);
         }
     }
+#ifdef FEMASR_TAPTIME
+    IT_STAMP_ALWAYS(4)
+    tt[5] = tprev - tstart;
+    if (lane == 0 && K1) {
+        const unsigned slot = (blockIdx.x * (WM * WN) + wave) & 65535u;
+        for (int i = 0; i < 6; ++i) g_igemm_time[slot * 8 + i] += tt[i];
+    }
+#endif
 }
 
 // =================================================================================================================
@@ -723,3 +770,22 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K;
     return FEMASR_OK;
 }
+
+#ifdef FEMASR_TAPTIME
+extern "C" int femasr_debug_igemm_time(unsigned long long *out8, int reset)
+{
+    static unsigned long long host[8 * 65536];
+    if (out8) {
+        hipMemcpyFromSymbol(host, HIP_SYMBOL(g_igemm_time), sizeof(host));
+        for (int i = 0; i < 8; ++i) out8[i] = 0;
+        for (int w = 0; w < 65536; ++w)
+            for (int i = 0; i < 8; ++i) out8[i] += host[w * 8 + i];
+    }
+    if (reset) {
+        void *d = nullptr;
+        hipGetSymbolAddress(&d, HIP_SYMBOL(g_igemm_time));
+        hipMemset(d, 0, sizeof(host));
+    }
+    return 0;
+}
+#endif

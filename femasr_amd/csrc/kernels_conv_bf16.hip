@@ -23,17 +23,27 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef FEMASR_TAPTIME
-__device__ unsigned long long g_taptime[16];     // debug build only: per-wave cycle sums (tap 0..8, barrier, total, prologue, epilogue)
-#define TT_STAMP(slot)                                              \
+// debug build only (tools/build_debug.sh): per-wave cycle sums (tap 0..8, barrier, total, prologue, epilogue).  Level 1
+// stamps only prologue / main loop / epilogue (4 s_memtime per wave: negligible intrusion); FEMASR_TAPTIME=2 also
+// stamps every tap and barrier (each stamp drains lgkmcnt, so that mode slows the kernel and is only for ratios).
+__device__ unsigned long long g_taptime[16 * 65536];     // [wave slot][16], plain stores (same-address atomics serialise)
+#define TT_STAMP_ALWAYS(slot)                                       \
     {                                                                \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
         tt[slot] += now_ - tprev;                                    \
         tprev = now_;                                                \
     }
+#if FEMASR_TAPTIME >= 2
+#define TT_STAMP(slot) TT_STAMP_ALWAYS(slot)
 #else
 #define TT_STAMP(slot) {}
+#endif
+#else
+#define TT_STAMP(slot) {}
+#define TT_STAMP_ALWAYS(slot) {}
 #endif
 
 namespace {
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
         }
-    TT_STAMP(11)
+    TT_STAMP_ALWAYS(11)
     for (int cc = 0; cc < ncc; ++cc) {
         const unsigned short *Pb = Ps + ((cc & 1) * 2) * HALF + koff;
         const int ccn = cc + 1 < ncc ? cc + 1 : cc;
@@ -385,33 +395,81 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         __syncthreads();
         TT_STAMP(9)
     }
+#if defined(FEMASR_TAPTIME) && FEMASR_TAPTIME < 2
+    TT_STAMP_ALWAYS(0)
+#endif
 
+    // ---- epilogue.  Stores are ISSUE-bound (one dword store per accumulator register = 256 B per wave instruction), so
+    // each 32x32 tile is transposed through a per-wave LDS scratch (pitch 36 floats: 16-byte rows, conflict-free both
+    // ways) and written with dwordx4 stores: lane l holds channels 4(l&7)..+3 of pixel rows (l>>3) + 8k, k = 0..3, i.e.
+    // 8 full 128-byte rows per instruction and 4x fewer store instructions.  Needs Cout % 4 == 0 (all layers but the
+    // 3-channel out_conv, which keeps the scalar stores).
     float colsum[TM][TN], colsq[TM][TN];
+    const bool full = (oy0 + 8 <= p.Ho) && (ox0 + TW <= p.Wo) && (n0 + BN <= p.Cout);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            float ps = 0.f, pss = 0.f;      // this lane's share of the GroupNorm moments of the OUTPUT (column `col`)
+            float ps = 0.f, pss = 0.f;      // this lane's share of the GroupNorm moments of the OUTPUT (its column)
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (ok_l(i, j, r)) {
-                    const float v = acc[i][j][r];
-                    stg_u32(p.out + uoff(i, j, r), loff4, v);
-                    ps += v;
-                    pss = __builtin_fmaf(v, v, pss);
+                for (int r = 0; r < 16; ++r) {
+                    ps += acc[i][j][r];
+                    pss = __builtin_fmaf(acc[i][j][r], acc[i][j][r], pss);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok_l(i, j, r)) {
+                        ps += acc[i][j][r];
+                        pss = __builtin_fmaf(acc[i][j][r], acc[i][j][r], pss);
+                    }
+            }
+            colsum[i][j] = ps;
+            colsq[i][j] = pss;
+        }
+    if ((p.Cout & 3) == 0) {
+        float *T = reinterpret_cast<float *>(smem_u16) + 2048 + wave * (32 * 36);      // 8 KB in: clear of the GN `red` area
+        const int trow = lane >> 3, tq = lane & 7;
+        const unsigned lvec4 = 4u * ((unsigned)trow * (unsigned)p.Cout + 4u * (unsigned)tq);      // bytes
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[i][j][r];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = *reinterpret_cast<const float4 *>(T + (trow + 8 * k) * 36 + 4 * tq);
+                    const int prow = 2 * (wm * TM + i) + (k >> 1), pcol0 = 8 * (k & 1);               // uniform
+                    const bool okv = full || ((oy0 + prow) < p.Ho && (ox0 + pcol0 + trow) < p.Wo && (n0 + (wn * TN + j) * 32 + 4 * tq) < p.Cout);
+                    if (okv) {
+                        float *ub = p.out + obase + (size_t)(prow * p.Wo + pcol0) * p.Cout + (wn * TN + j) * 32;
+                        const unsigned long long a = uniform_u64(reinterpret_cast<unsigned long long>(ub));
+                        *reinterpret_cast<__attribute__((address_space(1))) f32x4 *>(a + lvec4) = f32x4{v.x, v.y, v.z, v.w};
+                    }
                 }
             }
-            if (stats_part) { colsum[i][j] = ps; colsq[i][j] = pss; }
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok_l(i, j, r)) stg_u32(p.out + uoff(i, j, r), loff4, acc[i][j][r]);
+    }
 
     // Optional fused GroupNorm moments of the output (consumed by the NEXT conv's GN prologue): per (tile, group)
     // partial sums, reduced lane -> group (xor shuffles over the cg lanes of a group, then the two row halves) -> waves
     // (LDS) and written as doubles to stats_part[((n*tiles + tile)*32 + g)*2]; a fixed order, so runs are reproducible.
 #ifdef FEMASR_TAPTIME
-    TT_STAMP(12)
+    TT_STAMP_ALWAYS(12)
     tt[10] = tprev - tstart;
-    if (lane == 0)
-        for (int i = 0; i < 13; ++i) atomicAdd(&g_taptime[i], tt[i]);
+    if (lane == 0) {
+        const unsigned slot = (blockIdx.x * (WM * WN) + wave) & 65535u;
+        for (int i = 0; i < 13; ++i) g_taptime[slot * 16 + i] += tt[i];
+    }
 #endif
     if (stats_part) {
         const int cg = p.Cout >> 5;                       // channels per group (32 groups): 8 / 4 / 2
@@ -538,7 +596,9 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.ksz = 3; p.stride = 1; p.pad = 1; p.up2 = a->up2;
     p.Ho = Hv; p.Wo = Wv; p.NT32 = (a->Cout + 31) / 32;
     int cls = a->Cout > 128 ? 3 : (a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2));
-    if (getenv("FEMASR_BF16_CLS")) cls = atoi(getenv("FEMASR_BF16_CLS"));
+#ifdef FEMASR_TAPTIME
+    if (getenv("FEMASR_BF16_CLS")) cls = atoi(getenv("FEMASR_BF16_CLS"));      // debug build only: force a tile class
+#endif
     const int vi = cls * 3 + (a->up2 ? 2 : a->prologue);
     Variant16 &v = g_v16[vi];
     p.tilesX = (p.Wo + 15) / 16;
@@ -546,10 +606,12 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
     p.MB = a->B * p.tilesX * p.tilesY;
     p.NB = (a->Cout + v.bn - 1) / v.bn;
     if (!v.attr_set) {
-        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds + 8 * 1024));
+        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds + 40 * 1024));
         v.attr_set = true;
     }
-    const size_t lds = v.lds + (a->prologue == FEMASR_PRO_GN_SILU ? (size_t)2 * a->Cin * sizeof(float) : 0);
+    size_t lds = v.lds + (a->prologue == FEMASR_PRO_GN_SILU ? (size_t)2 * a->Cin * sizeof(float) : 0);
+    const size_t epi = 8192 + (size_t)(v.threads / 64) * 32 * 36 * sizeof(float);       // epilogue transpose scratch
+    if (lds < epi) lds = epi;
     FEMASR_REQUIRE(!a->gn_part || (a->Cout % 32 == 0 && (a->Cout / 32) <= 8 && v.bn % (a->Cout / 32) == 0),
                    "conv bf16x3: fused GN moments need Cout %% 32 == 0 and <= 8 channels per group");
     hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), lds, s, p, (const uint4 *)a->w_bf16x3,
@@ -563,10 +625,17 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
 #ifdef FEMASR_TAPTIME
 extern "C" int femasr_debug_taptime(unsigned long long *out16, int reset)
 {
-    if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_taptime), sizeof(unsigned long long) * 16);
+    static unsigned long long host[16 * 65536];
+    if (out16) {
+        hipMemcpyFromSymbol(host, HIP_SYMBOL(g_taptime), sizeof(host));
+        for (int i = 0; i < 16; ++i) out16[i] = 0;
+        for (int w = 0; w < 65536; ++w)
+            for (int i = 0; i < 16; ++i) out16[i] += host[w * 16 + i];
+    }
     if (reset) {
-        unsigned long long z[16] = {0};
-        hipMemcpyToSymbol(HIP_SYMBOL(g_taptime), z, sizeof(z));
+        void *d = nullptr;
+        hipGetSymbolAddress(&d, HIP_SYMBOL(g_taptime));
+        hipMemset(d, 0, sizeof(host));
     }
     return 0;
 }

@@ -20,6 +20,9 @@ def main():
     ap.add_argument('--res', action='store_true')
     ap.add_argument('--fp32', action='store_true')
     ap.add_argument('--gn-part', action='store_true')
+    ap.add_argument('--k1', action='store_true', help='1x1 conv / nn.Linear (fp32 igemm path)')
+    ap.add_argument('--ln', action='store_true')
+    ap.add_argument('--gelu', action='store_true')
     ap.add_argument('--iters', type=int, default=10)
     a_ = ap.parse_args()
     b, h, w, cin, cout = a_.dims
@@ -29,16 +32,17 @@ def main():
     torch.manual_seed(0)
     dev = 'cuda'
     x = torch.randn(b, h, w, cin, device=dev)
-    w_oihw = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    ks = 1 if a_.k1 else 3
+    w_oihw = torch.randn(cout, cin, ks, ks, device=dev) * 0.05
     bias = torch.randn(cout, device=dev)
     ho, wo = (2 * h, 2 * w) if a_.up2 else (h, w)
     out = torch.empty(b, ho, wo, cout, device=dev)
-    wp = torch.empty(int(lib.femasr_packed_weight_floats(cout, cin, 3, 3)), device=dev)
-    _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(w_oihw), cout, cin, 3, 3, _lib.ptr(wp)))
+    wp = torch.empty(int(lib.femasr_packed_weight_floats(cout, cin, ks, ks)), device=dev)
+    _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(w_oihw), cout, cin, ks, ks, _lib.ptr(wp)))
     args = _lib.ConvArgs()
     args.in_ = x.data_ptr(); args.B, args.H, args.W, args.Cin = b, h, w, cin
     args.w = wp.data_ptr(); args.bias = bias.data_ptr()
-    args.Cout, args.ksz, args.stride, args.pad, args.up2 = cout, 3, 1, 1, int(a_.up2)
+    args.Cout, args.ksz, args.stride, args.pad, args.up2 = cout, ks, 1, (0 if a_.k1 else 1), int(a_.up2)
     args.out = out.data_ptr(); args.Ho, args.Wo = ho, wo
     keep = []
     if a_.gn:
@@ -46,10 +50,18 @@ def main():
         pb = torch.randn(b, cin, device=dev) * 0.1
         args.prologue = _lib.PRO_GN_SILU; args.pro_a = pa.data_ptr(); args.pro_b = pb.data_ptr()
         keep += [pa, pb]
+    if a_.ln:
+        st = torch.rand(b * h * w, 2, device=dev) + 0.5
+        g_ = torch.rand(cin, device=dev) + 0.5
+        be = torch.randn(cin, device=dev) * 0.1
+        args.prologue = _lib.PRO_LN; args.pro_a = st.data_ptr(); args.pro_b = g_.data_ptr(); args.pro_c = be.data_ptr()
+        keep += [st, g_, be]
+    if a_.gelu:
+        args.act = _lib.ACT_GELU
     if a_.res:
         r = torch.randn(b, ho, wo, cout, device=dev)
         args.res1 = r.data_ptr(); keep.append(r)
-    if not a_.fp32:
+    if not a_.fp32 and not a_.k1:
         ws = torch.empty(int(lib.femasr_packed_weight_bf16x3_bytes(cout, cin, 3, 3)), dtype=torch.uint8, device=dev)
         _lib.check(lib.femasr_repack_oihw_bf16x3(None, _lib.ptr(w_oihw), cout, cin, 3, 3, _lib.ptr(ws)))
         args.w_bf16x3 = ws.data_ptr(); keep.append(ws)
@@ -64,6 +76,7 @@ def main():
     if tt:
         raw = lib._lib if hasattr(lib, '_lib') else lib
         raw.femasr_debug_taptime(None, 1)
+        raw.femasr_debug_igemm_time(None, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a_.iters):
@@ -71,7 +84,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a_.iters
-    fl = 2.0 * b * ho * wo * cout * 9 * cin
+    fl = 2.0 * b * ho * wo * cout * ks * ks * cin
     if tt:
         buf = (ctypes.c_ulonglong * 16)()
         raw.femasr_debug_taptime(buf, 0)
@@ -79,6 +92,9 @@ def main():
         names = ['tap%d' % i for i in range(9)] + ['barrier', 'total', 'prologue', 'epilogue']
         print('  per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(names) if n != 'total'))
         print('  total wave-cycles per launch: %.3e' % (tot / a_.iters))
+        raw.femasr_debug_igemm_time(buf, 0)
+        tot = float(buf[5]) or 1.0
+        print('  igemm per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(['mfma', 'store', 'barrier', 'prologue', 'epilogue'])) + '  total/launch %.3e' % (tot / a_.iters))
     print('conv %s abl=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_ABL', '0'),
                                                                     os.environ.get('FEMASR_BF16_CLS', '-'), ms, fl / ms / 1e9))
 
