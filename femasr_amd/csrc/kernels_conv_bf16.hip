@@ -569,6 +569,12 @@ Variant16 g_v16[] = {
     FEMASR_H16(256, 1, 4, FEMASR_PRO_NONE, false),     // 9   (4 waves: 128 px x 64 ch per wave, one column block for Cout = 256)
     FEMASR_H16(256, 1, 4, FEMASR_PRO_GN_SILU, false),  // 10
     FEMASR_H16(256, 1, 4, FEMASR_PRO_NONE, true),      // 11
+    FEMASR_H16(64, 4, 1, FEMASR_PRO_NONE, false),      // 12  (4 waves: 32 px x 64 ch per wave)
+    FEMASR_H16(64, 4, 1, FEMASR_PRO_GN_SILU, false),   // 13
+    FEMASR_H16(64, 4, 1, FEMASR_PRO_NONE, true),       // 14
+    FEMASR_H16(64, 2, 2, FEMASR_PRO_NONE, false),      // 15  (4 waves: 64 px x 32 ch per wave)
+    FEMASR_H16(64, 2, 2, FEMASR_PRO_GN_SILU, false),   // 16
+    FEMASR_H16(64, 2, 2, FEMASR_PRO_NONE, true),       // 17
 };
 constexpr int kNum16 = sizeof(g_v16) / sizeof(g_v16[0]);
 
@@ -599,7 +605,8 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
 #ifdef FEMASR_TAPTIME
     if (getenv("FEMASR_BF16_CLS")) cls = atoi(getenv("FEMASR_BF16_CLS"));      // debug build only: force a tile class
 #endif
-    const int vi = cls * 3 + (a->up2 ? 2 : a->prologue);
+    // Cout 33..64 uses the 4-wave 64 px x 32 ch tiling (rows 15..17: +2.5 % / +9 % fused-x2 over the 8-wave rows 3..5)
+    const int vi = (cls == 1 ? 15 : cls * 3) + (a->up2 ? 2 : a->prologue);
     Variant16 &v = g_v16[vi];
     p.tilesX = (p.Wo + 15) / 16;
     p.tilesY = (p.Ho + 7) / 8;
