@@ -62,7 +62,7 @@ __device__ unsigned long long g_igemm_time[8 * 65536];     // debug build only: 
 // conv_igemm: implicit GEMM, M = B*Ho*Wo pixels, N = Cout, K chunks of 32
 // =================================================================================================================
 template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ, bool K1>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : (K1 ? 3 : 2)) void conv_igemm_kernel(const ConvParams p)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 128) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p)
 {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
