@@ -432,7 +432,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     static_assert(2 + PUNITS <= BK / 2, "patch slices must fit the 16 k-pair steps of one tap");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int PSZ = ((PP * ALD + 3) / 4) * 4;
+    constexpr int PSZ = (((PP + 1) * ALD + 3) / 4) * 4;      // pixel PP is a write-only dummy slot (tail units)
     float *Ps = smem;               // [2][PP][ALD]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -522,28 +522,40 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         for (int i = 0; i < TM; ++i) py[i] = (m >> 4) + 2 * i;
     }
 
+    // LDS index of this lane's A-fragment pixel for (tap, row tile i): without the fused x2 upsample ONE per-lane base
+    // plus a compile-time constant (folded into the ds_read offset); with it the halving depends on the lane.
+    const int abase = (py[0] * PW + px) * ALD;
+    auto patch_idx = [&](int tap, int (&idx)[TM]) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (UP2) {
+                const int prow = ((py[i] + ky - 1) >> 1) + 1, pcol = ((px + kx - 1) >> 1) + 1;
+                idx[i] = (prow * PW + pcol) * ALD;
+            } else {
+                idx[i] = abase + ((2 * i + ky) * PW + kx) * ALD;
+            }
+        }
+    };
+
+    // Main loop: unconditional straight-line code (9 taps x 16 k-pair steps unrolled; the last channel block re-stages
+    // itself into the idle LDS buffer and re-reads the last weight chunk), so every s_waitcnt the compiler emits is exact.
+    const int nq = ncc * 9;
     for (int cc = 0; cc < ncc; ++cc) {
         const float *Pb = Ps + (cc & 1) * PSZ + (lane >> 5);
-        const bool more_p = cc + 1 < ncc;
-#pragma unroll 1
+        const int ccn = cc + 1 < ncc ? cc + 1 : cc;
+        const int nbuf = (cc + 1) & 1;
+        float af[2][TM];
+        int aidx[TM];
+        patch_idx(0, aidx);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = Pb[aidx[i]];
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int q = cc * 9 + tap;
-            const bool more_w = (q + 1) < ncc * 9;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            int aidx[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int prow = UP2 ? ((py[i] + ky - 1) >> 1) + 1 : py[i] + ky;
-                const int pcol = UP2 ? ((px + kx - 1) >> 1) + 1 : px + kx;
-                aidx[i] = (prow * PW + pcol) * ALD;
-            }
-            // the next channel block's patch is loaded at tap 0 and normalised / activated / stored at tap 1 in slices
-            // that sit between the MFMA k-pair steps (one unit per step), i.e. in the matrix pipe's shadow
-            const bool ld_p = more_p && tap == 0;
-            const bool st_p = more_p && tap == 1;
-            float af[2][TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = Pb[aidx[i]];
+            const size_t qn = (size_t)(q + 1 < nq ? q + 1 : nq - 1);
+            int nidx[TM];
+            patch_idx(tap < 8 ? tap + 1 : 8, nidx);
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
                 const int cur = kk & 1, nxt = cur ^ 1, g = kk >> 2, e = kk & 3;
@@ -551,14 +563,20 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
                     if (g < 3) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)q * wstride + 4 * (g + 1));
-                    } else if (more_w) {
+                    } else {
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)(q + 1) * wstride);
+                        for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + qn * wstride);
                     }
+                    // next channel block's patch: issued right AFTER a weight prefetch (loads complete in order; see
+                    // conv_igemm_kernel), normalised / activated / stored one unit per k-pair step of tap 1
+                    if (tap == 0 && kk == 0) load_patch(ccn);
                 }
                 if (kk + 1 < BK / 2) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[nxt][i] = Pb[aidx[i] + 2 * (kk + 1)];
+                } else if (tap < 8) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[nxt][i] = Pb[nidx[i]];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -570,10 +588,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bc[j] = bn[j];
                 }
-                if (kk == 1 && ld_p) load_patch(cc + 1);
-                if (kk >= 2 && kk < 2 + PUNITS && st_p) store_patch_unit((cc + 1) & 1, kk - 2);
+                if (tap == 1 && kk >= 2 && kk < 2 + PUNITS) store_patch_unit(nbuf, kk - 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) aidx[i] = nidx[i];
         }
         __syncthreads();     // patch buffers swap: ONE barrier per 32-channel block (9 taps x 16 MFMA steps)
     }
@@ -644,7 +663,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 template <bool UP2>
 constexpr size_t halo_lds_bytes()
 {
-    return (size_t)(2 * ((((UP2 ? 60 : 180) * ALD + 3) / 4) * 4)) * sizeof(float);
+    return (size_t)(2 * (((((UP2 ? 60 : 180) + 1) * ALD + 3) / 4) * 4)) * sizeof(float);
 }
 
 template <int BM>
