@@ -719,6 +719,9 @@ Variant g_variants[] = {
     FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, false),                   // 30 4-wave halo blocks: 64 px x 64 ch per wave
     FEMASR_HALO(128, 2, 2, FEMASR_PRO_GN_SILU, false),                // 31
     FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, true),                    // 32
+    FEMASR_HALO(64, 2, 2, FEMASR_PRO_NONE, false),                    // 33 (64 px x 32 ch per wave)
+    FEMASR_HALO(64, 2, 2, FEMASR_PRO_GN_SILU, false),                 // 34
+    FEMASR_HALO(64, 2, 2, FEMASR_PRO_NONE, true),                     // 35
 };
 constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
 
@@ -737,6 +740,7 @@ int pick_variant(const femasr_conv_args *a, bool vq)
     // Cout > 64: 4-wave halo blocks (64 px x 64 ch per wave: half the LDS / weight-fragment reads per MFMA, 4 waves per
     // barrier instead of 8; measured +4..9 % over the 8-wave tiling, fused-x2 variant 141 TFLOP/s = 90 % of peak)
     if (use_halo(a, vq) && cls == 0) return 30 + (a->up2 ? 2 : a->prologue);
+    if (use_halo(a, vq) && cls == 1) return 33 + (a->up2 ? 2 : a->prologue);        // 64 px x 32 ch per wave: +4..8 %
     if (use_halo(a, vq)) return 13 + cls * 3 + (a->up2 ? 2 : a->prologue);
     if (!vec) return 9 + cls;
     const bool k1 = a->ksz == 1 && a->stride == 1 && a->pad == 0 && !a->up2 && a->prologue != FEMASR_PRO_GN_SILU;
@@ -782,7 +786,7 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     Variant &v = g_variants[vi];
     p.MB = (p.M + v.bm - 1) / v.bm;
     p.NB = (p.Cout + v.bn - 1) / v.bn;
-    if ((vi >= 13 && vi <= 21) || (vi >= 30 && vi <= 32)) {   // halo kernels: 2-D tiles of 8 x 16 output pixels per image
+    if ((vi >= 13 && vi <= 21) || (vi >= 30 && vi <= 35)) {   // halo kernels: 2-D tiles of 8 x 16 output pixels per image
         p.tilesX = (Wo + 15) / 16;
         p.tilesY = (Ho + 7) / 8;
         p.MB = a->B * p.tilesX * p.tilesY;
