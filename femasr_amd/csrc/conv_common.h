@@ -42,6 +42,20 @@ __device__ __forceinline__ void stg_u32(float *ubase, unsigned byteoff, float v)
     *reinterpret_cast<gptr_f32>(a + byteoff) = v;
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t ldg4_u32(const float *ubase, unsigned byteoff)
+{
+    const unsigned long long a = uniform_u64(reinterpret_cast<unsigned long long>(ubase));
+    return *reinterpret_cast<__attribute__((address_space(1))) const f32x4_t *>(a + byteoff);
+}
+__device__ __forceinline__ void stg4_u32(float *ubase, unsigned byteoff, f32x4_t v)
+{
+    const unsigned long long a = uniform_u64(reinterpret_cast<unsigned long long>(ubase));
+    *reinterpret_cast<__attribute__((address_space(1))) f32x4_t *>(a + byteoff) = v;
+}
+constexpr int TPITCH = 36;                   // epilogue transpose scratch: 32 rows x 36 floats per wave (16-byte rows)
+constexpr int TSCRATCH = 32 * TPITCH;        // floats per wave
+
 __device__ __forceinline__ float f4get(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk)

@@ -41,6 +41,8 @@ namespace {
 // C/D layout of a 32x32 MFMA tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 
 #ifdef FEMASR_TAPTIME
+__constant__ int g_dbg_flags;       // debug build only: ablation switches for the igemm main loop (1 barrier, 2 LDS staging, 4 A loads, 8 weights)
+#define DBG_ON(bit) (g_dbg_flags & (bit))
 __device__ unsigned long long g_igemm_time[8 * 65536];     // debug build only: per-wave cycle sums (mfma, store, barrier, prologue, epilogue, total)
 #define IT_STAMP_ALWAYS(slot)                                       \
     {                                                                \
@@ -56,6 +58,7 @@ __device__ unsigned long long g_igemm_time[8 * 65536];     // debug build only: 
 #else
 #define IT_STAMP(slot) {}
 #define IT_STAMP_ALWAYS(slot) {}
+#define DBG_ON(bit) false
 #endif
 
 // =================================================================================================================
@@ -261,7 +264,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1, g = kk >> 2, e = kk & 3;
             if (e == 0) {       // prefetch the next 4 k-pairs of weight fragments (next chunk's first 4 at the end)
-                if (g < 3) {
+                if (DBG_ON(8)) {
+                } else if (g < 3) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)c * wstride + 4 * (g + 1));
                 } else {
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
                 // next chunk's A rows: issued right AFTER a weight prefetch.  Loads complete in order, so the first
                 // younger weight load that is waited for (two prefetch groups = 16 MFMAs later) also waits for these
                 // HBM loads; issued before the prefetch they would only get 8 MFMAs of cover.
-                if (kk == 0) load_chunk(cn);
+                if (kk == 0 && !DBG_ON(4)) load_chunk(cn);
             }
             if (kk + 1 < BK / 2) {
 #pragma unroll
@@ -290,9 +294,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
             __builtin_amdgcn_sched_barrier(0);
         }
         IT_STAMP(0)
-        store_chunk(buf ^ 1);
+        if (!DBG_ON(2)) store_chunk(buf ^ 1);
         IT_STAMP(1)
-        __syncthreads();
+        if (!DBG_ON(1)) __syncthreads();
         IT_STAMP(2)
     }
 #if defined(FEMASR_TAPTIME) && FEMASR_TAPTIME < 2
@@ -353,10 +357,57 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
                 if (NRES > 0 && DEPTH == 1 && tl + 1 < TM * TN) issue(tl + 1, 0);
             }
         };
+        // Full tiles with Cout % 4 == 0 (every nn.Linear): stores are ISSUE-bound (a dword store per accumulator register
+        // moves 256 B per wave instruction; the K = 256 linears write 64 KB per 16k MFMA-cycles of work), so each 32x32 tile
+        // is transposed through a per-wave LDS scratch and bias / GELU / residuals / store run on float4 rows: lane l owns
+        // columns 4(l&7)..+3 of tile rows (l>>3) + 8k.  Same per-element arithmetic and order, 4x fewer memory instructions.
+        constexpr bool VEC_FITS = (WM * WN * TSCRATCH) <= (2 * BM * ALD);
+        auto epilogue_vec = [&](auto nres_c) {
+            constexpr int NRES = decltype(nres_c)::value;
+            constexpr int DEPTH = NRES == 1 ? 2 : 1;
+            float *T = smem + wave * TSCRATCH;           // the A buffers are dead after the loop's last barrier
+            const int trow = lane >> 3, tq = lane & 7;
+            const unsigned lvec = 4u * ((unsigned)trow * (unsigned)p.Cout + 4u * (unsigned)tq);     // bytes
+            auto urow = [&](int i, int j, int k) -> size_t {       // uniform: tile row 8k, tile column 0
+                return (size_t)(m0 + (wm * TM + i) * 32 + 8 * k) * p.Cout + (n0 + (wn * TN + j) * 32);
+            };
+            f32x4_t rbuf[DEPTH][NRES > 0 ? NRES : 1][4];
+            auto issue = [&](int tl, int slot) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (NRES >= 1) rbuf[slot][0][k] = ldg4_u32(ra + urow(tl / TN, tl % TN, k), lvec);
+                    if (NRES >= 2) rbuf[slot][NRES >= 2 ? 1 : 0][k] = ldg4_u32(rb + urow(tl / TN, tl % TN, k), lvec);
+                }
+            };
+            if (NRES > 0) issue(0, 0);
+#pragma unroll
+            for (int tl = 0; tl < TM * TN; ++tl) {
+                const int i = tl / TN, j = tl % TN;
+                if (DEPTH == 2 && tl + 1 < TM * TN) issue(tl + 1, (tl + 1) & 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TPITCH + (lane & 31)] = acc[i][j][r];
+                const f32x4_t b4 = ldg4_u32(p.bias + n0 + (wn * TN + j) * 32, 16u * (unsigned)tq);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 a4 = *reinterpret_cast<const float4 *>(T + (trow + 8 * k) * TPITCH + 4 * tq);
+                    float v[4] = {a4.x + b4[0], a4.y + b4[1], a4.z + b4[2], a4.w + b4[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (p.act == FEMASR_ACT_GELU) v[e] = det_gelu(v[e]);
+                        if (NRES >= 1) v[e] = v[e] + rbuf[tl % DEPTH][0][k][e];
+                        if (NRES >= 2) v[e] = v[e] + rbuf[tl % DEPTH][NRES >= 2 ? 1 : 0][k][e];
+                    }
+                    stg4_u32(p.out + urow(i, j, k), lvec, f32x4_t{v[0], v[1], v[2], v[3]});
+                }
+                if (NRES > 0 && DEPTH == 1 && tl + 1 < TM * TN) issue(tl + 1, 0);
+            }
+        };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
-        if (rb) { if (full) epilogue(I2{}, std::true_type{}); else epilogue(I2{}, std::false_type{}); }
+        if (VEC_FITS && full && (p.Cout & 3) == 0) {
+            if (rb) epilogue_vec(I2{}); else if (ra) epilogue_vec(I1{}); else epilogue_vec(I0{});
+        } else if (rb) { if (full) epilogue(I2{}, std::true_type{}); else epilogue(I2{}, std::false_type{}); }
         else if (ra) { if (full) epilogue(I1{}, std::true_type{}); else epilogue(I1{}, std::false_type{}); }
         else { if (full) epilogue(I0{}, std::true_type{}); else epilogue(I0{}, std::false_type{}); }
     } else {
@@ -807,6 +858,11 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
 }
 
 #ifdef FEMASR_TAPTIME
+extern "C" int femasr_debug_set_flags(int flags)
+{
+    hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_flags), &flags, sizeof(int));
+    return 0;
+}
 extern "C" int femasr_debug_igemm_time(unsigned long long *out8, int reset)
 {
     static unsigned long long host[8 * 65536];
