@@ -145,6 +145,39 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restri
     }
 }
 
+// Finalise from the per-tile partial moments of the bf16x3 conv epilogue (tolerance-based path: the summation order is
+// free but FIXED, so runs are reproducible).  One wave per (image, group): lane l adds tiles l, l+64, ... then an xor
+// tree - the sequential version above takes 320 us on the 2592-tile 576^2 layers, this one a few us.
+__global__ __launch_bounds__(64) void gn_finalize_partials_kernel(const double *__restrict__ part, int tiles, int H, int W, int C, int G,
+                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                  float eps, float *__restrict__ a, float *__restrict__ b)
+{
+    const int n = blockIdx.x / G, g = blockIdx.x % G, lane = threadIdx.x, cg = C / G;
+    const double *src = part + ((size_t)n * tiles * G + g) * 2;
+    double S = 0.0, SS = 0.0;
+    for (int t = lane; t < tiles; t += 64) {
+        S += src[(size_t)t * G * 2];
+        SS += src[(size_t)t * G * 2 + 1];
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        S += __shfl_xor(S, sft, 64);
+        SS += __shfl_xor(SS, sft, 64);
+    }
+    const double N = (double)H * (double)W * (double)cg;
+    const double mean = S / N;
+    double var = SS / N - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = 1.0f / sqrtf((float)var + eps);
+    const float meanf = (float)mean;
+    if (lane < cg) {
+        const int c = g * cg + lane;
+        const float ac = rstd * gamma[c];
+        a[n * C + c] = ac;
+        b[n * C + c] = __builtin_fmaf(-meanf, ac, beta[c]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // LayerNorm moments (network_swinir.py:199,205): one wave per row of C = 64*PER floats
 // ------------------------------------------------------------------------------------------
@@ -485,8 +518,9 @@ int femasr_gn_coeffs_from_partials(void *stream, const double *part, int B, int 
 {
     FEMASR_REQUIRE(part && gamma && beta && a && b && B > 0 && tiles > 0 && H > 0 && W > 0, "gn_coeffs_from_partials: bad args");
     FEMASR_REQUIRE(G == 32 && C % G == 0, "gn_coeffs_from_partials: 32 groups");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), (size_t)GN_SLAB * G * 2 * sizeof(double),
-                       (hipStream_t)stream, part, B, tiles, H, W, C, G, gamma, beta, eps, a, b);
+    FEMASR_REQUIRE(C / G <= 64, "gn_coeffs_from_partials: at most 64 channels per group");
+    hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3((unsigned)(B * G)), dim3(64), 0, (hipStream_t)stream, part, tiles, H, W, C,
+                       G, gamma, beta, eps, a, b);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }
