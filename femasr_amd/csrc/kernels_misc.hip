@@ -223,11 +223,17 @@ __global__ void ln_stats_kernel(const float *__restrict__ x, long long rows, flo
 // label test; softmax and both products follow the oracle's sequential orders.
 constexpr int ATT_HD = 32, ATT_N = 64, ATT_LD = 36;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed-fp32 formulation (v_pk_fma_f32: two IEEE fmas per instruction, same rounding as two scalar fmaf):
+//   q.k^T: two KEYS per instruction (K is staged pair-interleaved [j/2][d][j&1]; each score is still ONE fmaf chain over
+//   d = 0..31 from +0), p.V: two output CHANNELS per instruction (each o[d] is still one chain over j = 0..63).
+// The arithmetic per element and its order are unchanged, so the result stays bit-identical to the oracle.
 __global__ __launch_bounds__(64) void window_attention_kernel(const float *__restrict__ qkv, int B, int H, int W, int C,
                                                               int heads, int shift, const float *__restrict__ table,
                                                               float *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) float Ks[ATT_N * ATT_LD];
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_N * ATT_HD];          // [j/2][d][2]
     __shared__ __attribute__((aligned(16))) float Vs[ATT_N * ATT_LD];
     __shared__ float Ts[225];
     __shared__ int Ls[ATT_N];
@@ -257,6 +263,7 @@ __global__ __launch_bounds__(64) void window_attention_kernel(const float *__res
     const float *base = qkv + tok * 3 * C + h * ATT_HD;
     const float scale = 0.17677669529663687f;   // (float)(32 ** -0.5)
     float q[ATT_HD];
+    float *kdst = Ks + (lane >> 1) * (2 * ATT_HD) + (lane & 1);
 #pragma unroll
     for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
         const float4 qv = ld4(base + 4 * d4);
@@ -264,29 +271,43 @@ __global__ __launch_bounds__(64) void window_attention_kernel(const float *__res
         q[4 * d4 + 1] = qv.y * scale;
         q[4 * d4 + 2] = qv.z * scale;
         q[4 * d4 + 3] = qv.w * scale;
-        *reinterpret_cast<float4 *>(Ks + lane * ATT_LD + 4 * d4) = ld4(base + C + 4 * d4);
+        const float4 kv = ld4(base + C + 4 * d4);
+        kdst[(4 * d4 + 0) * 2] = kv.x;
+        kdst[(4 * d4 + 1) * 2] = kv.y;
+        kdst[(4 * d4 + 2) * 2] = kv.z;
+        kdst[(4 * d4 + 3) * 2] = kv.w;
         *reinterpret_cast<float4 *>(Vs + lane * ATT_LD + 4 * d4) = ld4(base + 2 * C + 4 * d4);
     }
     __syncthreads();
 
     float s[ATT_N];
     float m = -INFINITY;
+    // four key pairs (8 scores) at a time: four independent fmaf chains and four LDS reads in flight per step
 #pragma unroll
-    for (int j = 0; j < ATT_N; ++j) {
-        float acc = 0.f;
+    for (int jq = 0; jq < ATT_N / 8; ++jq) {
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-        for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
-            const float4 kv = *reinterpret_cast<const float4 *>(Ks + j * ATT_LD + 4 * d4);
-            acc = __builtin_fmaf(q[4 * d4 + 0], kv.x, acc);
-            acc = __builtin_fmaf(q[4 * d4 + 1], kv.y, acc);
-            acc = __builtin_fmaf(q[4 * d4 + 2], kv.z, acc);
-            acc = __builtin_fmaf(q[4 * d4 + 3], kv.w, acc);
+        for (int d2 = 0; d2 < ATT_HD / 2; ++d2) {
+            float4 kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)      // (k_j[d], k_j+1[d], k_j[d+1], k_j+1[d+1])
+                kk[u] = *reinterpret_cast<const float4 *>(Ks + (4 * jq + u) * (2 * ATT_HD) + 4 * d2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_elementwise_fma(f32x2{q[2 * d2], q[2 * d2]}, f32x2{kk[u].x, kk[u].y}, acc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                acc[u] = __builtin_elementwise_fma(f32x2{q[2 * d2 + 1], q[2 * d2 + 1]}, f32x2{kk[u].z, kk[u].w}, acc[u]);
         }
-        const int dy = iy - (j >> 3) + 7, dx = ix - (j & 7) + 7;
-        acc = acc + Ts[dy * 15 + dx];
-        if (shift > 0) acc = acc + (Ls[j] != mylab ? -100.0f : 0.0f);
-        s[j] = acc;
-        m = acc > m ? acc : m;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = 8 * jq + u;
+            float a1 = acc[u >> 1][u & 1];
+            const int dy = iy - (j >> 3) + 7, dx = ix - (j & 7) + 7;
+            a1 = a1 + Ts[dy * 15 + dx];
+            if (shift > 0) a1 = a1 + (Ls[j] != mylab ? -100.0f : 0.0f);
+            s[j] = a1;
+            m = a1 > m ? a1 : m;
+        }
     }
     float sum = 0.f;
 #pragma unroll
@@ -294,25 +315,26 @@ __global__ __launch_bounds__(64) void window_attention_kernel(const float *__res
         s[j] = det_expf(s[j] - m);
         sum = sum + s[j];
     }
-    float o[ATT_HD];
+    f32x2 o[ATT_HD / 2];
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) o[d] = 0.f;
+    for (int d = 0; d < ATT_HD / 2; ++d) o[d] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < ATT_N; ++j) {
         const float pj = s[j] / sum;
+        const f32x2 pp = {pj, pj};
+        float4 vv[ATT_HD / 4];
+#pragma unroll
+        for (int d4 = 0; d4 < ATT_HD / 4; ++d4) vv[d4] = *reinterpret_cast<const float4 *>(Vs + j * ATT_LD + 4 * d4);
 #pragma unroll
         for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
-            const float4 vv = *reinterpret_cast<const float4 *>(Vs + j * ATT_LD + 4 * d4);
-            o[4 * d4 + 0] = __builtin_fmaf(pj, vv.x, o[4 * d4 + 0]);
-            o[4 * d4 + 1] = __builtin_fmaf(pj, vv.y, o[4 * d4 + 1]);
-            o[4 * d4 + 2] = __builtin_fmaf(pj, vv.z, o[4 * d4 + 2]);
-            o[4 * d4 + 3] = __builtin_fmaf(pj, vv.w, o[4 * d4 + 3]);
+            o[2 * d4] = __builtin_elementwise_fma(pp, f32x2{vv[d4].x, vv[d4].y}, o[2 * d4]);
+            o[2 * d4 + 1] = __builtin_elementwise_fma(pp, f32x2{vv[d4].z, vv[d4].w}, o[2 * d4 + 1]);
         }
     }
     float *op = out + tok * C + h * ATT_HD;
 #pragma unroll
     for (int d4 = 0; d4 < ATT_HD / 4; ++d4)
-        *reinterpret_cast<float4 *>(op + 4 * d4) = make_float4(o[4 * d4], o[4 * d4 + 1], o[4 * d4 + 2], o[4 * d4 + 3]);
+        *reinterpret_cast<float4 *>(op + 4 * d4) = make_float4(o[2 * d4][0], o[2 * d4][1], o[2 * d4 + 1][0], o[2 * d4 + 1][1]);
 }
 
 // ------------------------------------------------------------------------------------------
