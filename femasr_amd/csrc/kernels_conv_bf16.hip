@@ -41,9 +41,12 @@ __device__ unsigned long long g_taptime[16 * 65536];     // [wave slot][16], pla
 #else
 #define TT_STAMP(slot) {}
 #endif
+__constant__ int g_dbg16_flags;     // debug build only: 1 = skip the prologue's residual loads, 2 = skip its first patch loads
+#define DBG16_ON(bit) (g_dbg16_flags & (bit))
 #else
 #define TT_STAMP(slot) {}
 #define TT_STAMP_ALWAYS(slot) {}
+#define DBG16_ON(bit) false
 #endif
 
 namespace {
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     };
     f32x16 acc[TM][TN];
     const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
-    if (ra) {
+    if (ra && !DBG16_ON(1)) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     const size_t wstride = (size_t)p.NT32 << 8;     // uint4 per K chunk
 
     const int ncc = p.Cin / BK;
-    load_patch(0, 0);
+    if (!DBG16_ON(2)) load_patch(0, 0);
     uint4 bc[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     if (PRO == FEMASR_PRO_GN_SILU) __syncthreads();     // gco visible
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        if (g > 0) load_patch(0, g);
+        if (g > 0 && !DBG16_ON(2)) load_patch(0, g);
 #pragma unroll
         for (int i = 0; i < GS; ++i)
             if (g * GS + i < PUNITS) store_patch_unit(0, g * GS + i, 0);
@@ -630,6 +633,11 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
 }
 
 #ifdef FEMASR_TAPTIME
+extern "C" int femasr_debug_set_flags16(int flags)
+{
+    hipMemcpyToSymbol(HIP_SYMBOL(g_dbg16_flags), &flags, sizeof(int));
+    return 0;
+}
 extern "C" int femasr_debug_taptime(unsigned long long *out16, int reset)
 {
     static unsigned long long host[16 * 65536];

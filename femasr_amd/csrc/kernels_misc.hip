@@ -5,6 +5,7 @@
 // kernel here is bit-reproducible and bit-identical to the CPU restatement.
 #include "common.h"
 #include "detmath.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -338,6 +339,168 @@ __global__ __launch_bounds__(64) void window_attention_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------------------------------
+// Window attention on the matrix cores (same arithmetic as window_attention_kernel, bit for bit):
+//   S = (q*scale) K^T  : 2x2 tiles of v_mfma_f32_32x32x2_f32, 16 steps each; step s multiplies d = 2s, 2s+1, i.e. each score
+//                        is the one fmaf chain over d = 0..31 from +0 that the VALU kernel (and the oracle) computes;
+//   S -> LDS -> one ROW per lane: + relative-position bias, + shift mask, sequential max / exp / sum / divide exactly as
+//                        before (the softmax order is per row, so it needs the row in one lane);
+//   O = P V            : 2 tiles x 32 steps; step s multiplies j = 2s, 2s+1: each o[d] is one chain over j = 0..63.
+// One wave per (window, head).  The VALU kernel is bound by the LDS pipe (1040 broadcast ds_read_b128 per wave); here the
+// fragment traffic is 224 ds_read_b32 per wave and the dot products leave the VALU.
+// LDS per wave: Q|K (pitch 33) later re-used for S / P (pitch 68 / 65) and the O transpose, + the bias table: 18.6 KB.
+// ------------------------------------------------------------------------------------------
+typedef float att_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int ATT_QK = 2 * ATT_N * 33;            // floats: Q and K images
+constexpr int ATT_SP = ATT_N * 68;                // floats: score / probability image (>= ATT_QK)
+__global__ __launch_bounds__(64) void window_attention_mfma_kernel(const float *__restrict__ qkv, int B, int H, int W, int C,
+                                                                   int heads, int shift, const float *__restrict__ table,
+                                                                   float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float QKs[ATT_SP > ATT_QK ? ATT_SP : ATT_QK];
+    __shared__ float Ts[225];
+    __shared__ int Ls[ATT_N];
+
+    const int lane = threadIdx.x;
+    const int nwx = W >> 3, nwy = H >> 3;
+    int bid = blockIdx.x;
+    const int h = bid % heads;
+    bid /= heads;
+    const int wx = bid % nwx;
+    bid /= nwx;
+    const int wy = bid % nwy;
+    const int n = bid / nwy;
+
+    const int iy = lane >> 3, ix = lane & 7;
+    const int ys = wy * 8 + iy, xs = wx * 8 + ix;
+    int y = ys + shift, x = xs + shift;
+    if (y >= H) y -= H;
+    if (x >= W) x -= W;
+    const size_t tok = (size_t)n * H * W + (size_t)y * W + x;
+    const int ry = ys < H - 8 ? 0 : (ys < H - shift ? 1 : 2);
+    const int rx = xs < W - 8 ? 0 : (xs < W - shift ? 1 : 2);
+    const int mylab = 3 * ry + rx;
+    Ls[lane] = mylab;
+    for (int i = lane; i < 225; i += 64) Ts[i] = table[i * heads + h];
+
+    const float *base = qkv + tok * 3 * C + h * ATT_HD;
+    const float scale = 0.17677669529663687f;   // (float)(32 ** -0.5)
+    float *Qs = QKs, *Ks = QKs + ATT_N * 33;
+#pragma unroll
+    for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
+        const float4 qv = ld4(base + 4 * d4), kv = ld4(base + C + 4 * d4);
+        float *qd = Qs + lane * 33 + 4 * d4, *kd = Ks + lane * 33 + 4 * d4;
+        qd[0] = qv.x * scale; qd[1] = qv.y * scale; qd[2] = qv.z * scale; qd[3] = qv.w * scale;
+        kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    }
+    // V never touches LDS: its B fragments B[kk][d] = V[j = 2s + (lane>>5)][d = lane&31] are read straight from global
+    // (each half-wave reads one token's 128 contiguous bytes) NOW and consumed in the last phase, so 8 KB per wave stay
+    // in flight across the score and softmax phases (the kernel is HBM-latency bound: more bytes in flight is the lever).
+    float vf[ATT_N / 2];
+    {
+        const float *img = qkv + (size_t)n * H * W * 3 * C + 2 * C + h * ATT_HD + (lane & 31);
+#pragma unroll
+        for (int st = 0; st < ATT_N / 2; ++st) {
+            const int j = 2 * st + (lane >> 5);
+            int yy = wy * 8 + (j >> 3) + shift, xx = wx * 8 + (j & 7) + shift;
+            if (yy >= H) yy -= H;
+            if (xx >= W) xx -= W;
+            vf[st] = img[((size_t)yy * W + xx) * 3 * C];
+        }
+    }
+    __syncthreads();
+
+    // ---- S = Qs K^T on the matrix pipe: A[i][kk] = Qs[32 ti + (lane&31)][2s + (lane>>5)], B[kk][j] = K[32 tj + (lane&31)][2s + (lane>>5)]
+    const int frow = (lane & 31) * 33 + (lane >> 5);
+    att_f32x16 sc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[ti][tj][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < ATT_HD / 2; ++st) {
+        float af[2], bf[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            af[u] = Qs[u * 32 * 33 + frow + 2 * st];
+            bf[u] = Ks[u * 32 * 33 + frow + 2 * st];
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) sc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ti], bf[tj], sc[ti][tj], 0, 0, 0);
+    }
+    __syncthreads();          // every lane is done with Q / K: their LDS is re-used for the score image
+    float *Ss = QKs;          // [i][68]
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ss[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 68 + 32 * tj + (lane & 31)] = sc[ti][tj][r];
+    __syncthreads();
+
+    // ---- row phase: lane = query i, exactly the VALU kernel's arithmetic
+    float s[ATT_N];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j4 = 0; j4 < ATT_N / 4; ++j4) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(Ss + lane * 68 + 4 * j4);
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = 4 * j4 + u;
+            float a1 = vv[u];
+            const int dy = iy - (j >> 3) + 7, dx = ix - (j & 7) + 7;
+            a1 = a1 + Ts[dy * 15 + dx];
+            if (shift > 0) a1 = a1 + (Ls[j] != mylab ? -100.0f : 0.0f);
+            s[j] = a1;
+            m = a1 > m ? a1 : m;
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < ATT_N; ++j) {
+        s[j] = det_expf(s[j] - m);
+        sum = sum + s[j];
+    }
+    __syncthreads();          // all rows read: the image is re-used for P, pitch 65 (conflict-free fragment reads)
+    float *Ps = QKs;
+#pragma unroll
+    for (int j = 0; j < ATT_N; ++j) Ps[lane * 65 + j] = s[j] / sum;
+    __syncthreads();
+
+    // ---- O = P V: A[i][kk] = P[32 ti + (lane&31)][2s + (lane>>5)], B[kk][d] = V[2s + (lane>>5)][d = lane&31]
+    att_f32x16 oc[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oc[ti][r] = 0.f;
+    const int prow = (lane & 31) * 65 + (lane >> 5);
+#pragma unroll
+    for (int st = 0; st < ATT_N / 2; ++st) {
+        const float b = vf[st];
+        const float a0 = Ps[prow + 2 * st], a1 = Ps[32 * 65 + prow + 2 * st];
+        oc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, oc[0], 0, 0, 0);
+        oc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, oc[1], 0, 0, 0);
+    }
+    __syncthreads();          // P is dead: transpose O back to one row per lane through the same LDS (pitch 36)
+    float *Os = QKs;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Os[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = oc[ti][r];
+    __syncthreads();
+    float *op = out + tok * C + h * ATT_HD;
+#pragma unroll
+    for (int d4 = 0; d4 < ATT_HD / 4; ++d4)
+        *reinterpret_cast<float4 *>(op + 4 * d4) = *reinterpret_cast<const float4 *>(Os + lane * 36 + 4 * d4);
+}
+
+
+// ------------------------------------------------------------------------------------------
 // VQ helpers (femasr_arch.py:35-38,63-66,81-82,95,100,102-112)
 // ------------------------------------------------------------------------------------------
 // |row|^2 as ONE fmaf chain, c ascending; thread per row, float4 loads.
@@ -565,8 +728,13 @@ int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W,
     FEMASR_REQUIRE(heads > 0 && C == heads * ATT_HD, "window_attention: head_dim must be 32 (C=%d heads=%d)", C, heads);
     FEMASR_REQUIRE(shift >= 0 && shift < 8, "window_attention: bad shift %d", shift);
     const unsigned grid = (unsigned)((size_t)B * (H / 8) * (W / 8) * heads);
-    hipLaunchKernelGGL(window_attention_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads, shift,
-                       table, out);
+    static const bool valu = getenv("FEMASR_ATTENTION_VALU") != nullptr;      // the VALU formulation is kept for A/B runs
+    if (valu)
+        hipLaunchKernelGGL(window_attention_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads, shift,
+                           table, out);
+    else
+        hipLaunchKernelGGL(window_attention_mfma_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads,
+                           shift, table, out);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

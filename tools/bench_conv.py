@@ -77,6 +77,7 @@ def main():
         raw = lib._lib if hasattr(lib, '_lib') else lib
         raw.femasr_debug_taptime(None, 1)
         raw.femasr_debug_set_flags(int(os.environ.get('FEMASR_DBG', '0')))
+        raw.femasr_debug_set_flags16(int(os.environ.get('FEMASR_DBG16', '0')))
         raw.femasr_debug_igemm_time(None, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -96,7 +97,7 @@ def main():
         raw.femasr_debug_igemm_time(buf, 0)
         tot = float(buf[5]) or 1.0
         print('  igemm per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(['mfma', 'store', 'barrier', 'prologue', 'epilogue'])) + '  total/launch %.3e' % (tot / a_.iters))
-    print('conv %s dbg=%s abl=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_DBG', '0'), os.environ.get('FEMASR_ABL', '0'),
+    print('conv %s dbg=%s abl=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_DBG', '0') + '/' + os.environ.get('FEMASR_DBG16', '0'), os.environ.get('FEMASR_ABL', '0'),
                                                                     os.environ.get('FEMASR_BF16_CLS', '-'), ms, fl / ms / 1e9))
 
 
