@@ -70,7 +70,7 @@ __device__ __forceinline__ float fast_silu(float t)
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 &v) { return __builtin_bit_cast(bf16x8, v); }
 
 template <int BN, int WM, int WN, int PRO, bool UP2>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_halo_bf16x3_kernel(const ConvParams p, const uint4 *__restrict__ wsplit,
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || (BN <= 64 && !UP2)) ? 4 : 2) void conv3x3_halo_bf16x3_kernel(const ConvParams p, const uint4 *__restrict__ wsplit,
                                                                                           double *__restrict__ stats_part)
 {
     constexpr int BM = 128, TW = 16, NT = WM * WN * 64;
@@ -84,6 +84,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     // and whole-patch staging registers of the smaller tiles: A fragments rotate through ONE hi and ONE lo set (lo(s)
     // is fetched under the two hi terms, hi(s+1) under the lo term) and the next patch is staged in two halves.
     constexpr bool ROT = TM * TN >= 8;
+    // SB: single-buffered patch for the narrow layers (Cout <= 64: the 288^2 / 576^2 decoder end).  They are HBM-side with
+    // only 2-4 channel blocks per tile; halving the LDS footprint doubles the resident blocks (4 per CU) and with them the
+    // bytes in flight, which matters more there than overlapping the patch stores with this block's own MFMAs.
+    constexpr bool SB = BN <= 64 && !UP2;
+    static_assert(!(SB && ROT), "single-buffered patch is for the narrow tilings");
     constexpr int NG = ROT ? 3 : 1, GS = (PUNITS + NG - 1) / NG;      // patch units are loaded / stored in NG groups of GS
 
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_u16[];
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 
     // GroupNorm coefficients of this sample: staged once in LDS behind the patch buffers ([2][Cin] floats), read back per
     // unit at store time (no per-channel-block global loads in the main loop, no registers held across taps)
-    float *gco = reinterpret_cast<float *>(smem_u16 + 4 * HALF);
+    float *gco = reinterpret_cast<float *>(smem_u16 + (SB ? 2 : 4) * HALF);
     if (PRO == FEMASR_PRO_GN_SILU) {
         for (int c = t; c < p.Cin; c += NT) {
             gco[c] = p.pro_a[(size_t)n * p.Cin + c];
@@ -267,9 +272,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         }
     TT_STAMP_ALWAYS(11)
     for (int cc = 0; cc < ncc; ++cc) {
-        const unsigned short *Pb = Ps + ((cc & 1) * 2) * HALF + koff;
+        const unsigned short *Pb = Ps + (SB ? 0 : ((cc & 1) * 2) * HALF) + koff;
         const int ccn = cc + 1 < ncc ? cc + 1 : cc;
-        const int nbuf = (cc + 1) & 1;
+        const int nbuf = SB ? 0 : (cc + 1) & 1;
         if constexpr (ROT) {
             uint4 a_hi[TM], a_lo[TM];
             int aidx[TM], nidx[TM];
@@ -391,7 +396,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
                 for (int i = 0; i < TM; ++i) aidx[i] = nidx[i];
                 // next channel block's patch: loaded at tap 0, one unit normalised / split / stored per tap over the LAST
                 // PUNITS taps (bf16 taps are ~5x shorter than fp32 ones: the HBM latency needs the distance)
-                if (tap >= 9 - PUNITS) store_patch_unit(nbuf, tap - (9 - PUNITS), ccn);
+                if (!SB && tap >= 9 - PUNITS) store_patch_unit(nbuf, tap - (9 - PUNITS), ccn);
+            }
+            if (SB && cc + 1 < ncc) {       // everyone is done reading the (only) buffer: re-fill it with the next channel block
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < PUNITS; ++i) store_patch_unit(0, i, ccn);
             }
         }
         TT_STAMP(8)
@@ -545,8 +555,8 @@ __global__ void repack_oihw_bf16x3_kernel(const float *__restrict__ in, int O, i
     }
 }
 
-template <bool UP2>
-constexpr size_t bf16_lds_bytes() { return (size_t)2 * 2 * ((UP2 ? 60 : 180) + 1) * PPITCH * sizeof(unsigned short); }   // + 2*Cin floats (GN)
+template <int BN, bool UP2>
+constexpr size_t bf16_lds_bytes() { return (size_t)((BN <= 64 && !UP2) ? 1 : 2) * 2 * ((UP2 ? 60 : 180) + 1) * PPITCH * sizeof(unsigned short); }   // + 2*Cin floats (GN)
 
 struct Variant16 {
     const char *name;
@@ -557,7 +567,7 @@ struct Variant16 {
 };
 #define FEMASR_H16(BN, WM, WN, PRO, UP2)                                                        \
     { "conv3x3_halo_bf16x3<8x16x" #BN "," #PRO ",up2=" #UP2 ",waves=" #WM "x" #WN ">", BN, WM * WN * 64,   \
-      conv3x3_halo_bf16x3_kernel<BN, WM, WN, PRO, UP2>, bf16_lds_bytes<UP2>(), false }
+      conv3x3_halo_bf16x3_kernel<BN, WM, WN, PRO, UP2>, bf16_lds_bytes<BN, UP2>(), false }
 
 Variant16 g_v16[] = {
     FEMASR_H16(128, 2, 2, FEMASR_PRO_NONE, false),     // 0   (4 waves: 64 px x 64 ch per wave)
