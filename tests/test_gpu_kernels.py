@@ -180,6 +180,9 @@ BF16_CASES = [
     ('b16_gn_256_256_edges', (2, 13, 21, 256), 256, False, True),     # 256-wide block: 128 px x 64 ch per wave
     ('b16_up2_256_256', (1, 9, 12, 256), 256, True, False),
     ('b16_gn_64_256', (1, 17, 16, 64), 256, False, True),
+    ('b16_gn_32_64_one_block', (2, 11, 19, 32), 64, False, True),     # single channel block, single-buffered patch
+    ('b16_32_3', (1, 9, 40, 32), 3, False, False),
+    ('b16_gn_128_64', (1, 24, 16, 128), 64, False, True),             # 4 channel blocks through the single buffer
 ]
 
 
