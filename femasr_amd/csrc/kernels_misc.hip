@@ -825,6 +825,7 @@ int femasr_conv2d(void *stream, const femasr_conv_args *a)
         FEMASR_REQUIRE(femasr_conv_bf16x3_eligible(a), "conv2d: w_bf16x3 given but the layer is not eligible for the bf16x3 path");
         return femasr_conv_bf16x3_launch((hipStream_t)stream, a, nullptr, nullptr);
     }
+    FEMASR_REQUIRE(!a || !a->gn_part, "conv2d: gn_part (fused GroupNorm partial moments) needs the bf16x3 path (w_bf16x3)");
     return femasr_conv2d_launch((hipStream_t)stream, a, nullptr, nullptr, nullptr);
 }
 
