@@ -26,12 +26,14 @@
 //                    into the registers the MFMAs consume (weights are L2 / L1 resident: <= 9.4 MB per layer).
 //                    No weight staging, no B bank traffic, and the halo kernel needs ONE barrier per channel
 //                    block instead of one per tap.
-// Blocks: 512 threads = 8 waves (2 per SIMD; 2 blocks per CU), 128 output pixels x BN channels, BK = 32.
+// Blocks: 128 output pixels x BN channels, BK = 32.  Cout > 32: 256 threads = 4 waves of 64 x 64 (or 64 px x 32 ch)
+//   outputs, 2-3 blocks per CU; Cout <= 32 (out_conv) and the odd shapes: 512 threads = 8 waves of 32 x 64 / 32 x 32.
+// Main loops are UNCONDITIONAL straight-line code (last chunk re-stages itself into the idle buffer) so that the
+//   compiler's s_waitcnt values are exact; epilogues load residuals in branch-free per-tile batches.
 // Grid: 1-D, n-blocks fastest, bijective XCD remap (block b runs on XCD b % 8) so tiles sharing activations /
 //   halo rows share an L2.
 #include "conv_common.h"
 #include <type_traits>
-#include <stdlib.h>
 #include "detmath.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

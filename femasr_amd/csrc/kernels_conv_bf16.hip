@@ -1,7 +1,8 @@
 // kernels_conv_bf16.hip — 3x3 halo convolution on the bf16 matrix cores with a 3-term split ("bf16x3").
 //
-// Where it is used: ONLY behind the VQ codebook lookup (after_quant conv, the three DecoderBlocks, out_conv;
-// femasr_arch.py:195-211,267-273,352,366-369), and only when the caller opts in (femasr_set_decoder_math(1)).
+// Where it is used: ONLY for convs that cannot move a VQ index - behind the codebook lookup (after_quant conv, the three
+// DecoderBlocks, out_conv; femasr_arch.py:195-211,267-273,352,366-369) and the encoder's up-blocks whose outputs are
+// only the decoder's skip features - and only when the caller opts in (femasr_set_decoder_math(1)).
 // Everything that feeds the argmin stays on the exact-fp32 kernels (kernels_conv.hip), because VQ index parity
 // needs fp32-grade z (hard part 1); after the lookup the contract is the north-star's 1e-3 max-abs.
 //
@@ -13,10 +14,14 @@
 //
 // Structure = conv3x3_halo (kernels_conv.hip): 8x16 output pixels x BN channels per block, one halo patch per
 // 32-channel block staged ONCE (GroupNorm-apply + SiLU in fp32, then split) and swept by all 9 taps; weights are
-// pre-split and stored fragment-major by femasr_repack_oihw_bf16x3 and read straight into MFMA operands.
-//   LDS patch image: ushort [2 buffers][hi|lo][pixel][40]  (80-byte pixel pitch -> the ds_read_b128 of the A fragment
-//   A[i=lane&31][k=8*(lane>>5)..+7] is conflict-free across each 16-lane group)
-// Blocks: 256 threads = 4 waves, 64x64 (BN=128) / 32x64 (BN=64) / 32x32 (BN=32) outputs per wave.
+// pre-split and stored fragment-major by femasr_repack_oihw_bf16x3 ([q][ntile][k-step][hi|lo][lane] x 8 bf16: every
+// wave-level load is one contiguous KiB) and read straight into MFMA operands.
+//   LDS patch image: ushort [buffers][hi|lo][pixel][40]  (80-byte pixel pitch -> the ds_read_b128 of the A fragment
+//   A[i=lane&31][k=8*(lane>>5)..+7] is conflict-free across each 16-lane group), + the sample's GN coefficients.
+// Blocks: 256 threads = 4 waves.  Cout > 128: one 256-wide block, 128 px x 64 ch per wave (rotating A fragments);
+//   65..128: 64 x 64 per wave; 33..64: 64 px x 32 ch per wave, SINGLE-buffered patch (4 blocks per CU); <= 32: 32 x 32.
+// The main loop is unconditional straight-line code (9 taps unrolled) so every s_waitcnt is exact; the epilogue
+// transposes tiles through LDS for dwordx4 stores and can emit per-tile GroupNorm partial moments of its output.
 #include "conv_common.h"
 #include "detmath.h"
 #include <stdlib.h>
