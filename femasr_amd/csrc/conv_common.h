@@ -58,6 +58,15 @@ constexpr int TSCRATCH = 32 * TPITCH;        // floats per wave
 
 __device__ __forceinline__ float f4get(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
+// 32-column weight tile a wave reads for its accumulator tile t: tiles past the packed matrix (Cout not a multiple of the
+// block width) are clamped to the last real tile - their products land in columns >= Cout, which are never stored - so
+// the fragment loads never leave the packed buffer.
+__device__ __forceinline__ int wtile(int n0, int t, int nt32)
+{
+    const int idx = (n0 >> 5) + t;
+    return idx < nt32 ? idx : nt32 - 1;
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nblk)
 {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
     const float *wl[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-        wl[j] = p.w + ((((size_t)(n0 >> 5) + wn * TN + j) * 64 + lane) << 4);
+        wl[j] = p.w + ((((size_t)wtile(n0, wn * TN + j, p.NT32)) * 64 + lane) << 4);
     const size_t wstride = (size_t)p.NT32 << 10;
 
     load_chunk(0);
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     const float *wl[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-        wl[j] = p.w + ((((size_t)(n0 >> 5) + wn * TN + j) * 64 + lane) << 4);
+        wl[j] = p.w + ((((size_t)wtile(n0, wn * TN + j, p.NT32)) * 64 + lane) << 4);
     const size_t wstride = (size_t)p.NT32 << 10;
 
     const int ncc = p.Cin / BK;

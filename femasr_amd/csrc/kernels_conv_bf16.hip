@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || (BN <= 64 && !UP2)) 
     // split weights, fragment-major: [q][ntile][kstep(2)][hi|lo][lane] x 8 bf16: every wave-level load is one contiguous KiB
     const uint4 *wl[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) wl[j] = wsplit + (((size_t)(n0 >> 5) + wn * TN + j) * 256 + lane);
+    for (int j = 0; j < TN; ++j) wl[j] = wsplit + ((size_t)wtile(n0, wn * TN + j, p.NT32) * 256 + lane);
     const size_t wstride = (size_t)p.NT32 << 8;     // uint4 per K chunk
 
     const int ncc = p.Cin / BK;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || (BN <= 64 && !UP2)) 
 #endif
     if (stats_part) {
         const int cg = p.Cout >> 5;                       // channels per group (32 groups): 8 / 4 / 2
-        double *red = reinterpret_cast<double *>(smem_u16);   // [WM][BN/2][2] (patch buffers are dead after the last barrier)
+        double *red = reinterpret_cast<double *>(smem_u16);   // [WM][BN][2] (patch buffers are dead after the last barrier)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             double s_ = 0.0, q_ = 0.0;      // cross-lane / cross-wave part in fp64 (per-lane partials are <= 32 fp32 terms)
@@ -505,8 +505,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || (BN <= 64 && !UP2)) 
             q_ += __shfl_xor(q_, 32, 64);
             if (lane < 32 && (lane % cg) == 0) {
                 const int gl = ((wn * TN + j) * 32 + lane) / cg;        // group index inside this block's BN columns
-                red[(wm * (BN / 2) + gl) * 2] = s_;
-                red[(wm * (BN / 2) + gl) * 2 + 1] = q_;
+                red[(wm * BN + gl) * 2] = s_;
+                red[(wm * BN + gl) * 2 + 1] = q_;
             }
         }
         __syncthreads();
@@ -515,8 +515,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || (BN <= 64 && !UP2)) 
             double S = 0.0, Q = 0.0;
 #pragma unroll
             for (int w2 = 0; w2 < WM; ++w2) {
-                S += red[(w2 * (BN / 2) + t) * 2];
-                Q += red[(w2 * (BN / 2) + t) * 2 + 1];
+                S += red[(w2 * BN + t) * 2];
+                Q += red[(w2 * BN + t) * 2 + 1];
             }
             const int g = n0 / cg + t;
             const size_t tile_id = (size_t)n * p.tilesX * p.tilesY + (size_t)ty * p.tilesX + tx;
@@ -637,8 +637,8 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
     size_t lds = v.lds + (a->prologue == FEMASR_PRO_GN_SILU ? (size_t)2 * a->Cin * sizeof(float) : 0);
     const size_t epi = 8192 + (size_t)(v.threads / 64) * 32 * 36 * sizeof(float);       // epilogue transpose scratch
     if (lds < epi) lds = epi;
-    FEMASR_REQUIRE(!a->gn_part || (a->Cout % 32 == 0 && (a->Cout / 32) <= 8 && v.bn % (a->Cout / 32) == 0),
-                   "conv bf16x3: fused GN moments need Cout %% 32 == 0 and <= 8 channels per group");
+    FEMASR_REQUIRE(!a->gn_part || (a->Cout % 32 == 0 && (a->Cout / 32) <= 8 && ((a->Cout / 32) & (a->Cout / 32 - 1)) == 0),
+                   "conv bf16x3: fused GN moments need Cout = 32 * {1, 2, 4, 8} (32 groups, power-of-two channels per group)");
     hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), lds, s, p, (const uint4 *)a->w_bf16x3,
                        (double *)a->gn_part);
     FEMASR_CHECK_HIP(hipGetLastError());

@@ -333,7 +333,7 @@ struct Ctx {
         // bf16x3 eligibility by shape (same rule as femasr_conv_bf16x3_eligible) so that the dry run plans the same buffers
         const bool lowp_on = o.lowp && h->decoder_math && o.ksz == 3 && o.stride == 1 && o.pad == 1 && (x.C % 32) == 0 &&
                              o.pro != FEMASR_PRO_LN && o.act == FEMASR_ACT_NONE && !(o.up2 && o.pro != FEMASR_PRO_NONE);
-        if (o.want_gn && lowp_on && cout % 32 == 0 && cout / 32 <= 8) {
+        if (o.want_gn && lowp_on && cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0) {
             y.gn_tiles = ((Ho + 7) / 8) * ((Wo + 15) / 16);
             y.gn_part = (double *)arena->alloc((size_t)x.B * y.gn_tiles * 32 * 2 * sizeof(double));
             if (!y.gn_part && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");

@@ -141,7 +141,8 @@ typedef struct {
                              exact fp32 */
     double *gn_part;      /* optional, bf16x3 path only: per-(sample, 8x16 tile, group) partial GroupNorm moments
                              (sum, sum of squares) of the OUTPUT, [B][tilesY*tilesX][32][2] doubles, for
-                             femasr_gn_coeffs_from_partials (saves the separate moments pass over the tensor) */
+                             femasr_gn_coeffs_from_partials (saves the separate moments pass over the tensor).
+                             Needs Cout = 32 * {1, 2, 4, 8}; anything else is refused. */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 

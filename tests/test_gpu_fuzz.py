@@ -1,0 +1,118 @@
+"""Randomised (fixed-seed) shape sweep of the conv kernels against the oracle: every tiling / edge-tile / epilogue
+branch (full and ragged tiles, Cout not a multiple of the tile, odd sizes, fused x2, residual count 0/1/2, LN / GN
+prologues, GELU) with small tensors the CPU oracle finishes in milliseconds.  fp32 paths must be bit-exact; the
+bf16x3 path is bounded at 1e-4 of the output scale (network-level contract: 1e-3)."""
+import os
+
+import numpy as np
+import pytest
+
+from femasr_amd import _lib, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+_MULT = int(os.environ.get('FEMASR_FUZZ_MULT', '1'))     # FEMASR_FUZZ_MULT=8 for a longer one-off sweep
+
+
+def _cases(seed, n):
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        out.append(dict(id=i, b=int(rng.randint(1, 3)), h=int(rng.randint(3, 37)), w=int(rng.randint(3, 41)),
+                        cin=int(rng.choice([32, 64, 96, 128, 256])), cout=int(rng.choice([3, 24, 32, 64, 96, 128, 160, 256, 320])),
+                        up2=bool(rng.randint(0, 2)), gn=bool(rng.randint(0, 2)), nres=int(rng.randint(0, 3))))
+    return out
+
+
+def _tensors(c, tag, ho, wo):
+    x = synth.uniform(100 + c['id'], tag + 'x', (c['b'], c['h'], c['w'], c['cin']), -2.0, 3.0)
+    w = synth.uniform(100 + c['id'], tag + 'w', (3, 3, c['cin'], c['cout']), -0.1, 0.1)
+    bias = synth.uniform(100 + c['id'], tag + 'b', (c['cout'],), -0.5, 0.5)
+    res = [synth.uniform(100 + c['id'], tag + f'r{k}', (c['b'], ho, wo, c['cout']), -1, 1) for k in range(c['nres'])]
+    return x, w, bias, (res + [None, None])[:2]
+
+
+@pytest.mark.parametrize('c', _cases(2024, 36 * _MULT), ids=lambda c: 'f%(id)d_%(b)dx%(h)dx%(w)d_%(cin)d_%(cout)d_u%(up2)d_g%(gn)d_r%(nres)d' % c)
+def test_fuzz_conv3x3_fp32_bit_exact(cuda_device, c):
+    import gpu_utils as G
+    up = c['up2'] and not c['gn']            # the fused x2 has no GN prologue (never needed by the network)
+    ho, wo = (2 * c['h'], 2 * c['w']) if up else (c['h'], c['w'])
+    x, w, bias, (r1, r2) = _tensors(c, 'fz', ho, wo)
+    if c['gn'] and c['cin'] % 32 == 0:
+        gamma = synth.uniform(7, 'fzg', (c['cin'],), 0.5, 1.5)
+        beta = synth.uniform(7, 'fzbe', (c['cin'],), -0.5, 0.5)
+        a_, b_ = orc.gn_coeffs(x, gamma, beta)
+        ref = orc.conv2d(orc.scale_shift_silu(x, a_, b_), w, bias, 3, 1, 1, up, res1=r1, res2=r2)
+        got = G.conv2d(x, w, bias, 3, 1, 1, up, prologue=_lib.PRO_GN_SILU, pro=(a_, b_, None), res1=r1, res2=r2)
+    else:
+        ref = orc.conv2d(x, w, bias, 3, 1, 1, up, res1=r1, res2=r2)
+        got = G.conv2d(x, w, bias, 3, 1, 1, up, res1=r1, res2=r2)
+    assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), \
+        f'max-abs {np.abs(got - ref).max():.3e}'
+
+
+@pytest.mark.parametrize('c', _cases(77, 30 * _MULT), ids=lambda c: 'b%(id)d_%(b)dx%(h)dx%(w)d_%(cin)d_%(cout)d_u%(up2)d_g%(gn)d_r%(nres)d' % c)
+def test_fuzz_conv3x3_bf16x3_within_tolerance(cuda_device, c):
+    import gpu_utils as G
+    import torch
+    up = c['up2'] and not c['gn']
+    ho, wo = (2 * c['h'], 2 * c['w']) if up else (c['h'], c['w'])
+    x, w, bias, (r1, r2) = _tensors(c, 'bz', ho, wo)
+    want_part = (c['cout'] % 32 == 0) and (c['cout'] // 32) in (1, 2, 4, 8)     # channels per group must be a power of two
+    kw = dict(res1=r1, res2=r2, bf16x3=True, gn_part=want_part)
+    if c['gn']:
+        gamma = synth.uniform(8, 'bzg', (c['cin'],), 0.5, 1.5)
+        beta = synth.uniform(8, 'bzbe', (c['cin'],), -0.5, 0.5)
+        a_, b_ = orc.gn_coeffs(x, gamma, beta)
+        ref = orc.conv2d(orc.scale_shift_silu(x, a_, b_), w, bias, 3, 1, 1, up, res1=r1, res2=r2)
+        got = G.conv2d(x, w, bias, 3, 1, 1, up, prologue=_lib.PRO_GN_SILU, pro=(a_, b_, None), **kw)
+    else:
+        ref = orc.conv2d(x, w, bias, 3, 1, 1, up, res1=r1, res2=r2)
+        got = G.conv2d(x, w, bias, 3, 1, 1, up, **kw)
+    part = None
+    if want_part:
+        got, part = got
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert got.shape == ref.shape and float(np.abs(got - ref).max()) <= 1e-4 * scale
+    if part is not None:                      # fused GroupNorm partial moments of the output
+        assert not torch.isnan(part).any()
+        g2 = synth.uniform(9, 'bzg2', (c['cout'],), 0.5, 1.5)
+        b2 = synth.uniform(9, 'bzb2', (c['cout'],), -0.5, 0.5)
+        a, bb = G.gn_coeffs_from_partials(part, got.shape[1], got.shape[2], c['cout'], g2, b2)
+        a_ref, b_ref = orc.gn_coeffs(got, g2, b2)
+        assert np.abs(a - a_ref).max() <= 1e-5 * np.abs(a_ref).max()
+        assert np.abs(bb - b_ref).max() <= 2e-5 * max(1.0, np.abs(b_ref).max())
+
+
+def _lin_cases(seed, n):
+    rng = np.random.RandomState(seed)
+    return [dict(id=i, rows=int(rng.randint(1, 700)), cin=int(rng.choice([32, 64, 256, 512, 1024])),
+                 cout=int(rng.choice([3, 32, 64, 96, 128, 256, 384, 768])), ln=bool(rng.randint(0, 2)),
+                 act=int(rng.randint(0, 2)), nres=int(rng.randint(0, 3))) for i in range(n)]
+
+
+@pytest.mark.parametrize('c', _lin_cases(5, 30 * _MULT), ids=lambda c: 'l%(id)d_%(rows)d_%(cin)d_%(cout)d_ln%(ln)d_a%(act)d_r%(nres)d' % c)
+def test_fuzz_linear_bit_exact(cuda_device, c):
+    """1x1 conv / nn.Linear path (igemm K1): ragged row tiles, all epilogue variants (scalar and float4 stores)."""
+    import gpu_utils as G
+    rows, cin, cout = c['rows'], c['cin'], c['cout']
+    ln = c['ln'] and cin == 256                         # ln_stats is built for C = 256 (the Swin width)
+    x = synth.uniform(200 + c['id'], 'lzx', (rows, cin), -3, 4)
+    w = synth.uniform(200 + c['id'], 'lzw', (cin, cout), -0.1, 0.1)
+    bias = synth.uniform(200 + c['id'], 'lzb', (cout,), -0.5, 0.5)
+    res = [synth.uniform(200 + c['id'], f'lzr{k}', (rows, cout), -1, 1) for k in range(c['nres'])]
+    r1, r2 = (res + [None, None])[:2]
+    xin, pro, prologue = x, (None, None, None), 0
+    if ln:
+        gamma = synth.uniform(6, 'lzg', (256,), 0.5, 1.5)
+        beta = synth.uniform(6, 'lzbe', (256,), -0.5, 0.5)
+        pro, prologue = (G.ln_stats(x), gamma, beta), _lib.PRO_LN
+        xin = orc.layernorm(x, gamma, beta)
+    ref = orc.linear(xin, w, bias, act=c['act'], res=r1)
+    if r2 is not None:
+        ref = ref + r2                                  # second residual: one more fp32 add, in this order
+    got = G.conv2d(x.reshape(1, rows, 1, cin), w.reshape(1, 1, cin, cout), bias, 1, prologue=prologue, pro=pro, act=c['act'],
+                   res1=None if r1 is None else r1.reshape(1, rows, 1, cout),
+                   res2=None if r2 is None else r2.reshape(1, rows, 1, cout)).reshape(rows, cout)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f'max-abs {np.abs(got - ref).max():.3e}'
