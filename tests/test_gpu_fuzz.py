@@ -116,3 +116,61 @@ def test_fuzz_linear_bit_exact(cuda_device, c):
                    res1=None if r1 is None else r1.reshape(1, rows, 1, cout),
                    res2=None if r2 is None else r2.reshape(1, rows, 1, cout)).reshape(rows, cout)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f'max-abs {np.abs(got - ref).max():.3e}'
+
+
+def _gen_cases(seed, n):
+    rng = np.random.RandomState(seed)
+    return [dict(id=i, b=int(rng.randint(1, 3)), h=int(rng.randint(4, 34)), w=int(rng.randint(4, 34)),
+                 cin=int(rng.choice([3, 5, 32, 64, 96])), cout=int(rng.choice([3, 32, 64, 96, 128, 256])),
+                 k=int(rng.choice([1, 3, 4])), s=int(rng.choice([1, 2])), p=int(rng.randint(0, 2)),
+                 nres=int(rng.randint(0, 3)), act=int(rng.randint(0, 2))) for i in range(n)]
+
+
+@pytest.mark.parametrize('c', _gen_cases(31, 24 * _MULT), ids=lambda c: 'g%(id)d_%(b)dx%(h)dx%(w)d_%(cin)d_%(cout)d_k%(k)ds%(s)dp%(p)d_r%(nres)d_a%(act)d' % c)
+def test_fuzz_general_conv_bit_exact(cuda_device, c):
+    """implicit-GEMM path: in_conv-like (Cin not a multiple of 32), strided and unpadded convs, k = 1 / 3 / 4."""
+    import gpu_utils as G
+    if c['h'] + 2 * c['p'] < c['k'] or c['w'] + 2 * c['p'] < c['k']:
+        pytest.skip('kernel larger than the padded image')
+    ho, wo = (c['h'] + 2 * c['p'] - c['k']) // c['s'] + 1, (c['w'] + 2 * c['p'] - c['k']) // c['s'] + 1
+    x = synth.uniform(300 + c['id'], 'gzx', (c['b'], c['h'], c['w'], c['cin']), -2, 2)
+    w = synth.uniform(300 + c['id'], 'gzw', (c['k'], c['k'], c['cin'], c['cout']), -0.2, 0.2)
+    bias = synth.uniform(300 + c['id'], 'gzb', (c['cout'],), -0.5, 0.5)
+    res = [synth.uniform(300 + c['id'], f'gzr{k}', (c['b'], ho, wo, c['cout']), -1, 1) for k in range(c['nres'])]
+    r1, r2 = (res + [None, None])[:2]
+    ref = orc.conv2d(x, w, bias, c['k'], c['s'], c['p'], False, act=c['act'], res1=r1, res2=r2)
+    got = G.conv2d(x, w, bias, c['k'], c['s'], c['p'], False, act=c['act'], res1=r1, res2=r2)
+    assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), \
+        f'max-abs {np.abs(got - ref).max():.3e}'
+
+
+@pytest.mark.parametrize('seed', range(6 * _MULT))
+def test_fuzz_window_attention_bit_exact(cuda_device, seed):
+    import gpu_utils as G
+    rng = np.random.RandomState(900 + seed)
+    b, h, w = int(rng.randint(1, 3)), 8 * int(rng.randint(1, 5)), 8 * int(rng.randint(1, 5))
+    heads = int(rng.choice([1, 2, 8]))
+    c = 32 * heads
+    shift = int(rng.choice([0, 4])) if min(h, w) > 8 else 0
+    qkv = synth.uniform(400 + seed, 'aq', (b, h * w, 3 * c), -3, 3)
+    table = synth.uniform(400 + seed, 'at', (225, heads), -1, 1)
+    got = G.window_attention(qkv, b, h, w, c, heads, shift, table)
+    ref = orc.window_attention(qkv, b, h, w, c, heads, shift, table)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f'max-abs {np.abs(got - ref).max():.3e}'
+
+
+@pytest.mark.parametrize('seed', range(5 * _MULT))
+def test_fuzz_vq_bit_exact(cuda_device, seed):
+    import gpu_utils as G
+    rng = np.random.RandomState(700 + seed)
+    m, n_e, d = int(rng.randint(1, 600)), int(rng.choice([128, 256, 1024])), int(rng.choice([32, 64, 256, 512]))
+    cb = synth.uniform(500 + seed, 'vc', (n_e, d), -1, 1)
+    z = synth.uniform(500 + seed, 'vz', (m, d), -1, 1)
+    for t in range(min(m, 8)):                        # a few exact and near ties
+        j = int(rng.randint(0, n_e))
+        z[t] = cb[j]
+        cb[(j * 7 + 3) % n_e] = cb[j]
+    idx_ref, zq_ref = orc.vq(z, cb)
+    idx, zq, _, _ = G.vq(z, cb)
+    assert np.array_equal(idx, idx_ref)
+    assert np.array_equal(zq.view(np.uint32), zq_ref.view(np.uint32))
