@@ -174,3 +174,46 @@ def test_fuzz_vq_bit_exact(cuda_device, seed):
     idx, zq, _, _ = G.vq(z, cb)
     assert np.array_equal(idx, idx_ref)
     assert np.array_equal(zq.view(np.uint32), zq_ref.view(np.uint32))
+
+
+def _net_cases(seed, n):
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        cfg = str(rng.choice(['x4', 'x2', 'hq']))
+        if cfg == 'hq':                              # forward() of the HQ net: multiples of 8, no padding
+            h, w = 8 * int(rng.randint(2, 8)), 8 * int(rng.randint(2, 8))
+        else:                                        # test(): any size the mirror pad accepts
+            h, w = int(rng.randint(16, 57)), int(rng.randint(16, 57))
+        out.append(dict(id=i, cfg=cfg, b=int(rng.randint(1, 4)), h=h, w=w, streams=int(rng.choice([1, 2, 3])),
+                        math=str(rng.choice(['fp32', 'bf16x3']))))
+    return out
+
+
+@pytest.mark.parametrize('c', _net_cases(4242, 8 * _MULT), ids=lambda c: 'n%(id)d_%(cfg)s_%(b)dx%(h)dx%(w)d_s%(streams)d_%(math)s' % c)
+def test_fuzz_network_vs_oracle(cuda_device, c):
+    """Whole network at random small sizes / batch / stream count / math mode: fp32 mode bit-exact against the oracle
+    (output and VQ indices), bf16x3 mode identical indices and <= 1e-3 (workspace planner, stream fork/join, ragged
+    tiles in every layer)."""
+    import gpu_utils as G
+    import torch
+    from helpers import oracle_net, synth_weights
+    w = synth_weights(c['cfg'], 21 + c['id'], 'trained')
+    net = G.build_net(c['cfg'], w, cuda_device)
+    net.num_streams, net.decoder_math = c['streams'], c['math']
+    x = synth.synth_input(50 + c['id'], (c['b'], 3, c['h'], c['w']))
+    xt = torch.from_numpy(x).to(cuda_device)
+    onet = oracle_net(c['cfg'], w)
+    if c['cfg'] == 'hq':
+        y, _, _, idx_list = net(xt)
+        y, idx = y.cpu().numpy(), idx_list[0].cpu().numpy()
+        yo, io = onet.forward(x)
+    else:
+        y, idx = net.test_with_indices(xt)
+        y, idx = y.cpu().numpy(), idx.cpu().numpy()
+        yo, io = onet.test(x, return_indices=True)
+    assert np.array_equal(idx.reshape(-1), np.asarray(io).reshape(-1)), 'VQ indices differ from the oracle'
+    if c['math'] == 'fp32':
+        assert np.array_equal(y, yo), f'not bit-identical: max-abs {np.abs(y - yo).max():.3e}'
+    else:
+        assert float(np.abs(y - yo).max()) < 1e-3
