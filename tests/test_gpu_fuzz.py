@@ -217,3 +217,53 @@ def test_fuzz_network_vs_oracle(cuda_device, c):
         assert np.array_equal(y, yo), f'not bit-identical: max-abs {np.abs(y - yo).max():.3e}'
     else:
         assert float(np.abs(y - yo).max()) < 1e-3
+
+
+@pytest.mark.parametrize('seed', range(8 * _MULT))
+def test_fuzz_gn_and_ln_moments_bit_exact(cuda_device, seed):
+    import gpu_utils as G
+    rng = np.random.RandomState(1200 + seed)
+    b, h, w = int(rng.randint(1, 4)), int(rng.randint(1, 70)), int(rng.randint(1, 50))
+    c = int(rng.choice([32, 64, 96, 128, 160, 256, 512]))
+    off = float(rng.choice([0.0, 10.0, -50.0]))              # cancellation-prone offsets
+    x = synth.uniform(600 + seed, 'mx', (b, h, w, c), off - 2, off + 3)
+    gamma = synth.uniform(600 + seed, 'mg', (c,), 0.5, 1.5)
+    beta = synth.uniform(600 + seed, 'mb', (c,), -0.5, 0.5)
+    a, bb = G.gn_coeffs(x, gamma, beta)
+    a_ref, b_ref = orc.gn_coeffs(x, gamma, beta)
+    assert np.array_equal(a.view(np.uint32), a_ref.view(np.uint32)) and np.array_equal(bb.view(np.uint32), b_ref.view(np.uint32))
+    rows = int(rng.randint(1, 3000))
+    xl = synth.uniform(700 + seed, 'lx', (rows, 256), off - 4, off + 6)
+    g2 = synth.uniform(700 + seed, 'lg', (256,), 0.5, 1.5)
+    b2 = synth.uniform(700 + seed, 'lb', (256,), -0.5, 0.5)
+    st = G.ln_stats(xl)
+    # LN is pinned through the linear that consumes the stats (identity-like weights would hide nothing: use a real one)
+    wl = synth.uniform(700 + seed, 'lw', (256, 32), -0.1, 0.1)
+    bl = synth.uniform(700 + seed, 'lbias', (32,), -0.5, 0.5)
+    got = G.conv2d(xl.reshape(1, rows, 1, 256), wl.reshape(1, 1, 256, 32), bl, 1, prologue=_lib.PRO_LN,
+                   pro=(st, g2, b2)).reshape(rows, 32)
+    ref = orc.linear(orc.layernorm(xl, g2, b2), wl, bl)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize('seed', range(4 * _MULT))
+def test_fuzz_test_tile_vs_oracle(cuda_device, seed):
+    """`test_tile` with random tile size / pad (ragged border tiles, several shape classes) == the oracle's test_tile."""
+    import gpu_utils as G
+    import torch
+    from helpers import oracle_net, synth_weights
+    rng = np.random.RandomState(1500 + seed)
+    w = synth_weights('x4', 31 + seed, 'trained')
+    net = G.build_net('x4', w, cuda_device)
+    net.num_streams = int(rng.choice([1, 2]))
+    ts, pad = int(rng.choice([24, 32, 40, 48])), int(rng.choice([0, 4, 8]))
+
+    def size():          # whole tiles plus a ragged remainder the mirror pad of test() accepts (>= 12 px; the reference
+        rem = int(rng.choice([0, int(rng.randint(12, ts))]))      # also rejects narrower tiles)
+        return ts * int(rng.randint(1, 3)) + rem
+    h, wd = size(), size()
+    x = synth.synth_input(60 + seed, (1, 3, h, wd))
+    y = net.test_tile(torch.from_numpy(x).to(cuda_device), ts, pad).cpu().numpy()
+    yo = oracle_net('x4', w).test_tile(x, ts, pad)
+    assert y.shape == yo.shape == (1, 3, 4 * h, 4 * wd)
+    assert np.array_equal(y, yo), f'max-abs {np.abs(y - yo).max():.3e}'
