@@ -1,6 +1,7 @@
 """Micro-benchmark of ONE conv through the C ABI (femasr_conv2d) with device-resident synthetic tensors.
 Usage: python tools/bench_conv.py B H W Cin Cout [--up2] [--gn] [--res] [--fp32] [--iters N] [--gn-part]
-Prints ms per launch and algorithmic TFLOP/s.  Used for kernel experiments (FEMASR_ABL / FEMASR_BF16_CLS env)."""
+Prints ms per launch and algorithmic TFLOP/s.  With FEMASR_SO=tools/dbg/libfemasr_hip_tt.so (tools/build_debug.sh) it also
+prints the per-wave cycle shares and honours FEMASR_BF16_CLS (tile class), FEMASR_DBG / FEMASR_DBG16 (ablation switches)."""
 import argparse
 import ctypes
 import os
@@ -97,7 +98,7 @@ def main():
         raw.femasr_debug_igemm_time(buf, 0)
         tot = float(buf[5]) or 1.0
         print('  igemm per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(['mfma', 'store', 'barrier', 'prologue', 'epilogue'])) + '  total/launch %.3e' % (tot / a_.iters))
-    print('conv %s dbg=%s abl=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_DBG', '0') + '/' + os.environ.get('FEMASR_DBG16', '0'), os.environ.get('FEMASR_ABL', '0'),
+    print('conv %s dbg=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_DBG', '0') + '/' + os.environ.get('FEMASR_DBG16', '0'),
                                                                     os.environ.get('FEMASR_BF16_CLS', '-'), ms, fl / ms / 1e9))
 
 
