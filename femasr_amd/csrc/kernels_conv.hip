@@ -393,9 +393,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
                 for (int k = 0; k < 4; ++k) {
                     const float4 a4 = *reinterpret_cast<const float4 *>(T + (trow + 8 * k) * TPITCH + 4 * tq);
                     float v[4] = {a4.x + b4[0], a4.y + b4[1], a4.z + b4[2], a4.w + b4[3]};
+                    if (p.act == FEMASR_ACT_GELU) {         // two at a time on the packed fp32 ALU (bit-identical per element)
+                        const det_f32x2 g0 = det_gelu2(det_f32x2{v[0], v[1]}), g1 = det_gelu2(det_f32x2{v[2], v[3]});
+                        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (p.act == FEMASR_ACT_GELU) v[e] = det_gelu(v[e]);
                         if (NRES >= 1) v[e] = v[e] + rbuf[tl % DEPTH][0][k][e];
                         if (NRES >= 2) v[e] = v[e] + rbuf[tl % DEPTH][NRES >= 2 ? 1 : 0][k][e];
                     }
