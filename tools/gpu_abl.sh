@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT; timeout 600 python - <<'PY' 2>&1 | tail -4
+cd $GRAFT_REPO_ROOT; timeout 600 python - <<'PY' 2>&1 | tail -8
 import os, sys, time, torch
 sys.path.insert(0, 'tests')
 import gpu_utils as G
@@ -6,11 +6,15 @@ from femasr_amd import synth
 from helpers import synth_weights
 dev = torch.device('cuda', 0)
 net = G.build_net('x4', synth_weights('x4', 0, 'trained'), dev)
-net.num_streams, net.decoder_math = 2, 'bf16x3'
-x = torch.from_numpy(synth.synth_input(3, (1, 3, 2048, 2048))).to(dev)
-for ts, pad in ((128, 0), (240, 16)):
-    y = net.test_tile(x, ts, pad); torch.cuda.synchronize()
-    t0 = time.perf_counter(); y = net.test_tile(x, ts, pad); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f'config 3: 2048x2048 LR -> {tuple(y.shape)} test_tile(tile={ts}, pad={pad}) on 1 GPU: {dt*1e3:.0f} ms = {y.shape[2]*y.shape[3]/1e6/dt:.1f} output MPix/s, finite={bool(torch.isfinite(y).all())}', flush=True)
-    del y
+net.decoder_math = 'bf16x3'
+for B in (1, 2, 4, 8, 16, 32):
+    x = torch.from_numpy(synth.synth_input(3, (B, 3, 128, 128))).to(dev)
+    for streams in (1, 2):
+        net.num_streams = streams
+        net.test(x); torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n): net.test(x)
+        torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / n * 1e3
+        print(f'B={B} streams={streams}: {ms:.2f} ms/step, {ms/B:.2f} ms/tile, {B*512*512/1e6/ms*1e3:.1f} MPix/s', flush=True)
 PY
