@@ -10,7 +10,11 @@ exactly as `test_tile` does (overlap-discard).
 
 xGMI is point-to-point (7 links/GPU): a single large all-gather lets RCCL use
 all links at once; the payload (3 MiB fp32 per 512x512 tile) is <3 % of the
-tile's compute time, so it is issued once, un-bucketed.
+tile's compute time, so it is issued once, un-bucketed, as
+`all_gather_into_tensor` on a persistent (world, cap) buffer: tiles are written
+straight into this rank's send slab by the batched `test()` calls' consumers
+(one copy per class), nothing is zero-filled and nothing is re-copied on receive
+— the per-rank results are views into the receive buffer.
 """
 import os
 
@@ -40,39 +44,60 @@ def _class_numel(hw, count, batch, channel, scale):
     return count * batch * channel * hw[0] * scale * hw[1] * scale
 
 
-def gather_tiles(results, classes, batch, channel, scale, group=None):
-    """All-gather every rank's upscaled tiles with ONE collective.
+class TileGather:
+    """Persistent send/receive buffers for the all-gather of one image geometry.
 
-    results: {(h,w): tensor (n_owned*batch, channel, h*s, w*s)} of THIS rank, classes in `classes` order.
-    Returns a list (one entry per rank) of dicts with the same structure.
-    Each rank's payload is flattened into one buffer, padded to the largest rank payload (sizes follow
-    from the deterministic partition, so no size exchange is needed)."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    sizes = []
-    for r in range(world):
-        owned = tiling.partition(classes, r, world)
-        sizes.append(sum(_class_numel(hw, len(tl), batch, channel, scale) for hw, tl in owned.items()))
-    cap = max(sizes)
-    ref = next(iter(results.values()))
-    flat = torch.zeros(cap, dtype=ref.dtype, device=ref.device)
-    off = 0
-    for hw in classes:
-        t = results[hw].reshape(-1)
-        flat[off:off + t.numel()] = t
-        off += t.numel()
-    assert off == sizes[rank], (off, sizes[rank])
-    bufs = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(bufs, flat, group=group)
-    out = []
-    for r in range(world):
-        owned = tiling.partition(classes, r, world)
+    Sizes follow from the deterministic partition (tiling.partition), so no size exchange is needed; every
+    rank's slab is `cap` = the largest rank payload (ranks with fewer tiles leave their tail unused)."""
+
+    def __init__(self, classes, batch, channel, scale, dtype, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.classes, self.batch, self.channel, self.scale = classes, batch, channel, scale
+        self.owned = [tiling.partition(classes, r, self.world) for r in range(self.world)]
+        self.sizes = [sum(_class_numel(hw, len(tl), batch, channel, scale) for hw, tl in o.items()) for o in self.owned]
+        self.cap = max(max(self.sizes), 1)
+        self.send = torch.empty(self.cap, dtype=dtype, device=device)
+        self.recv = torch.empty((self.world, self.cap), dtype=dtype, device=device)
+
+    def _views(self, flat, r):
         d, off = {}, 0
-        for hw, tl in owned.items():
-            n = _class_numel(hw, len(tl), batch, channel, scale)
-            d[hw] = bufs[r][off:off + n].reshape(len(tl) * batch, channel, hw[0] * scale, hw[1] * scale)
+        for hw, tl in self.owned[r].items():
+            n = _class_numel(hw, len(tl), self.batch, self.channel, self.scale)
+            d[hw] = flat[off:off + n].view(len(tl) * self.batch, self.channel, hw[0] * self.scale, hw[1] * self.scale)
             off += n
-        out.append(d)
+        return d
+
+    def send_views(self):
+        """{(h,w): view into this rank's send slab}: batched `test()` results are copied (or written) here."""
+        return self._views(self.send, self.rank)
+
+    def gather(self, async_op=False):
+        """ONE collective.  Returns (list of per-rank {(h,w): view into the receive buffer}, work handle or None)."""
+        work = dist.all_gather_into_tensor(self.recv.view(-1), self.send, group=self.group, async_op=async_op)
+        return [self._views(self.recv[r], r) for r in range(self.world)], work
+
+
+_gathers = {}
+
+
+def gather_tiles(results, classes, batch, channel, scale, group=None):
+    """All-gather every rank's upscaled tiles with ONE `all_gather_into_tensor` on persistent buffers.
+
+    results: {(h,w): tensor (n_owned*batch, channel, h*s, w*s)} of THIS rank.
+    Returns a list (one entry per rank) of dicts with the same structure (views into the receive buffer,
+    valid until the next call with the same geometry)."""
+    ref = next(iter(results.values()))
+    key = (tuple((hw, tuple(t.index for t in tl)) for hw, tl in classes.items()), batch, channel, scale, ref.dtype,
+           str(ref.device), id(group))
+    tg = _gathers.get(key)
+    if tg is None:
+        _gathers.clear()            # one geometry at a time keeps the footprint bounded
+        tg = _gathers[key] = TileGather(classes, batch, channel, scale, ref.dtype, ref.device, group)
+    for hw, dst in tg.send_views().items():
+        dst.copy_(results[hw])
+    out, _ = tg.gather()
     return out
 
 
