@@ -68,6 +68,8 @@ SIGNATURES = {
     'femasr_gn_coeffs': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, c_f32, vp, vp, vp]),
     'femasr_gn_coeffs_from_partials': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, c_f32, vp, vp]),
     'femasr_ln_stats': (c_int, [vp, vp, c_i64, c_int, c_f32, vp]),
+    'femasr_layernorm': (c_int, [vp, vp, c_i64, c_int, vp, vp, c_f32, vp]),
+    'femasr_gn_scratch_bytes': (szt, [c_int, c_int, c_int, c_int, c_int]),
     'femasr_window_attention': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp]),
     'femasr_vq': (c_int, [vp, vp, c_i64, c_int, vp, vp, vp, c_int, vp, vp, vp]),
     'femasr_row_sqsum': (c_int, [vp, vp, c_i64, c_int, vp]),

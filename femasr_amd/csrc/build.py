@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['kernels_conv.hip', 'kernels_conv_bf16.hip', 'kernels_misc.hip', 'model.hip']
+SOURCES = ['kernels_conv.hip', 'kernels_gemm.hip', 'kernels_conv_bf16.hip', 'kernels_misc.hip', 'model.hip']
 HEADERS = ['common.h', 'conv_common.h', 'detmath.h', '../../include/femasr_hip.h']
 SO = os.path.join(HERE, 'libfemasr_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
@@ -27,7 +27,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(HERE, src)
         o = os.path.join(HERE, src.replace('.hip', '.o'))
@@ -35,8 +35,11 @@ def build(force=False, verbose=True):
             cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append((src, subprocess.Popen(cmd)))       # translation units compile in parallel
         objs.append(o)
+    failed = [src for src, p in jobs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f'hipcc failed for {failed}')
     if force or _stale(SO, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', SO] + objs
         if verbose:

@@ -33,9 +33,20 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
                          int *variant_out, double *flops_out);
 int femasr_conv_variant_count();
 const char *femasr_conv_variant_name(int v);
+bool femasr_conv_halo_eligible(const femasr_conv_args *a);      // 3x3 s1 p1, Cin % 32 == 0: the halo kernels
+// fused GroupNorm(32) partial moments in a halo conv's epilogue: channels per group a power of two <= 32
+inline bool femasr_gn_fusable(int cout) { const int cg = cout / 32; return cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0; }
+
+// 1x1 convs / nn.Linear / VQ distance matrix on the LDS-DMA GEMM (kernels_gemm.hip)
+bool femasr_gemm_eligible(const femasr_conv_args *a);
+int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_epilogue *vq, int *variant_out, double *flops_out);
+int femasr_gemm_variant_count();
+const char *femasr_gemm_variant_name(int v);
+int femasr_repack_k1(hipStream_t s, const float *in, int O, int I, float *out);
 
 // bf16x3 3x3 halo convs (kernels_conv_bf16.hip)
 bool femasr_conv_bf16x3_eligible(const femasr_conv_args *a);
+bool femasr_conv_bf16x3_shape_ok(const femasr_conv_args *a);      // the same rule without the w_bf16x3 pointer (planner)
 int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out);
 int femasr_conv_bf16x3_variant_count();
 const char *femasr_conv_bf16x3_variant_name(int v);

@@ -10,9 +10,11 @@ struct ConvParams {
     const float *vq_zz, *vq_ee;
     float *vq_part;
     int vq_nblk;
+    double *gn_part;      // fused GroupNorm partial moments of the OUTPUT, [B][tiles][32][2] (halo kernels) or null
     int B, H, W, Cin, Cout, ksz, stride, pad, up2, act, Ho, Wo;
     int M, K, nchunks, taps, MB, NB, NT32;
     int tilesX, tilesY;
+    int kperm;            // conv_igemm: weights are in the GEMM layout of the 1x1 layers (k order 0,4,1,5,.. inside groups of 8)
 };
 
 constexpr int BK = 32;

@@ -3,10 +3,8 @@
 // Two kernel families cover every dense contraction of the hot path:
 //   conv3x3_halo  3x3 stride-1 pad-1 convs (753 of the 964 GFLOP per tile), optional fused nearest-x2
 //                 (nn.Upsample, femasr_arch.py:172,202) and fused GroupNorm-apply + SiLU (fema_utils.py:72-79)
-//   conv_igemm    everything else as an implicit GEMM: k4 in_conv, stride-2 convs, 1x1 convs and all nn.Linear
-//                 (network_swinir.py:19-21,105-112; ksz=1 on a (1,rows,1,Cin) tensor) with LayerNorm-apply on
-//                 load (network_swinir.py:243,277), and the VQ distance + per-tile first-min argmin
-//                 (femasr_arch.py:35-38,63-66)
+//   conv_igemm    the remaining general convs as an implicit GEMM: k4 in_conv, stride-2 convs, odd shapes
+//                 (1x1 convs / nn.Linear / the VQ distance matrix live in kernels_gemm.hip)
 //   both          bias, exact-erf GELU, up to two residual adds on store (fema_utils.py:82-83;
 //                 network_swinir.py:276-277,482; femasr_arch.py:361-362)
 //
@@ -42,32 +40,11 @@ namespace {
 
 // C/D layout of a 32x32 MFMA tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 
-#ifdef FEMASR_TAPTIME
-__constant__ int g_dbg_flags;       // debug build only: ablation switches for the igemm main loop (1 barrier, 2 LDS staging, 4 A loads, 8 weights)
-#define DBG_ON(bit) (g_dbg_flags & (bit))
-__device__ unsigned long long g_igemm_time[8 * 65536];     // debug build only: per-wave cycle sums (mfma, store, barrier, prologue, epilogue, total)
-#define IT_STAMP_ALWAYS(slot)                                       \
-    {                                                                \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        tt[slot] += now_ - tprev;                                    \
-        tprev = now_;                                                \
-    }
-#if FEMASR_TAPTIME >= 2
-#define IT_STAMP(slot) IT_STAMP_ALWAYS(slot)
-#else
-#define IT_STAMP(slot) {}
-#endif
-#else
-#define IT_STAMP(slot) {}
-#define IT_STAMP_ALWAYS(slot) {}
-#define DBG_ON(bit) false
-#endif
-
 // =================================================================================================================
 // conv_igemm: implicit GEMM, M = B*Ho*Wo pixels, N = Cout, K chunks of 32
 // =================================================================================================================
-template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC, bool VQ, bool K1>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 128) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p)
+template <int BM, int BN, int WM, int WN, int PRO, bool CINVEC>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_igemm_kernel(const ConvParams p)
 {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -75,18 +52,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
     constexpr int AROWS = BM / RSTEP;            // A float4 units per thread
     static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && AROWS >= 1, "tile config");
     static_assert(CINVEC || PRO == FEMASR_PRO_NONE, "generic-Cin path has no prologue");
-    static_assert(!K1 || CINVEC, "K1 (1x1 / linear fast addressing) needs Cin % 32 == 0");
+    static_assert(PRO != FEMASR_PRO_LN, "LayerNorm is a separate pass (femasr_layernorm)");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                  // [2][BM][ALD]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform -> SGPR arithmetic
-#ifdef FEMASR_TAPTIME
-    unsigned long long tt[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = __builtin_amdgcn_s_memtime();
-    const unsigned long long tstart = tprev;
-#endif
     const int wm = wave / WN, wn = wave % WN;
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
     const int nb = L % p.NB, mb = L / p.NB;
@@ -95,66 +67,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
     // ---- per-thread A rows: (mrow + RSTEP j, k-quad kq)
     const int kq = t & 7, mrow = t >> 3;
     int rn[AROWS], riy[AROWS], rix[AROWS];
-    float lmean[AROWS], lrstd[AROWS];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int j = 0; j < AROWS; ++j) {
         const int r = m0 + mrow + RSTEP * j;
-        if (K1) {
-            rn[j] = 0; riy[j] = 0; rix[j] = 0;
-            if (PRO == FEMASR_PRO_LN) {
-                lmean[j] = r < p.M ? p.pro_a[2 * (size_t)r] : 0.f;
-                lrstd[j] = r < p.M ? p.pro_a[2 * (size_t)r + 1] : 0.f;
-            }
-        } else if (r < p.M) {
+        if (r < p.M) {
             const int n = r / HoWo, rem = r - n * HoWo;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             rn[j] = n;
             riy[j] = oy * p.stride - p.pad;
             rix[j] = ox * p.stride - p.pad;
-            if (PRO == FEMASR_PRO_LN) {
-                lmean[j] = p.pro_a[2 * (size_t)r];
-                lrstd[j] = p.pro_a[2 * (size_t)r + 1];
-            }
         } else {
             rn[j] = 0;
             riy[j] = -(1 << 28);
             rix[j] = -(1 << 28);
-            if (PRO == FEMASR_PRO_LN) { lmean[j] = 0.f; lrstd[j] = 0.f; }
         }
     }
     const int Hv = p.up2 ? 2 * p.H : p.H, Wv = p.up2 ? 2 * p.W : p.W;
-    // K1 (1x1 conv / nn.Linear): row r of the GEMM is row r of the input -> per-lane offsets are fixed per tile and
-    // only a scalar base moves with the K chunk (no per-chunk VALU address math)
-    unsigned aoff[AROWS];
-    unsigned k1mask = 0;
-    if (K1) {
-#pragma unroll
-        for (int j = 0; j < AROWS; ++j) {
-            const bool ok = (m0 + mrow + RSTEP * j) < p.M;
-            aoff[j] = ok ? (unsigned)((mrow + RSTEP * j) * p.Cin + 4 * kq) : (unsigned)(4 * kq);
-            k1mask |= (ok ? 1u : 0u) << j;
-        }
-    }
 
     float4 ra[AROWS], rga[AROWS], rgb[AROWS];
-    float4 lng, lnb;
     unsigned amask = 0;
 
     // ---- global -> register staging of the A part of K-chunk c (branch-free: out-of-image taps / tail rows read
     //      element 0 and are zeroed at store time, so the loads stay in flight across the MFMA steps)
     auto load_chunk = [&](int c) {
         amask = 0;
-        if (K1) {
-            const float *base = p.in + (size_t)m0 * p.Cin + c * BK;
-#pragma unroll
-            for (int j = 0; j < AROWS; ++j) ra[j] = ld4(base + aoff[j]);
-            amask = k1mask;
-            if (PRO == FEMASR_PRO_LN) {
-                lng = ld4(p.pro_b + c * BK + 4 * kq);
-                lnb = ld4(p.pro_c + c * BK + 4 * kq);
-            }
-        } else if (CINVEC) {
+        if (CINVEC) {
             const int cc = c / p.taps, tap = c - cc * p.taps, c0 = cc * BK + 4 * kq;
             const int ky = tap / p.ksz, kx = tap - ky * p.ksz;
 #pragma unroll
@@ -169,10 +107,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
                     rgb[j] = ld4(p.pro_b + (size_t)rn[j] * p.Cin + c0);
                 }
                 amask |= (ok ? 1u : 0u) << j;
-            }
-            if (PRO == FEMASR_PRO_LN) {
-                lng = ld4(p.pro_b + c0);
-                lnb = ld4(p.pro_c + c0);
             }
         } else {
 #pragma unroll
@@ -212,11 +146,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
                 v.y = det_silu(__builtin_fmaf(v.y, rga[j].y, rgb[j].y));
                 v.z = det_silu(__builtin_fmaf(v.z, rga[j].z, rgb[j].z));
                 v.w = det_silu(__builtin_fmaf(v.w, rga[j].w, rgb[j].w));
-            } else if (PRO == FEMASR_PRO_LN) {
-                v.x = __builtin_fmaf((v.x - lmean[j]) * lrstd[j], lng.x, lnb.x);
-                v.y = __builtin_fmaf((v.y - lmean[j]) * lrstd[j], lng.y, lnb.y);
-                v.z = __builtin_fmaf((v.z - lmean[j]) * lrstd[j], lng.z, lnb.z);
-                v.w = __builtin_fmaf((v.w - lmean[j]) * lrstd[j], lng.w, lnb.w);
             }
             if (!(amask & (1u << j))) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
             float *dst = Ab + (mrow + RSTEP * j) * ALD + 4 * kq;
@@ -235,11 +164,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // B fragments: lane-contiguous 16 floats per (chunk, 32-column tile); chunk stride = NT32 * 1024 floats
+    // B fragments: lane-contiguous 16 floats per (chunk, 32-column tile); chunk stride = NT32 * 1024 floats.
+    // 1x1 layers with Cin % 32 == 0 that are not plain GEMMs (padded / strided / GN prologue) still carry the GEMM weight
+    // layout [chunk][ntile][j][lane][t] and its k order (ORC_KPERM): 4 floats per lane and 8-channel group, groups 1 KiB apart.
+    const bool kp = p.kperm != 0;             // uniform
+    const int wgs = kp ? 256 : 4;             // floats between consecutive 4-step weight groups of a lane
     const float *wl[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-        wl[j] = p.w + ((((size_t)wtile(n0, wn * TN + j, p.NT32)) * 64 + lane) << 4);
+    for (int j = 0; j < TN; ++j) {
+        const size_t tile = (size_t)wtile(n0, wn * TN + j, p.NT32);
+        wl[j] = kp ? p.w + tile * 1024 + lane * 4 : p.w + ((tile * 64 + lane) << 4);
+    }
     const size_t wstride = (size_t)p.NT32 << 10;
 
     load_chunk(0);
@@ -249,8 +184,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
     store_chunk(0);
     __syncthreads();
 
-    const int arow = (wm * TM * 32 + (lane & 31)) * ALD + (lane >> 5);
-    IT_STAMP(3)
+    const int arow = (wm * TM * 32 + (lane & 31)) * ALD + (kp ? 4 : 1) * (lane >> 5);
+    auto kofs = [&](int kk) -> int { return kp ? 8 * (kk >> 2) + (kk & 3) : 2 * kk; };       // A column of MFMA step kk (lanes 0-31)
 
     // The loop body is unconditional straight-line code: the last chunk re-loads itself and re-stages it into the idle
     // LDS buffer, so the compiler knows exactly how many loads are in flight at every wait (a conditional load forces a
@@ -266,10 +201,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1, g = kk >> 2, e = kk & 3;
             if (e == 0) {       // prefetch the next 4 k-pairs of weight fragments (next chunk's first 4 at the end)
-                if (DBG_ON(8)) {
-                } else if (g < 3) {
+                if (g < 3) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)c * wstride + 4 * (g + 1));
+                    for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)c * wstride + wgs * (g + 1));
                 } else {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bn[j] = ld4(wl[j] + (size_t)cn * wstride);
@@ -277,11 +211,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
                 // next chunk's A rows: issued right AFTER a weight prefetch.  Loads complete in order, so the first
                 // younger weight load that is waited for (two prefetch groups = 16 MFMAs later) also waits for these
                 // HBM loads; issued before the prefetch they would only get 8 MFMAs of cover.
-                if (kk == 0 && !DBG_ON(4)) load_chunk(cn);
+                if (kk == 0) load_chunk(cn);
             }
             if (kk + 1 < BK / 2) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[nxt][i] = Ab[i * 32 * ALD + 2 * (kk + 1)];
+                for (int i = 0; i < TM; ++i) af[nxt][i] = Ab[i * 32 * ALD + kofs(kk + 1)];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -295,17 +229,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        IT_STAMP(0)
-        if (!DBG_ON(2)) store_chunk(buf ^ 1);
-        IT_STAMP(1)
-        if (!DBG_ON(1)) __syncthreads();
-        IT_STAMP(2)
+        store_chunk(buf ^ 1);
+        __syncthreads();
     }
-#if defined(FEMASR_TAPTIME) && FEMASR_TAPTIME < 2
-    IT_STAMP_ALWAYS(0)
-#endif
 
-    if (!VQ) {
+    {
         // store: out = act(acc + bias) + res1 + res2, in that order (the bit-exact contract).  Address = uniform (tile,
         // wave, i, j, r) part in SGPRs + one per-lane offset.  On full tiles the residuals are loaded as branch-free batches
         // of one 32x32 tile (16 values per lane), ONE TILE AHEAD of the tile being stored: a per-element `load; add; store`
@@ -415,60 +343,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((K1 && BM == 12
         } else if (rb) { if (full) epilogue(I2{}, std::true_type{}); else epilogue(I2{}, std::false_type{}); }
         else if (ra) { if (full) epilogue(I1{}, std::true_type{}); else epilogue(I1{}, std::false_type{}); }
         else { if (full) epilogue(I0{}, std::true_type{}); else epilogue(I0{}, std::false_type{}); }
-    } else {
-        // d = (|z|^2 + |e|^2) - 2 z.e ; first-min over this block's BN columns, per row.
-        float *red = smem;   // [WN][BM][2]  (the A buffers are dead after the loop's last barrier)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowl = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int row = m0 + rowl;
-                const float zz = row < p.M ? p.vq_zz[row] : 0.f;
-                float bd = INFINITY;
-                int bi = 0x7fffffff;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-                    if (col < p.Cout) {
-                        const float d = (zz + p.vq_ee[col]) - 2.0f * acc[i][j][r];
-                        if (d < bd || (d == bd && col < bi)) { bd = d; bi = col; }
-                    }
-                }
-#pragma unroll
-                for (int s = 16; s >= 1; s >>= 1) {
-                    const float od = __shfl_xor(bd, s, 64);
-                    const int oi = __shfl_xor(bi, s, 64);
-                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
-                }
-                if ((lane & 31) == 0) {
-                    red[(wn * BM + rowl) * 2] = bd;
-                    red[(wn * BM + rowl) * 2 + 1] = __int_as_float(bi);
-                }
-            }
-        __syncthreads();
-        if (t < BM && m0 + t < p.M) {
-            float bd = red[t * 2];
-            int bi = __float_as_int(red[t * 2 + 1]);
-#pragma unroll
-            for (int w2 = 1; w2 < WN; ++w2) {
-                const float od = red[(w2 * BM + t) * 2];
-                const int oi = __float_as_int(red[(w2 * BM + t) * 2 + 1]);
-                if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
-            }
-            float *dst = p.vq_part + ((size_t)(m0 + t) * p.vq_nblk + nb) * 2;
-            dst[0] = bd;
-            dst[1] = __int_as_float(bi);
-        }
     }
-#ifdef FEMASR_TAPTIME
-    IT_STAMP_ALWAYS(4)
-    tt[5] = tprev - tstart;
-    if (lane == 0 && K1) {
-        const unsigned slot = (blockIdx.x * (WM * WN) + wave) & 65535u;
-        for (int i = 0; i < 6; ++i) g_igemm_time[slot * 8 + i] += tt[i];
-    }
-#endif
 }
 
 // =================================================================================================================
@@ -665,6 +540,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     auto uoff = [&](int i, int j, int r) -> size_t {            // uniform
         return obase + (size_t)((2 * (wmu * TM + i) + (r >> 3)) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1)) * p.Cout + (wnu * TN + j) * 32;
     };
+    // Fused GroupNorm(32) partial moments of the OUTPUT (consumed by the next conv's GN prologue): fp64 sums of the stored
+    // values in the fixed order of oracle/femasr_oracle.c orc_gn_coeffs - per lane over its 16 accumulator registers
+    // (level 0), the two lane halves (1), the channels of the group (2), the tile's four 32-pixel blocks (3).
+    const bool gnp = p.gn_part != nullptr;
+    double gs[TM][TN], gss[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { gs[i][j] = 0.0; gss[i][j] = 0.0; }
     // edge tiles: the same code with clamped addresses (uniform part -> this tile's first element, lane part -> 0) for the
     // loads and masked stores
     auto epilogue = [&](auto nres_c, auto full_c) {
@@ -703,7 +587,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
                 float v = acc[i][j][r] + bv;
                 if (NRES >= 1) v = v + rbuf[tl % DEPTH][0][r];
                 if (NRES >= 2) v = v + rbuf[tl % DEPTH][NRES >= 2 ? 1 : 0][r];
-                if (ok_l(i, j, r)) stg_u32(p.out + uoff(i, j, r), 4u * loff, v);
+                if (ok_l(i, j, r)) {
+                    stg_u32(p.out + uoff(i, j, r), 4u * loff, v);
+                    if (gnp) {
+                        const double d = (double)v;
+                        gs[i][j] = gs[i][j] + d;
+                        gss[i][j] = __builtin_fma(d, d, gss[i][j]);
+                    }
+                }
             }
             if (NRES > 0 && DEPTH == 1 && tl + 1 < TM * TN) issue(tl + 1, 0);
         }
@@ -714,6 +605,44 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     if (rb) { if (full) epilogue(I2{}, std::true_type{}); else epilogue(I2{}, std::false_type{}); }
     else if (ra) { if (full) epilogue(I1{}, std::true_type{}); else epilogue(I1{}, std::false_type{}); }
     else { if (full) epilogue(I0{}, std::true_type{}); else epilogue(I0{}, std::false_type{}); }
+
+    if (gnp) {      // uniform
+        const int cg = p.Cout >> 5;                          // channels per group (power of two <= 32, checked by the launcher)
+        const int gpb = BN / cg;                             // groups per block (<= 64 here: BN = 32 only serves Cout <= 32)
+        double *red = reinterpret_cast<double *>(smem);      // [4 (q)][gpb][2]; the patch buffers are dead (last loop barrier)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                double a = gs[i][j] + __shfl_xor(gs[i][j], 32, 64);          // level 1: lane halves (commutative: same bits in both)
+                double b = gss[i][j] + __shfl_xor(gss[i][j], 32, 64);
+                for (int d = 1; d < cg; d <<= 1) {                            // level 2: xor-butterfly over the group's channels
+                    a = a + __shfl_xor(a, d, 64);
+                    b = b + __shfl_xor(b, d, 64);
+                }
+                const int cl = (wnu * TN + j) * 32 + (lane & 31);             // channel inside the block
+                if (lane < 32 && (cl & (cg - 1)) == 0) {
+                    double *dst = red + ((size_t)(wmu * TM + i) * gpb + cl / cg) * 2;
+                    dst[0] = a;
+                    dst[1] = b;
+                }
+            }
+        __syncthreads();
+        if (t < gpb) {
+            const int g = n0 / cg + t;
+            if (g < 32) {
+                double S = red[(0 * gpb + t) * 2], SS = red[(0 * gpb + t) * 2 + 1];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {                                // level 3: ((q0 + q1) + q2) + q3
+                    S = S + red[((size_t)q * gpb + t) * 2];
+                    SS = SS + red[((size_t)q * gpb + t) * 2 + 1];
+                }
+                double *dst = p.gn_part + (((size_t)n * p.tilesY * p.tilesX + (size_t)ty * p.tilesX + tx) * 32 + g) * 2;
+                dst[0] = S;
+                dst[1] = SS;
+            }
+        }
+    }
 }
 
 template <bool UP2>
@@ -730,87 +659,67 @@ struct Variant {
     int bm, bn;
     void (*kern)(const ConvParams);
     size_t lds;
-    bool attr_set;
+    unsigned long long attr_devs;       // bit d: MaxDynamicSharedMemorySize set on device d (the attribute is per device)
     int threads;
 };
 
-#define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC, VQ, K1)                                                   \
-    { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",vq=" #VQ ",k1=" #K1 ",waves=" #WM "x" #WN ">",  \
-      BM, BN, conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC, VQ, K1>, conv_lds_bytes<BM>(), false, WM * WN * 64 }
+#define FEMASR_VARIANT(BM, BN, WM, WN, PRO, VEC)                                                            \
+    { "conv_igemm<" #BM "x" #BN "," #PRO ",cinvec=" #VEC ",waves=" #WM "x" #WN ">",                         \
+      BM, BN, conv_igemm_kernel<BM, BN, WM, WN, PRO, VEC>, conv_lds_bytes<BM>(), 0ull, WM * WN * 64 }
 #define FEMASR_HALO(BN, WM, WN, PRO, UP2)                                                                  \
     { "conv3x3_halo<8x16x" #BN "," #PRO ",up2=" #UP2 ",waves=" #WM "x" #WN ">", 128, BN,                   \
-      conv3x3_halo_kernel<BN, WM, WN, PRO, UP2>, halo_lds_bytes<UP2>(), false, WM * WN * 64 }
+      conv3x3_halo_kernel<BN, WM, WN, PRO, UP2>, halo_lds_bytes<UP2>(), 0ull, WM * WN * 64 }
 
 Variant g_variants[] = {
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, false, false),     // 0
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_GN_SILU, true, false, false),  // 1
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_LN, true, false, false),       // 2
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, true, false, false),      // 3
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_GN_SILU, true, false, false),   // 4
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_LN, true, false, false),        // 5
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false, false),      // 6
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_GN_SILU, true, false, false),   // 7
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false, false),        // 8
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, false, false, false),    // 9  generic Cin (in_conv)
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, false, false, false),     // 10
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false, false, false),     // 11
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, true, true),       // 12 VQ distance + argmin (K1 addressing)
-    FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, false),                   // 13 3x3 s1 halo kernels
-    FEMASR_HALO(128, 4, 2, FEMASR_PRO_GN_SILU, false),                // 14
-    FEMASR_HALO(128, 4, 2, FEMASR_PRO_NONE, true),                    // 15 fused nearest-x2
-    FEMASR_HALO(64, 4, 2, FEMASR_PRO_NONE, false),                    // 16
-    FEMASR_HALO(64, 4, 2, FEMASR_PRO_GN_SILU, false),                 // 17
-    FEMASR_HALO(64, 4, 2, FEMASR_PRO_NONE, true),                     // 18
-    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, false),                    // 19 (out_conv, Cout = 3)
-    FEMASR_HALO(32, 4, 1, FEMASR_PRO_GN_SILU, false),                 // 20
-    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, true),                     // 21
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true, false, true),     // 22 1x1 conv / nn.Linear fast addressing
-    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_LN, true, false, true),       // 23
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, true, false, true),      // 24
-    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_LN, true, false, true),        // 25
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true, false, true),      // 26
-    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_LN, true, false, true),        // 27
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_NONE, true, false, true),     // 28 4-wave blocks: 64x64 per wave
-    FEMASR_VARIANT(128, 128, 2, 2, FEMASR_PRO_LN, true, false, true),       // 29
-    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, false),                   // 30 4-wave halo blocks: 64 px x 64 ch per wave
-    FEMASR_HALO(128, 2, 2, FEMASR_PRO_GN_SILU, false),                // 31
-    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, true),                    // 32
-    FEMASR_HALO(64, 2, 2, FEMASR_PRO_NONE, false),                    // 33 (64 px x 32 ch per wave)
-    FEMASR_HALO(64, 2, 2, FEMASR_PRO_GN_SILU, false),                 // 34
-    FEMASR_HALO(64, 2, 2, FEMASR_PRO_NONE, true),                     // 35
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, true),       // 0  general convs, Cin % 32 == 0 (stride-2 convs): cls*2 + pro
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_GN_SILU, true),    // 1
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, true),        // 2
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_GN_SILU, true),     // 3
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, true),        // 4
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_GN_SILU, true),     // 5
+    FEMASR_VARIANT(128, 128, 4, 2, FEMASR_PRO_NONE, false),      // 6  generic Cin (in_conv): 6 + cls
+    FEMASR_VARIANT(128, 64, 4, 2, FEMASR_PRO_NONE, false),       // 7
+    FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false),       // 8
+    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, false),              // 9  3x3 s1 halo kernels, 4 waves of 64 px x 64 ch: 9 + cls*3 + (up2 ? 2 : pro)
+    FEMASR_HALO(128, 2, 2, FEMASR_PRO_GN_SILU, false),           // 10
+    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, true),               // 11 fused nearest-x2
+    FEMASR_HALO(64, 2, 2, FEMASR_PRO_NONE, false),               // 12 (64 px x 32 ch per wave)
+    FEMASR_HALO(64, 2, 2, FEMASR_PRO_GN_SILU, false),            // 13
+    FEMASR_HALO(64, 2, 2, FEMASR_PRO_NONE, true),                // 14
+    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, false),               // 15 (out_conv, Cout = 3): 4 waves of 32 px x 32 ch
+    FEMASR_HALO(32, 4, 1, FEMASR_PRO_GN_SILU, false),            // 16
+    FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, true),                // 17
 };
 constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
+constexpr int kFirstHalo = 9;
 
-bool use_halo(const femasr_conv_args *a, bool vq)
-{
-    return !vq && a->ksz == 3 && a->stride == 1 && a->pad == 1 && (a->Cin % BK) == 0 && a->prologue != FEMASR_PRO_LN &&
-           a->act == FEMASR_ACT_NONE && !(a->up2 && a->prologue != FEMASR_PRO_NONE) &&
-           (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31);
-}
-
-int pick_variant(const femasr_conv_args *a, bool vq)
+int pick_variant(const femasr_conv_args *a)
 {
     const bool vec = (a->Cin % BK) == 0;
-    if (vq) return 12;
     const int cls = a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2);     // BN = 128 / 64 / 32
-    // Cout > 64: 4-wave halo blocks (64 px x 64 ch per wave: half the LDS / weight-fragment reads per MFMA, 4 waves per
+    // Cout > 32: 4-wave halo blocks (64 px x 64 / 32 ch per wave: half the LDS / weight-fragment reads per MFMA, 4 waves per
     // barrier instead of 8; measured +4..9 % over the 8-wave tiling, fused-x2 variant 141 TFLOP/s = 90 % of peak)
-    if (use_halo(a, vq) && cls == 0) return 30 + (a->up2 ? 2 : a->prologue);
-    if (use_halo(a, vq) && cls == 1) return 33 + (a->up2 ? 2 : a->prologue);        // 64 px x 32 ch per wave: +4..8 %
-    if (use_halo(a, vq)) return 13 + cls * 3 + (a->up2 ? 2 : a->prologue);
-    if (!vec) return 9 + cls;
-    const bool k1 = a->ksz == 1 && a->stride == 1 && a->pad == 0 && !a->up2 && a->prologue != FEMASR_PRO_GN_SILU;
-    // Cout > 64 linears (every Swin nn.Linear): 4-wave blocks, 64x64 outputs per wave, 3 blocks per CU - fewer waves per
-    // barrier and half the LDS / weight-fragment reads per MFMA of the 8-wave tiling (measured +5..9 %)
-    if (k1 && cls == 0) return 28 + (a->prologue == FEMASR_PRO_LN ? 1 : 0);
-    if (k1) return 22 + cls * 2 + (a->prologue == FEMASR_PRO_LN ? 1 : 0);
-    return cls * 3 + a->prologue;
+    if (femasr_conv_halo_eligible(a)) return kFirstHalo + cls * 3 + (a->up2 ? 2 : a->prologue);
+    if (!vec) return 6 + cls;
+    return cls * 2 + a->prologue;
 }
 
 }  // namespace
 
-int femasr_conv_variant_count() { return kNumVariants; }
-const char *femasr_conv_variant_name(int v) { return (v >= 0 && v < kNumVariants) ? g_variants[v].name : "?"; }
+// 3x3 stride-1 pad-1 convs with Cin % 32 == 0 run on the halo kernels (shared with model.hip's planner)
+bool femasr_conv_halo_eligible(const femasr_conv_args *a)
+{
+    return a->ksz == 3 && a->stride == 1 && a->pad == 1 && (a->Cin % BK) == 0 && a->prologue != FEMASR_PRO_LN &&
+           a->act == FEMASR_ACT_NONE && !(a->up2 && a->prologue != FEMASR_PRO_NONE) &&
+           (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31);
+}
+
+int femasr_conv_variant_count() { return kNumVariants + femasr_gemm_variant_count(); }
+const char *femasr_conv_variant_name(int v)
+{
+    if (v >= kNumVariants) return femasr_gemm_variant_name(v - kNumVariants);
+    return v >= 0 ? g_variants[v].name : "?";
+}
 
 int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_epilogue *vq,
                          int *variant_out, double *flops_out)
@@ -820,14 +729,23 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     FEMASR_REQUIRE(vq || (a->bias && a->out), "conv2d: bias/out must be set");
     FEMASR_REQUIRE(a->ksz >= 1 && a->ksz <= 7 && (a->stride == 1 || a->stride == 2) && a->pad >= 0,
                    "conv2d: unsupported ksz=%d stride=%d pad=%d", a->ksz, a->stride, a->pad);
-    FEMASR_REQUIRE(a->prologue >= 0 && a->prologue <= 2, "conv2d: bad prologue %d", a->prologue);
+    FEMASR_REQUIRE(a->prologue == FEMASR_PRO_NONE || a->prologue == FEMASR_PRO_GN_SILU,
+                   "conv2d: bad prologue %d (LayerNorm is a separate pass: femasr_layernorm)", a->prologue);
     const int Hv = a->up2 ? 2 * a->H : a->H, Wv = a->up2 ? 2 * a->W : a->W;
     const int Ho = (Hv + 2 * a->pad - a->ksz) / a->stride + 1, Wo = (Wv + 2 * a->pad - a->ksz) / a->stride + 1;
     FEMASR_REQUIRE(Ho == a->Ho && Wo == a->Wo, "conv2d: Ho/Wo mismatch (%d,%d) vs expected (%d,%d)", a->Ho, a->Wo, Ho, Wo);
+    // 1x1 convs / nn.Linear / the VQ distance matrix: the LDS-DMA GEMM (kernels_gemm.hip); its weights are packed by
+    // femasr_repack_oihw in the k-permuted layout that kernel consumes
+    if (femasr_gemm_eligible(a)) {
+        int gv = 0;
+        const int rc = femasr_gemm_launch(s, a, vq, &gv, flops_out);
+        if (variant_out) *variant_out = kNumVariants + gv;
+        return rc;
+    }
+    FEMASR_REQUIRE(!vq, "conv2d: the VQ epilogue needs a 1x1 layer with Cin %% 32 == 0");
     const bool vec = (a->Cin % BK) == 0;
     FEMASR_REQUIRE(vec || a->prologue == FEMASR_PRO_NONE, "conv2d: prologue needs Cin %% 32 == 0 (Cin=%d)", a->Cin);
     if (a->prologue == FEMASR_PRO_GN_SILU) FEMASR_REQUIRE(a->pro_a && a->pro_b, "conv2d: GN prologue needs a,b");
-    if (a->prologue == FEMASR_PRO_LN) FEMASR_REQUIRE(a->pro_a && a->pro_b && a->pro_c, "conv2d: LN prologue needs stats,gamma,beta");
     const long long M = (long long)a->B * Ho * Wo;
     FEMASR_REQUIRE(M < (1ll << 31) - 256, "conv2d: too many output pixels");
 
@@ -838,22 +756,24 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     p.pad = a->pad; p.up2 = a->up2; p.act = a->act; p.Ho = Ho; p.Wo = Wo;
     p.M = (int)M; p.K = a->ksz * a->ksz * a->Cin; p.nchunks = (p.K + BK - 1) / BK; p.taps = a->ksz * a->ksz;
     p.NT32 = (a->Cout + 31) / 32;
-    const int vi = pick_variant(a, vq != nullptr);
+    p.gn_part = a->gn_part;
+    p.kperm = (a->ksz == 1 && vec) ? 1 : 0;       // weights packed by femasr_repack_oihw in the GEMM layout
+    const int vi = pick_variant(a);
     Variant &v = g_variants[vi];
     p.MB = (p.M + v.bm - 1) / v.bm;
     p.NB = (p.Cout + v.bn - 1) / v.bn;
-    if ((vi >= 13 && vi <= 21) || (vi >= 30 && vi <= 35)) {   // halo kernels: 2-D tiles of 8 x 16 output pixels per image
+    if (vi >= kFirstHalo) {   // halo kernels: 2-D tiles of 8 x 16 output pixels per image
         p.tilesX = (Wo + 15) / 16;
         p.tilesY = (Ho + 7) / 8;
         p.MB = a->B * p.tilesX * p.tilesY;
     }
-    if (vq) {
-        FEMASR_REQUIRE(vq->zz && vq->ee && vq->part && vq->nblk == p.NB && (a->Cout % 32) == 0, "vq epilogue: bad args");
-        p.vq_zz = vq->zz; p.vq_ee = vq->ee; p.vq_part = vq->part; p.vq_nblk = vq->nblk;
-    }
-    if (!v.attr_set) {
+    FEMASR_REQUIRE(!a->gn_part || (vi >= kFirstHalo && femasr_gn_fusable(a->Cout)),
+                   "conv2d: gn_part (fused GroupNorm partial moments) needs a 3x3 stride-1 halo conv and 32 | Cout, Cout/32 a power of two <= 32");
+    int dev = 0;
+    FEMASR_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull)) {
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
-        v.attr_set = true;
+        if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
     }
     hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), v.lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());
@@ -861,27 +781,3 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K;
     return FEMASR_OK;
 }
-
-#ifdef FEMASR_TAPTIME
-extern "C" int femasr_debug_set_flags(int flags)
-{
-    hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_flags), &flags, sizeof(int));
-    return 0;
-}
-extern "C" int femasr_debug_igemm_time(unsigned long long *out8, int reset)
-{
-    static unsigned long long host[8 * 65536];
-    if (out8) {
-        hipMemcpyFromSymbol(host, HIP_SYMBOL(g_igemm_time), sizeof(host));
-        for (int i = 0; i < 8; ++i) out8[i] = 0;
-        for (int w = 0; w < 65536; ++w)
-            for (int i = 0; i < 8; ++i) out8[i] += host[w * 8 + i];
-    }
-    if (reset) {
-        void *d = nullptr;
-        hipGetSymbolAddress(&d, HIP_SYMBOL(g_igemm_time));
-        hipMemset(d, 0, sizeof(host));
-    }
-    return 0;
-}
-#endif

@@ -568,11 +568,11 @@ struct Variant16 {
     int bn, threads;
     void (*kern)(const ConvParams, const uint4 *, double *);
     size_t lds;
-    bool attr_set;
+    unsigned long long attr_devs;       // bit d: MaxDynamicSharedMemorySize set on device d (the attribute is per device)
 };
 #define FEMASR_H16(BN, WM, WN, PRO, UP2)                                                        \
     { "conv3x3_halo_bf16x3<8x16x" #BN "," #PRO ",up2=" #UP2 ",waves=" #WM "x" #WN ">", BN, WM * WN * 64,   \
-      conv3x3_halo_bf16x3_kernel<BN, WM, WN, PRO, UP2>, bf16_lds_bytes<BN, UP2>(), false }
+      conv3x3_halo_bf16x3_kernel<BN, WM, WN, PRO, UP2>, bf16_lds_bytes<BN, UP2>(), 0ull }
 
 Variant16 g_v16[] = {
     FEMASR_H16(128, 2, 2, FEMASR_PRO_NONE, false),     // 0   (4 waves: 64 px x 64 ch per wave)
@@ -601,9 +601,11 @@ constexpr int kNum16 = sizeof(g_v16) / sizeof(g_v16[0]);
 int femasr_conv_bf16x3_variant_count() { return kNum16; }
 const char *femasr_conv_bf16x3_variant_name(int v) { return (v >= 0 && v < kNum16) ? g_v16[v].name : "?"; }
 
-bool femasr_conv_bf16x3_eligible(const femasr_conv_args *a)
+bool femasr_conv_bf16x3_eligible(const femasr_conv_args *a) { return a->w_bf16x3 && femasr_conv_bf16x3_shape_ok(a); }
+
+bool femasr_conv_bf16x3_shape_ok(const femasr_conv_args *a)
 {
-    return a->w_bf16x3 && a->ksz == 3 && a->stride == 1 && a->pad == 1 && (a->Cin % BK) == 0 &&
+    return a->ksz == 3 && a->stride == 1 && a->pad == 1 && (a->Cin % BK) == 0 &&
            a->prologue != FEMASR_PRO_LN && a->act == FEMASR_ACT_NONE && !(a->up2 && a->prologue != FEMASR_PRO_NONE) &&
            a->Cin <= 1024 && (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31) &&
            (size_t)a->B * a->H * a->W * (a->up2 ? 4 : 1) * a->Cout < ((size_t)1 << 31);
@@ -630,9 +632,11 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
     p.tilesY = (p.Ho + 7) / 8;
     p.MB = a->B * p.tilesX * p.tilesY;
     p.NB = (a->Cout + v.bn - 1) / v.bn;
-    if (!v.attr_set) {
+    int dev = 0;
+    FEMASR_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull)) {
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds + 40 * 1024));
-        v.attr_set = true;
+        if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
     }
     size_t lds = v.lds + (a->prologue == FEMASR_PRO_GN_SILU ? (size_t)2 * a->Cin * sizeof(float) : 0);
     const size_t epi = 8192 + (size_t)(v.threads / 64) * 32 * 36 * sizeof(float);       // epilogue transpose scratch

@@ -1,0 +1,387 @@
+// kernels_gemm.hip — fp32 GEMM for every 1x1 conv / nn.Linear of the hot path and for the VQ distance matrix:
+//     out[M][N] = epi( A[M][K] . W[K][N] ),   A = NHWC activations / tokens (row-major), W = packed weights
+// (network_swinir.py:19-21,105-112 qkv / proj / fc1 / fc2;  femasr_arch.py:298 before_quant;  femasr_arch.py:35-38 z.e^T)
+//
+// MI355X design (this replaces the K1 variants of conv_igemm_kernel, which staged A through registers):
+//   * BOTH operands reach LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction): no staging VGPRs, no
+//     ds_write, no VALU in the main loop at all — fp32 MFMA shares its lanes with the VALU (SQ_VALU_MFMA_COEXEC = 0),
+//     so every VALU instruction removed from the loop is matrix time won back.
+//   * A tile [128 rows][32 k] per K chunk, one 128-byte line per row, XOR-swizzled by the SOURCE address (the DMA
+//     destination is lane-linear): 16-byte granule g of row r sits at  r*8 + (g ^ ((r>>1)&7))  -> the MFMA A fragment
+//     A[i = lane&31][k-granule 2j + (lane>>5)] is ONE conflict-free ds_read_b128 per lane and row tile.
+//   * W is stored in the order the B fragments are consumed,  [chunk][n/32][j][lane][t]  with
+//     k = 32*chunk + 8j + 4*(lane>>5) + t,  n = 32*(n/32) + (lane&31):  the DMA copy is linear and the fragment read is
+//     one conflict-free ds_read_b128 per lane and column tile.
+//   * One 16-byte fragment feeds 4 MFMA steps: step t multiplies k = 8j + t (lanes 0-31) and k = 8j + 4 + t (lanes 32-63),
+//     i.e. each output is ONE fp32 fmaf chain in the order 0,4,1,5,2,6,3,7 inside every group of 8 channels — the order
+//     oracle/femasr_oracle.c (ORC_KPERM) specifies for these layers, so results stay bit-identical to the CPU oracle.
+//   * 256 threads = 4 waves of 64 x 64 outputs (2 x 2 accumulator tiles of v_mfma_f32_32x32x2_f32); two 32 KB stages
+//     (A 16 KB + W 16 KB), 2 blocks per CU; the DMA of chunk c+2 is issued as soon as every wave has finished reading
+//     chunk c; waits are counted (vmcnt(8): the next chunk's 8 pieces stay in flight across the barrier).
+//   * Epilogue: bias, exact-erf GELU, up to two residuals (order fixed by the bit-exact contract), each 32 x 32 tile
+//     transposed through a per-wave LDS scratch and stored as float4 rows; or the VQ first-min epilogue.
+#include "conv_common.h"
+#include <type_traits>
+#include "detmath.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct GemmParams {
+    const float *A, *W, *bias, *res1, *res2;
+    float *out;
+    const float *vq_zz, *vq_ee;
+    float *vq_part;
+    int vq_nblk;
+    int M, N, K, nchunks, MB, NB, NT32;
+};
+
+constexpr int G_BM = 128, G_BN = 128;
+// Pipeline configuration <KB, ST>: KB = 8-channel groups per K chunk (4: 32-deep chunks, 2: 16-deep), ST = LDS stages.
+//   ST = 2: two barriers per chunk (data landed / stage free again);  ST = 3: one barrier per chunk.
+template <int KB, int ST>
+struct GCfg {
+    static constexpr int kTile = 1024 * KB;                 // floats of one operand tile per stage (128 rows x 8 KB floats)
+    static constexpr int kStage = 2 * kTile;                // A tile + W tile
+    static constexpr int kLdsBytes = (ST * kStage * 4) > (4 * TSCRATCH * 4) ? (ST * kStage * 4) : (4 * TSCRATCH * 4);
+    static constexpr int kBlocksPerCU = (160 * 1024) / kLdsBytes > 4 ? 4 : (160 * 1024) / kLdsBytes;
+};
+
+typedef __attribute__((address_space(3))) void *lds_vptr;
+typedef __attribute__((address_space(1))) const void *glb_cvptr;
+
+__device__ __forceinline__ void dma16(const float *gsrc, float *lds_dst_uniform)
+{
+    // 64 lanes x 16 bytes -> 1 KiB at lds_dst_uniform (wave-uniform) + lane*16
+    __builtin_amdgcn_global_load_lds((glb_cvptr)gsrc, (lds_vptr)lds_dst_uniform, 16, 0, 0);
+}
+
+template <int KB, int ST, int ACT, int NRES, bool VQ>
+__global__ __launch_bounds__(256, (GCfg<KB, ST>::kBlocksPerCU)) void gemm_dma_kernel(const GemmParams p)
+{
+    using C = GCfg<KB, ST>;
+    constexpr int GR = 2 * KB;                 // 16-byte granules per A row and chunk
+    constexpr int RPP = 64 / GR;               // rows per 1 KiB DMA piece
+    constexpr int SW = GR == 8 ? 1 : 2;        // swizzle: granule g of row r sits at r*GR + (g ^ ((r >> SW) & (GR-1)))
+    constexpr int PW = 2 * KB;                 // DMA pieces per wave and stage (KB of A + KB of W)
+    static_assert(KB == 2 || KB == 4, "chunk depth");
+    static_assert(ST == 2 || ST == 3, "stages");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
+    const int nb = L % p.NB, mb = L / p.NB;
+    const int m0 = mb * G_BM, n0 = nb * G_BN;
+    const int h = lane >> 5, c31 = lane & 31;
+
+    // ---- DMA sources.  A piece i of this wave = rows RPP*(KB*wave+i) .. of the tile: lane -> (row, granule).
+    const float *srcA[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+        const int row = RPP * (KB * wave + i) + lane / GR;
+        const int g = (lane & (GR - 1)) ^ ((row >> SW) & (GR - 1));
+        int grow = m0 + row;
+        grow = grow < p.M ? grow : p.M - 1;                 // tail rows: clamp (computed, never stored)
+        srcA[i] = p.A + (size_t)grow * p.K + 4 * g;
+    }
+    // W pieces of column tile (n0/32 + wave): [chunk32][ntile][j = 0..3][lane][t]; a KB = 2 chunk takes j = 2*(c&1) + {0,1}
+    int ntile = (n0 >> 5) + wave;
+    ntile = ntile < p.NT32 ? ntile : p.NT32 - 1;            // tiles past the packed matrix: clamp (never stored)
+    const float *srcW = p.W + ((size_t)ntile * 256 + lane) * 4;
+    const size_t wchunk = (size_t)p.NT32 * 1024;            // floats per 32-deep K chunk of the packed matrix
+
+    auto issue = [&](int sb, int c) {
+        float *dA = smem + sb * C::kStage + wave * (256 * KB);          // this wave's KB A pieces
+        float *dW = smem + sb * C::kStage + C::kTile + wave * (256 * KB);
+#pragma unroll
+        for (int i = 0; i < KB; ++i) dma16(srcA[i] + c * (8 * KB), dA + i * 256);
+        const float *w = KB == 4 ? srcW + (size_t)c * wchunk : srcW + (size_t)(c >> 1) * wchunk + (c & 1) * 512;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) dma16(w + j * 256, dW + j * 256);
+    };
+
+    // ---- fragment addresses (floats inside a stage)
+    const int xq = h ^ ((c31 >> SW) & (GR - 1));
+    int aoff[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) aoff[j] = ((wm * 64 + c31) * GR + ((2 * j) ^ xq)) * 4;
+    const int boff = C::kTile + (wn * 2 * KB) * 256 + lane * 4;
+    constexpr int AROW32 = 32 * GR * 4;        // floats between the two row tiles of a wave
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nch = p.K / (8 * KB);
+    issue(0, 0);
+    issue(1, nch > 1 ? 1 : 0);
+
+    auto compute = [&](const float *S) {
+        f32x4_t af[2][2], bf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const f32x4_t *>(S + aoff[0] + i * AROW32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[0][j] = *reinterpret_cast<const f32x4_t *>(S + boff + j * (256 * KB));
+#pragma unroll
+        for (int g = 0; g < KB; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < KB) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[nxt][i] = *reinterpret_cast<const f32x4_t *>(S + aoff[g + 1 < KB ? g + 1 : 0] + i * AROW32);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4_t *>(S + boff + j * (256 * KB) + (g + 1) * 256);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if constexpr (ST == 2) {
+        for (int c = 0; c < nch; ++c) {
+            if constexpr (PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // this wave's pieces of chunk c have landed ... and every other wave's
+            asm volatile("" ::: "memory");
+            compute(smem + (c & 1) * C::kStage);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads of stage c&1 have RETURNED ...
+            __builtin_amdgcn_s_barrier();                         // ... and every other wave's: the stage may be overwritten
+            asm volatile("" ::: "memory");
+            const int cn = c + 2 < nch ? c + 2 : nch - 1;         // unconditional (keeps the vmcnt count constant); the
+            issue(c & 1, cn);                                     // surplus copies at the end land in a dead stage
+        }
+    } else {
+        int sc = 0, sn = 2;                                       // stage of chunk c / of chunk c+2
+        for (int c = 0; c < nch; ++c) {
+            if constexpr (PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the previous chunk's fragment reads have returned)
+            __builtin_amdgcn_s_barrier();                         // chunk c landed everywhere; stage of chunk c-1 is free everywhere
+            asm volatile("" ::: "memory");
+            const int cn = c + 2 < nch ? c + 2 : nch - 1;
+            issue(sn, cn);                                        // chunk c+2 -> the stage chunk c-1 used
+            compute(smem + sc * C::kStage);
+            sc = sc == 2 ? 0 : sc + 1;
+            sn = sn == 2 ? 0 : sn + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may still be writing LDS when the epilogue re-uses it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    if constexpr (!VQ) {
+        // out = act(acc + bias) + res1 + res2, in that order (bit-exact contract).  Each 32x32 tile goes through a
+        // per-wave LDS scratch so that lane l owns columns 4(l&7)..+3 of tile rows (l>>3) + 8k: float4 loads / stores.
+        float *T = smem + wave * TSCRATCH;
+        const int trow = lane >> 3, tq = lane & 7;
+        const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
+        const bool vec = (p.N & 3) == 0;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const int i = tl >> 1, j = tl & 1;
+            const int rbase = m0 + (wm * 2 + i) * 32, cbase = n0 + (wn * 2 + j) * 32;
+            if (vec) {
+                const int col = cbase + 4 * tq;
+                const bool cok = col < p.N;
+                f32x4_t r1[4], r2[4];
+                if (NRES >= 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = rbase + trow + 8 * k;
+                        const bool ok = cok && row < p.M;
+                        const size_t o = ok ? (size_t)row * p.N + col : 0;
+                        r1[k] = *reinterpret_cast<const f32x4_t *>(ra + o);
+                        if (NRES >= 2) r2[k] = *reinterpret_cast<const f32x4_t *>(rb + o);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TPITCH + c31] = acc[i][j][r];
+                const f32x4_t b4 = *reinterpret_cast<const f32x4_t *>(p.bias + (cok ? col : 0));
+                // (same wave wrote and reads the scratch: LDS ops of one wave complete in order)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4_t a4 = *reinterpret_cast<const f32x4_t *>(T + (trow + 8 * k) * TPITCH + 4 * tq);
+                    float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
+                    if (ACT == FEMASR_ACT_GELU) {         // two at a time on the packed fp32 ALU (bit-identical per element)
+                        const det_f32x2 g0 = det_gelu2(det_f32x2{v[0], v[1]}), g1 = det_gelu2(det_f32x2{v[2], v[3]});
+                        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (NRES >= 1) v[e] = v[e] + r1[k][e];
+                        if (NRES >= 2) v[e] = v[e] + r2[k][e];
+                    }
+                    const int row = rbase + trow + 8 * k;
+                    if (cok && row < p.M)
+                        *reinterpret_cast<f32x4_t *>(p.out + (size_t)row * p.N + col) = f32x4_t{v[0], v[1], v[2], v[3]};
+                }
+            } else {
+                const int col = cbase + c31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < p.M && col < p.N) {
+                        const size_t o = (size_t)row * p.N + col;
+                        float v = acc[i][j][r] + p.bias[col];
+                        if (ACT == FEMASR_ACT_GELU) v = det_gelu(v);
+                        if (NRES >= 1) v = v + ra[o];
+                        if (NRES >= 2) v = v + rb[o];
+                        p.out[o] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        // d = (|z|^2 + |e|^2) - 2 z.e ; first-min over this block's 128 columns, per row (femasr_arch.py:35-38,63-66).
+        float *red = smem;   // [2 (wn)][128 rows][2]  (2 KB)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowl = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = m0 + rowl;
+                const float zz = row < p.M ? p.vq_zz[row] : 0.f;
+                float bd = INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + (wn * 2 + j) * 32 + c31;
+                    if (col < p.N) {
+                        const float d = (zz + p.vq_ee[col]) - 2.0f * acc[i][j][r];
+                        if (d < bd || (d == bd && col < bi)) { bd = d; bi = col; }
+                    }
+                }
+#pragma unroll
+                for (int s = 16; s >= 1; s >>= 1) {
+                    const float od = __shfl_xor(bd, s, 64);
+                    const int oi = __shfl_xor(bi, s, 64);
+                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                }
+                if (c31 == 0) {
+                    red[(wn * G_BM + rowl) * 2] = bd;
+                    red[(wn * G_BM + rowl) * 2 + 1] = __int_as_float(bi);
+                }
+            }
+        __syncthreads();
+        if (t < G_BM && m0 + t < p.M) {
+            float bd = red[t * 2];
+            int bi = __float_as_int(red[t * 2 + 1]);
+            const float od = red[(G_BM + t) * 2];
+            const int oi = __float_as_int(red[(G_BM + t) * 2 + 1]);
+            if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+            float *dst = p.vq_part + ((size_t)(m0 + t) * p.vq_nblk + nb) * 2;
+            dst[0] = bd;
+            dst[1] = __int_as_float(bi);
+        }
+    }
+}
+
+struct GVariant {
+    const char *name;
+    void (*kern)(const GemmParams);
+    int lds;
+    unsigned long long attr_devs;       // bit d: MaxDynamicSharedMemorySize set on device d
+};
+
+#define G_VARIANT(KB, ST, ACT, NRES, VQ) { "gemm_dma<128x128x" #KB "*8,stages=" #ST ",act=" #ACT ",nres=" #NRES ",vq=" #VQ ">", \
+                                            gemm_dma_kernel<KB, ST, ACT, NRES, VQ>, GCfg<KB, ST>::kLdsBytes, 0ull }
+#define G_CFG(KB, ST) G_VARIANT(KB, ST, 0, 0, false), G_VARIANT(KB, ST, 0, 1, false), G_VARIANT(KB, ST, 0, 2, false), \
+                      G_VARIANT(KB, ST, 1, 0, false), G_VARIANT(KB, ST, 1, 1, false), G_VARIANT(KB, ST, 1, 2, false), G_VARIANT(KB, ST, 0, 0, true)
+GVariant g_gv[] = { G_CFG(4, 2), G_CFG(2, 2), G_CFG(2, 3) };
+constexpr int kPerCfg = 7;
+constexpr int kNumG = sizeof(g_gv) / sizeof(g_gv[0]);
+int g_cfg = -1;          // -1: not read yet, -2: automatic, >= 0: forced by FEMASR_GEMM_CFG (A/B runs)
+
+// [chunk][n/32][j][lane][t] <- W[n][k]  (torch (out,in) / OIHW with 1x1 taps), zero padded in n
+__global__ void repack_k1_kernel(const float *__restrict__ in, int O, int I, float *__restrict__ out, size_t total)
+{
+    const int NT32 = (O + 31) / 32;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tt = (int)(i & 3), lane = (int)((i >> 2) & 63), j = (int)((i >> 8) & 3);
+        const size_t rest = i >> 10;
+        const int ntile = (int)(rest % NT32), c = (int)(rest / NT32);
+        const int k = 32 * c + 8 * j + 4 * (lane >> 5) + tt, n = 32 * ntile + (lane & 31);
+        out[i] = n < O ? in[(size_t)n * I + k] : 0.f;
+    }
+}
+
+}  // namespace
+
+bool femasr_gemm_eligible(const femasr_conv_args *a)
+{
+    return a->ksz == 1 && a->stride == 1 && a->pad == 0 && !a->up2 && (a->Cin % 32) == 0 && a->prologue == FEMASR_PRO_NONE;
+}
+
+int femasr_gemm_variant_count() { return kNumG; }
+const char *femasr_gemm_variant_name(int v) { return (v >= 0 && v < kNumG) ? g_gv[v].name : "?"; }
+
+int femasr_repack_k1(hipStream_t s, const float *in, int O, int I, float *out)
+{
+    FEMASR_REQUIRE(in && out && O > 0 && I > 0 && (I % 32) == 0, "repack_k1: bad args");
+    const size_t total = (size_t)I * ((O + 31) / 32) * 32;
+    size_t g = (total + 255) / 256;
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    hipLaunchKernelGGL(repack_k1_kernel, dim3((unsigned)g), dim3(256), 0, s, in, O, I, out, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_epilogue *vq, int *variant_out, double *flops_out)
+{
+    FEMASR_REQUIRE(a && a->in && a->w && femasr_gemm_eligible(a), "gemm: layer is not a 1x1 / linear layer with Cin %% 32 == 0");
+    FEMASR_REQUIRE(vq || (a->bias && a->out), "gemm: bias/out must be set");
+    FEMASR_REQUIRE(a->act == FEMASR_ACT_NONE || a->act == FEMASR_ACT_GELU, "gemm: bad activation %d", a->act);
+    const long long M = (long long)a->B * a->H * a->W;
+    FEMASR_REQUIRE(a->Ho == a->H && a->Wo == a->W, "gemm: Ho/Wo mismatch");
+    FEMASR_REQUIRE(M > 0 && M < (1ll << 31) - 256, "gemm: bad row count");
+    GemmParams p{};
+    p.A = a->in; p.W = a->w; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
+    p.M = (int)M; p.N = a->Cout; p.K = a->Cin; p.nchunks = a->Cin / 32;
+    p.MB = (p.M + G_BM - 1) / G_BM; p.NB = (p.N + G_BN - 1) / G_BN; p.NT32 = (p.N + 31) / 32;
+    int vi;
+    if (vq) {
+        FEMASR_REQUIRE(vq->zz && vq->ee && vq->part && vq->nblk == p.NB && (a->Cout % 32) == 0, "vq epilogue: bad args");
+        p.vq_zz = vq->zz; p.vq_ee = vq->ee; p.vq_part = vq->part; p.vq_nblk = vq->nblk;
+        vi = 6;
+    } else {
+        const int nres = (a->res1 ? 1 : 0) + (a->res2 ? 1 : 0);
+        vi = (a->act == FEMASR_ACT_GELU ? 3 : 0) + nres;
+    }
+    if (g_cfg == -1) {
+        const char *e = getenv("FEMASR_GEMM_CFG");          // A/B runs: force one pipeline configuration
+        g_cfg = e ? atoi(e) : -2;
+        if (g_cfg >= kNumG / kPerCfg) g_cfg = -2;
+    }
+    // Pipeline configuration by tile count: all tiles cost the same, so a launch takes ceil(tiles / resident slots) rounds.
+    // <4,2> (32-deep chunks, 2 blocks per CU) unless the 3-blocks-per-CU configuration <2,3> wastes less of its last round.
+    int cfg = g_cfg;
+    if (cfg < 0) {
+        const double tiles = (double)p.MB * p.NB;
+        auto eff = [&](double slots) { const double r = tiles / slots; return r / (double)(long long)(r + 0.999999); };
+        cfg = eff(768.0) > eff(512.0) + 0.02 ? 2 : 0;
+    }
+    vi += cfg * kPerCfg;
+    GVariant &v = g_gv[vi];
+    int dev = 0;
+    FEMASR_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull)) {
+        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds));
+        if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
+    }
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(256), (size_t)v.lds, s, p);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    if (variant_out) *variant_out = vi;
+    if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)a->Cin;
+    return FEMASR_OK;
+}

@@ -146,7 +146,54 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restri
     }
 }
 
-// Finalise from the per-tile partial moments of the bf16x3 conv epilogue (tolerance-based path: the summation order is
+// Per-(sample, 8x16 tile, group) partial moments in the order of oracle/femasr_oracle.c orc_gn_coeffs (levels 0-3), for
+// tensors that do not come out of a 3x3 halo conv (whose epilogue emits the same partials itself).  One wave per
+// (sample, tile, 32-channel slab): lane = (channel c31, half h) exactly like an MFMA accumulator lane.
+__global__ __launch_bounds__(64) void gn_tile_partials_kernel(const float *__restrict__ x, int H, int W, int C, int tilesX, int tilesY,
+                                                              double *__restrict__ part)
+{
+    const int lane = threadIdx.x, c31 = lane & 31, h = lane >> 5;
+    const int slabs = C >> 5, cg = C >> 5;          // 32 groups: channels per group == number of 32-channel slabs
+    int b = blockIdx.x;
+    const int slab = b % slabs;
+    b /= slabs;
+    const int tx = b % tilesX;
+    b /= tilesX;
+    const int ty = b % tilesY;
+    const int n = b / tilesY;
+    const float *xn = x + (size_t)n * H * W * C + slab * 32 + c31;
+    double S = 0.0, SS = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * q + 4 * h + (r & 3) + 8 * (r >> 2);
+            const int y = 8 * ty + (m >> 4), xx = 16 * tx + (m & 15);
+            if (y < H && xx < W) {
+                const double d = (double)xn[((size_t)y * W + xx) * C];
+                s = s + d;
+                ss = __builtin_fma(d, d, ss);
+            }
+        }
+        s = s + __shfl_xor(s, 32, 64);
+        ss = ss + __shfl_xor(ss, 32, 64);
+        for (int d = 1; d < cg; d <<= 1) {
+            s = s + __shfl_xor(s, d, 64);
+            ss = ss + __shfl_xor(ss, d, 64);
+        }
+        if (q == 0) { S = s; SS = ss; } else { S = S + s; SS = SS + ss; }
+    }
+    const int ch = slab * 32 + c31;
+    if (lane < 32 && (ch & (cg - 1)) == 0) {
+        double *dst = part + ((((size_t)n * tilesY + ty) * tilesX + tx) * 32 + ch / cg) * 2;
+        dst[0] = S;
+        dst[1] = SS;
+    }
+}
+
+// Finalise from the per-tile partial moments (fp32 halo conv epilogue / gn_tile_partials_kernel: exact fixed order,
+// level 4 of orc_gn_coeffs; bf16x3 conv epilogue: tolerance-based path, same finalize) (tolerance-based path: the summation order is
 // free but FIXED, so runs are reproducible).  One wave per (image, group): lane l adds tiles l, l+64, ... then an xor
 // tree - the sequential version above takes 320 us on the 2592-tile 576^2 layers, this one a few us.
 __global__ __launch_bounds__(64) void gn_finalize_partials_kernel(const double *__restrict__ part, int tiles, int H, int W, int C, int G,
@@ -213,6 +260,39 @@ __global__ void ln_stats_kernel(const float *__restrict__ x, long long rows, flo
         stats[2 * row] = mean;
         stats[2 * row + 1] = 1.0f / sqrtf(var + eps);
     }
+}
+
+// y = LayerNorm(x): the moments above, then fmaf((x - mean) * rstd, gamma, beta) (network_swinir.py:243,277).  The
+// normalised tokens are materialised ONCE so that the qkv / fc1 GEMMs can stream raw operand tiles into LDS by DMA.
+__global__ void layernorm_kernel(const float *__restrict__ x, long long rows, const float *__restrict__ gamma,
+                                 const float *__restrict__ beta, float eps, float *__restrict__ y)
+{
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4 v = ld4(x + row * 256 + lane * 4);
+    float s = v.x;
+    s = s + v.y;
+    s = s + v.z;
+    s = s + v.w;
+    const float mean = wave_tree_sum(s) * (1.0f / 256.0f);
+    float d = v.x - mean;
+    float q = d * d;
+    d = v.y - mean;
+    q = __builtin_fmaf(d, d, q);
+    d = v.z - mean;
+    q = __builtin_fmaf(d, d, q);
+    d = v.w - mean;
+    q = __builtin_fmaf(d, d, q);
+    const float var = wave_tree_sum(q) * (1.0f / 256.0f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4 g = ld4(gamma + lane * 4), b = ld4(beta + lane * 4);
+    float4 o;
+    o.x = __builtin_fmaf((v.x - mean) * rstd, g.x, b.x);
+    o.y = __builtin_fmaf((v.y - mean) * rstd, g.y, b.y);
+    o.z = __builtin_fmaf((v.z - mean) * rstd, g.z, b.z);
+    o.w = __builtin_fmaf((v.w - mean) * rstd, g.w, b.w);
+    *reinterpret_cast<float4 *>(y + row * 256 + lane * 4) = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -672,6 +752,13 @@ int femasr_crop_nhwc_to_nchw(void *stream, const float *in, int B, int Hs, int W
     return FEMASR_OK;
 }
 
+size_t femasr_gn_scratch_bytes(int B, int H, int W, int C, int G)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || G <= 0) return 0;
+    if (G == 32 && femasr_gn_fusable(C)) return (size_t)B * ((H + 7) / 8) * ((W + 15) / 16) * 32 * 2 * sizeof(double);
+    return (size_t)B * H * G * 2 * sizeof(double);
+}
+
 int femasr_gn_coeffs(void *stream, const float *x, int B, int H, int W, int C, int G, const float *gamma,
                      const float *beta, float eps, float *a, float *b, void *scratch)
 {
@@ -680,6 +767,13 @@ int femasr_gn_coeffs(void *stream, const float *x, int B, int H, int W, int C, i
     const int cg = C / G;
     hipStream_t s = (hipStream_t)stream;
     double *part = (double *)scratch;
+    if (G == 32 && femasr_gn_fusable(C)) {      // the order the conv epilogues produce (orc_gn_coeffs, tiled branch)
+        const int tilesX = (W + 15) / 16, tilesY = (H + 7) / 8;
+        hipLaunchKernelGGL(gn_tile_partials_kernel, dim3((unsigned)((size_t)B * tilesY * tilesX * (C / 32))), dim3(64), 0, s, x, H, W, C,
+                           tilesX, tilesY, part);
+        FEMASR_CHECK_HIP(hipGetLastError());
+        return femasr_gn_coeffs_from_partials(stream, part, B, tilesX * tilesY, H, W, C, G, gamma, beta, eps, a, b);
+    }
     const size_t total = (size_t)B * H * G;
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     if (cg == 8 && C % 4 == 0)
@@ -716,6 +810,16 @@ int femasr_ln_stats(void *stream, const float *x, int64_t rows, int C, float eps
     FEMASR_REQUIRE(C == 256, "ln_stats: only C == 256 (Swin embed_dim, femasr_arch.py:115) is built, got %d", C);
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                        (long long)rows, eps, stats);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_layernorm(void *stream, const float *x, int64_t rows, int C, const float *gamma, const float *beta, float eps, float *y)
+{
+    FEMASR_REQUIRE(x && y && gamma && beta && rows > 0, "layernorm: bad args");
+    FEMASR_REQUIRE(C == 256, "layernorm: only C == 256 (Swin embed_dim, femasr_arch.py:115) is built, got %d", C);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows,
+                       gamma, beta, eps, y);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }
@@ -792,6 +896,7 @@ size_t femasr_packed_weight_floats(int O, int I, int kh, int kw)
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out)
 {
     FEMASR_REQUIRE(in && out && O > 0 && I > 0 && kh > 0 && kw > 0, "repack: bad args");
+    if (kh == 1 && kw == 1 && (I % 32) == 0) return femasr_repack_k1((hipStream_t)stream, in, O, I, out);   // GEMM layout, same size
     const size_t total = femasr_packed_weight_floats(O, I, kh, kw);
     hipLaunchKernelGGL(repack_oihw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, O, I, kh, kw, out,
                        total);
@@ -825,7 +930,6 @@ int femasr_conv2d(void *stream, const femasr_conv_args *a)
         FEMASR_REQUIRE(femasr_conv_bf16x3_eligible(a), "conv2d: w_bf16x3 given but the layer is not eligible for the bf16x3 path");
         return femasr_conv_bf16x3_launch((hipStream_t)stream, a, nullptr, nullptr);
     }
-    FEMASR_REQUIRE(!a || !a->gn_part, "conv2d: gn_part (fused GroupNorm partial moments) needs the bf16x3 path (w_bf16x3)");
     return femasr_conv2d_launch((hipStream_t)stream, a, nullptr, nullptr, nullptr);
 }
 

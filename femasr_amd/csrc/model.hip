@@ -156,7 +156,7 @@ struct femasr_handle {
 namespace {
 
 enum { SLOT_GN = 0, SLOT_LN, SLOT_ATTN, SLOT_VQ, SLOT_LAYOUT, SLOT_SMALL_COUNT };
-const char *kSmallNames[SLOT_SMALL_COUNT] = {"gn_moments", "ln_moments", "window_attention", "vq(row_sqsum+distance_argmin+finalize)",
+const char *kSmallNames[SLOT_SMALL_COUNT] = {"gn_moments", "layernorm", "window_attention", "vq(row_sqsum+distance_argmin+finalize)",
                                              "pad/crop/gather layout"};
 
 struct Scope {   // event pair around one launch (or a small group of launches)
@@ -330,40 +330,38 @@ struct Ctx {
         const int Hv = o.up2 ? 2 * x.H : x.H, Wv = o.up2 ? 2 * x.W : x.W;
         const int Ho = (Hv + 2 * o.pad - o.ksz) / o.stride + 1, Wo = (Wv + 2 * o.pad - o.ksz) / o.stride + 1;
         T y = alloc_t(x.B, Ho, Wo, cout);
-        // bf16x3 eligibility by shape (same rule as femasr_conv_bf16x3_eligible) so that the dry run plans the same buffers
-        const bool lowp_on = o.lowp && h->decoder_math && o.ksz == 3 && o.stride == 1 && o.pad == 1 && (x.C % 32) == 0 &&
-                             o.pro != FEMASR_PRO_LN && o.act == FEMASR_ACT_NONE && !(o.up2 && o.pro != FEMASR_PRO_NONE);
-        if (o.want_gn && lowp_on && cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0) {
+        // The args struct is populated (shapes; pointers may be null in the dry run) BEFORE the planning decisions, and the
+        // same eligibility helpers decide in the dry and in the real run, so both plan identical buffers.
+        femasr_conv_args a{};
+        a.in = x.p; a.B = x.B; a.H = x.H; a.W = x.W; a.Cin = x.C;
+        a.Cout = cout; a.ksz = o.ksz; a.stride = o.stride; a.pad = o.pad; a.up2 = o.up2;
+        a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
+        a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
+        const void *split = nullptr;
+        if (o.lowp && h->decoder_math) {
+            auto it = h->index.find(prefix + ".weight");
+            if (it != h->index.end()) split = h->specs[it->second].split;
+        }
+        const bool lowp_on = split != nullptr && femasr_conv_bf16x3_shape_ok(&a);
+        const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
+                                   : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
+        if (o.want_gn && gn_ok) {
             y.gn_tiles = ((Ho + 7) / 8) * ((Wo + 15) / 16);
             y.gn_part = (double *)arena->alloc((size_t)x.B * y.gn_tiles * 32 * 2 * sizeof(double));
             if (!y.gn_part && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
         }
         if (rc || dry()) return y;
-        femasr_conv_args a{};
-        a.in = x.p; a.B = x.B; a.H = x.H; a.W = x.W; a.Cin = x.C;
-        a.w = Wt(prefix + ".weight"); a.bias = Wt(prefix + ".bias"); a.Cout = cout;
-        a.ksz = o.ksz; a.stride = o.stride; a.pad = o.pad; a.up2 = o.up2;
-        a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
-        a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
-        if (lowp_on) {
-            auto it = h->index.find(prefix + ".weight");
-            if (it != h->index.end()) a.w_bf16x3 = h->specs[it->second].split;
-        }
+        a.w = Wt(prefix + ".weight"); a.bias = Wt(prefix + ".bias");
+        a.gn_part = y.gn_part;
         if (rc) return y;
-        if (a.w_bf16x3 && femasr_conv_bf16x3_eligible(&a)) {
-            a.gn_part = y.gn_part;
-        } else if (y.gn_part) {      // fell back to the fp32 kernel: nobody writes the partials
-            release(y.gn_part);
-            y.gn_part = nullptr;
-        }
         Scope sc(h, s(), dry(), 0, 0.0, 0.0);
         int variant = 0; double flops = 0;
         int r;
-        if (a.w_bf16x3 && femasr_conv_bf16x3_eligible(&a)) {
+        if (lowp_on) {
+            a.w_bf16x3 = split;
             r = femasr_conv_bf16x3_launch(s(), &a, &variant, &flops);
             variant += femasr_conv_variant_count();
         } else {
-            a.w_bf16x3 = nullptr;
             r = femasr_conv2d_launch(s(), &a, nullptr, &variant, &flops);
         }
         sc.set_slot(SLOT_SMALL_COUNT + variant);
@@ -376,7 +374,7 @@ struct Ctx {
     float *gn(T &x, const std::string &norm_prefix)
     {
         float *ab = alloc_f((size_t)2 * x.B * x.C);
-        if (x.gn_part) {         // moments were accumulated by the producing bf16x3 conv: finalize only
+        if (x.gn_part) {         // moments were accumulated by the producing halo conv's epilogue: finalize only
             if (!rc && !dry()) {
                 Scope sc(h, s(), dry(), SLOT_GN, 0.0, (double)x.B * x.gn_tiles * 32 * 16.0);
                 const int r = femasr_gn_coeffs_from_partials(s(), x.gn_part, x.B, x.gn_tiles, x.H, x.W, x.C, 32, Wt(norm_prefix + ".weight"),
@@ -387,7 +385,7 @@ struct Ctx {
             x.gn_part = nullptr;
             return ab;
         }
-        double *scratch = (double *)arena->alloc((size_t)x.B * x.H * 32 * 2 * sizeof(double));
+        void *scratch = arena->alloc(femasr_gn_scratch_bytes(x.B, x.H, x.W, x.C, 32));
         if (!scratch && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
         if (!rc && !dry()) {
             Scope sc(h, s(), dry(), SLOT_GN, 0.0, (double)x.numel() * 4.0);
@@ -404,7 +402,7 @@ struct Ctx {
     {
         const size_t bc = (size_t)x.B * x.C;
         float *ab = gn(x, p + ".conv.0.norm");
-        ConvOpt o1; o1.pro = FEMASR_PRO_GN_SILU; o1.pa = ab; o1.pb = ab ? ab + bc : nullptr; o1.lowp = lowp; o1.want_gn = lowp;
+        ConvOpt o1; o1.pro = FEMASR_PRO_GN_SILU; o1.pa = ab; o1.pb = ab ? ab + bc : nullptr; o1.lowp = lowp; o1.want_gn = true;
         T u = conv(x, p + ".conv.2", x.C, o1);
         release(ab);
         float *ab2 = gn(u, p + ".conv.3.norm");
@@ -421,16 +419,18 @@ struct Ctx {
     T swin_block(const T &y, int B, int H, int W, const std::string &bp, int shift)
     {
         const int rows = B * H * W, C = 256;
-        float *stats = alloc_f((size_t)rows * 2);
-        auto ln = [&](const T &t) {
-            if (rc || dry()) return;
-            Scope sc(h, s(), dry(), SLOT_LN, 0.0, (double)t.numel() * 4.0);
-            const int r = femasr_ln_stats(s(), t.p, rows, C, 1e-5f, stats);
+        auto ln = [&](const T &t, const std::string &np) {       // normalised tokens, materialised once (read by DMA in the GEMM)
+            T o = alloc_t(1, rows, 1, C);
+            if (rc || dry()) return o;
+            Scope sc(h, s(), dry(), SLOT_LN, 0.0, (double)t.numel() * 8.0);
+            const int r = femasr_layernorm(s(), t.p, rows, C, Wt(np + ".weight"), Wt(np + ".bias"), 1e-5f, o.p);
             if (r && !rc) rc = r;
+            return o;
         };
-        ln(y);
-        ConvOpt oq; oq.ksz = 1; oq.pad = 0; oq.pro = FEMASR_PRO_LN; oq.pa = stats; oq.pb = Wt(bp + ".norm1.weight"); oq.pc = Wt(bp + ".norm1.bias");
-        T qkv = conv(y, bp + ".attn.qkv", 3 * C, oq);
+        T n1 = ln(y, bp + ".norm1");
+        ConvOpt oq; oq.ksz = 1; oq.pad = 0;
+        T qkv = conv(n1, bp + ".attn.qkv", 3 * C, oq);
+        release(n1);
         T att = alloc_t(1, rows, 1, C);
         if (!rc && !dry()) {
             Scope sc(h, s(), dry(), SLOT_ATTN, 4.0 * (double)rows * 64.0 * C, (double)rows * C * 16.0);
@@ -441,15 +441,14 @@ struct Ctx {
         ConvOpt op; op.ksz = 1; op.pad = 0; op.res1 = y.p;
         T y1 = conv(att, bp + ".attn.proj", C, op);
         release(att);
-        ln(y1);
-        ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.pro = FEMASR_PRO_LN; o1.pa = stats; o1.pb = Wt(bp + ".norm2.weight"); o1.pc = Wt(bp + ".norm2.bias");
-        o1.act = FEMASR_ACT_GELU;
-        T hdn = conv(y1, bp + ".mlp.fc1", 4 * C, o1);
+        T n2 = ln(y1, bp + ".norm2");
+        ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.act = FEMASR_ACT_GELU;
+        T hdn = conv(n2, bp + ".mlp.fc1", 4 * C, o1);
+        release(n2);
         ConvOpt o2; o2.ksz = 1; o2.pad = 0; o2.res1 = y1.p;
         T y2 = conv(hdn, bp + ".mlp.fc2", C, o2);
         release(hdn);
         release(y1);
-        release(stats);
         return y2;
     }
 
@@ -477,9 +476,9 @@ struct Ctx {
 
     T up_block(const T &x, const std::string &p, int cout, const float *res2_last, bool lowp = false)   // Upsample x2 -> conv -> RB -> RB
     {
-        ConvOpt o; o.up2 = 1; o.lowp = lowp; o.want_gn = lowp;
+        ConvOpt o; o.up2 = 1; o.lowp = lowp; o.want_gn = true;
         T c = conv(x, p + ".1", cout, o);
-        T r1 = resblock(c, p + ".2", nullptr, true, lowp, lowp);
+        T r1 = resblock(c, p + ".2", nullptr, true, lowp, true);
         return resblock(r1, p + ".3", res2_last, true, lowp, false);
     }
 };
@@ -545,7 +544,7 @@ int run_forward(femasr_handle *h, Arena *arena, hipStream_t stream, const float 
         Ctx::ConvOpt od; od.stride = 2;
         T d = c.conv(t, p + ".0", channels_at(res / 2), od);
         c.release(t);
-        t = c.resblock(d, p + ".1", nullptr, true);
+        t = c.resblock(d, p + ".1", nullptr, true, false, true);
         t = c.resblock(t, p + ".2", nullptr, true);
         res /= 2;
     }

@@ -113,13 +113,15 @@ int femasr_pad_nchw_to_nhwc(void *stream, const float *in, int B, int C, int H, 
 /* crop + layout: NHWC (B,Hs,Ws,C) -> NCHW (B,C,Hc,Wc) top-left (femasr_arch.py:464-465). */
 int femasr_crop_nhwc_to_nchw(void *stream, const float *in, int B, int Hs, int Ws, int C, int Hc, int Wc, float *out);
 
-enum { FEMASR_PRO_NONE = 0, FEMASR_PRO_GN_SILU = 1, FEMASR_PRO_LN = 2 };
+enum { FEMASR_PRO_NONE = 0, FEMASR_PRO_GN_SILU = 1, FEMASR_PRO_LN = 2 /* retired: LayerNorm is femasr_layernorm, a separate pass */ };
 enum { FEMASR_ACT_NONE = 0, FEMASR_ACT_GELU = 1 };
 
-/* Implicit-GEMM convolution / linear on fp32 MFMA.  Replaces nn.Conv2d (femasr_arch.py:150,159,173,
+/* Convolution / linear on fp32 MFMA.  Replaces nn.Conv2d (femasr_arch.py:150,159,173,
  * 203,273,298; fema_utils.py:75,78,90; network_swinir.py:465), nn.Upsample(x2) fused on load
  * (femasr_arch.py:172,202), nn.Linear (network_swinir.py:19-21,105-112; ksz=1 on (1,rows,1,Cin)),
- * GroupNorm-apply+SiLU / LayerNorm-apply fused on load, bias / GELU / residual adds fused on store. */
+ * GroupNorm-apply+SiLU fused on load, bias / GELU / residual adds fused on store.
+ * Kernel families: 3x3 stride-1 pad-1 with Cin % 32 == 0 -> halo kernels; 1x1 stride-1 with Cin % 32 == 0 (every
+ * nn.Linear) -> the LDS-DMA GEMM; everything else -> the general implicit GEMM. */
 typedef struct {
     const float *in;      /* (B,H,W,Cin) NHWC, pre-upsample size */
     int32_t B, H, W, Cin;
@@ -127,9 +129,9 @@ typedef struct {
     const float *bias;    /* [Cout] */
     int32_t Cout, ksz, stride, pad, up2;
     int32_t prologue;     /* FEMASR_PRO_* */
-    const float *pro_a;   /* GN: a[B][Cin]      LN: stats[rows][2] = (mean, rstd) */
-    const float *pro_b;   /* GN: b[B][Cin]      LN: gamma[Cin]                    */
-    const float *pro_c;   /*                    LN: beta[Cin]                     */
+    const float *pro_a;   /* GN: a[B][Cin] */
+    const float *pro_b;   /* GN: b[B][Cin] */
+    const float *pro_c;   /* unused (was LN beta) */
     int32_t act;          /* FEMASR_ACT_* (applied after bias, before residuals) */
     const float *res1;    /* optional (B,Ho,Wo,Cout) added after act   */
     const float *res2;    /* optional second residual                   */
@@ -139,28 +141,35 @@ typedef struct {
                              stride-1 pad-1 conv with Cin % 32 == 0 (no LN prologue / GELU) it runs on the bf16
                              matrix cores with the 3-term hi/lo split (~1e-5 relative, NOT bit-exact); NULL =
                              exact fp32 */
-    double *gn_part;      /* optional, bf16x3 path only: per-(sample, 8x16 tile, group) partial GroupNorm moments
-                             (sum, sum of squares) of the OUTPUT, [B][tilesY*tilesX][32][2] doubles, for
-                             femasr_gn_coeffs_from_partials (saves the separate moments pass over the tensor).
-                             Needs Cout = 32 * {1, 2, 4, 8}; anything else is refused. */
+    double *gn_part;      /* optional, 3x3 stride-1 halo convs (exact fp32 and bf16x3): per-(sample, 8x16 tile, group)
+                             partial GroupNorm(32) moments (sum, sum of squares) of the OUTPUT,
+                             [B][tilesY*tilesX][32][2] doubles, for femasr_gn_coeffs_from_partials (saves the separate
+                             moments pass over the tensor).  fp32 path: exactly the partials of the specified
+                             summation order (bit-identical coefficients to femasr_gn_coeffs); needs Cout/32 a power of
+                             two <= 32 (bf16x3: <= 8); anything else is refused. */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 
 /* GroupNorm(32,eps) moments folded into per-(n,c) scale/shift: y = fmaf(x,a,b) (fema_utils.py:22).
- * scratch: >= B*H*G*2 doubles. */
+ * scratch: >= femasr_gn_scratch_bytes(B,H,W,C,G) bytes. */
+size_t femasr_gn_scratch_bytes(int B, int H, int W, int C, int G);
 int femasr_gn_coeffs(void *stream, const float *x, int B, int H, int W, int C, int G,
                      const float *gamma, const float *beta, float eps, float *a, float *b, void *scratch);
-/* Same as femasr_gn_coeffs, from the partial moments a bf16x3 conv wrote with femasr_conv_args.gn_part
+/* Same as femasr_gn_coeffs, from the partial moments a halo conv wrote with femasr_conv_args.gn_part
  * (tiles = ceil(H/8)*ceil(W/16) of the producing conv's output). */
 int femasr_gn_coeffs_from_partials(void *stream, const double *part, int B, int tiles, int H, int W, int C, int G,
                                    const float *gamma, const float *beta, float eps, float *a, float *b);
 /* LayerNorm(C=256) row moments -> stats[rows][2] = (mean, rstd) (network_swinir.py:199,205). */
 int femasr_ln_stats(void *stream, const float *x, int64_t rows, int C, float eps, float *stats);
+/* y = LayerNorm(x) over the last dim (C = 256): the same moments, then fmaf((x-mean)*rstd, gamma, beta)
+ * (network_swinir.py:243,277: norm1 / norm2 ahead of qkv / fc1). */
+int femasr_layernorm(void *stream, const float *x, int64_t rows, int C, const float *gamma, const float *beta,
+                     float eps, float *y);
 /* 8x8 (shifted-)window multi-head attention incl. rel-pos bias and shift mask
  * (network_swinir.py:114-145, 216-237, 249-272).  qkv (B,H*W,3C) -> out (B,H*W,C), natural token order. */
 int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W, int C, int heads, int shift,
                             const float *table, float *out);
-/* VectorQuantizer.forward (femasr_arch.py:35-38,50-100): z (M,D) rows; cbT = codebook^T [D][n_e];
+/* VectorQuantizer.forward (femasr_arch.py:35-38,50-100): z (M,D) rows; cbT = femasr_repack_oihw(cb, n_e, D, 1, 1);
  * ee[j] = |e_j|^2 (femasr_row_sqsum).  Writes idx (M) int64 first-min, zq (M,D) straight-through.
  * scratch: >= (M*(n_e/128)*2 + M + 64) floats. */
 int femasr_vq(void *stream, const float *z, int64_t M, int D, const float *cb, const float *cbT,
@@ -171,6 +180,8 @@ int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, c
  * and the codebook for femasr_vq):  out[q][ntile][lane][kk], zero padded, with
  *   K index k = ((ci/32)*kh*kw + ky*kw + kx)*32 + ci%32 when I % 32 == 0, else (ky*kw + kx)*I + ci;
  *   q = k/32, kk = (k%32)/2, lane = (k&1)*32 + o%32, ntile = o/32.
+ * 1x1 layers with I % 32 == 0 (kh = kw = 1: nn.Linear, 1x1 convs, the codebook) get the GEMM layout instead:
+ *   out[q][ntile][j][lane][t] = W[o = 32*ntile + lane%32][k = 32q + 8j + 4*(lane/32) + t]   (same size).
  * `out` must hold femasr_packed_weight_floats(O,I,kh,kw) floats. */
 size_t femasr_packed_weight_floats(int O, int I, int kh, int kw);
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out);

@@ -15,6 +15,13 @@ def lib_weight_layout(w_khwc):
     """Oracle layout [kh][kw][Cin][Cout] -> the library's packed FRAGMENT-MAJOR layout (numpy restatement of
     femasr_repack_oihw, include/femasr_hip.h): out[q][ntile][lane][kk], zero padded."""
     kh, kw, cin, cout = w_khwc.shape
+    if kh == 1 and kw == 1 and cin % 32 == 0:       # GEMM layout of the 1x1 / linear layers: [q][ntile][j][lane][t]
+        npad = (cout + 31) // 32 * 32
+        full = np.zeros((cin, npad), np.float32)
+        full[:, :cout] = w_khwc.reshape(cin, cout)
+        # k = 32q + 8j + 4h + t, n = 32*ntile + c:  [q][j][h][t][ntile][c] -> [q][ntile][j][h][c][t]
+        t = full.reshape(cin // 32, 4, 2, 4, npad // 32, 32).transpose(0, 4, 1, 2, 5, 3)
+        return np.ascontiguousarray(t).reshape(-1)
     if cin % 32 == 0:       # K order: channel blocks of 32 outermost
         rows = w_khwc.reshape(kh, kw, cin // 32, 32, cout).transpose(2, 0, 1, 3, 4).reshape(-1, cout)
     else:
@@ -78,7 +85,7 @@ def gn_coeffs(x, gamma, beta, eps=1e-6, groups=32):
     tx, tg, tb = dev(x), dev(gamma), dev(beta)
     a = torch.empty((b, c), dtype=torch.float32, device='cuda')
     bb = torch.empty((b, c), dtype=torch.float32, device='cuda')
-    scratch = torch.empty(b * h * groups * 2, dtype=torch.float64, device='cuda')
+    scratch = torch.empty(int(lib.femasr_gn_scratch_bytes(b, h, w, c, groups)), dtype=torch.uint8, device='cuda')
     _lib.check(lib.femasr_gn_coeffs(None, _lib.ptr(tx), b, h, w, c, groups, _lib.ptr(tg), _lib.ptr(tb), eps,
                                     _lib.ptr(a), _lib.ptr(bb), _lib.ptr(scratch)))
     torch.cuda.synchronize()
@@ -105,6 +112,16 @@ def ln_stats(x, eps=1e-5):
     _lib.check(lib.femasr_ln_stats(None, _lib.ptr(tx), rows, c, eps, _lib.ptr(st)))
     torch.cuda.synchronize()
     return st.cpu().numpy()
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    rows, c = x.shape
+    tx, tg, tb = dev(x), dev(gamma), dev(beta)
+    y = torch.full((rows, c), float('nan'), dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_layernorm(None, _lib.ptr(tx), rows, c, _lib.ptr(tg), _lib.ptr(tb), eps, _lib.ptr(y)))
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
 
 
 def window_attention(qkv, b, h, w, c, heads, shift, table):

@@ -94,7 +94,7 @@ def _lin_cases(seed, n):
 
 @pytest.mark.parametrize('c', _lin_cases(5, 30 * _MULT), ids=lambda c: 'l%(id)d_%(rows)d_%(cin)d_%(cout)d_ln%(ln)d_a%(act)d_r%(nres)d' % c)
 def test_fuzz_linear_bit_exact(cuda_device, c):
-    """1x1 conv / nn.Linear path (igemm K1): ragged row tiles, all epilogue variants (scalar and float4 stores)."""
+    """1x1 conv / nn.Linear path (LDS-DMA GEMM): ragged row tiles, all epilogue variants (scalar and float4 stores)."""
     import gpu_utils as G
     rows, cin, cout = c['rows'], c['cin'], c['cout']
     ln = c['ln'] and cin == 256                         # ln_stats is built for C = 256 (the Swin width)
@@ -103,16 +103,17 @@ def test_fuzz_linear_bit_exact(cuda_device, c):
     bias = synth.uniform(200 + c['id'], 'lzb', (cout,), -0.5, 0.5)
     res = [synth.uniform(200 + c['id'], f'lzr{k}', (rows, cout), -1, 1) for k in range(c['nres'])]
     r1, r2 = (res + [None, None])[:2]
-    xin, pro, prologue = x, (None, None, None), 0
+    xin, xg = x, x
     if ln:
         gamma = synth.uniform(6, 'lzg', (256,), 0.5, 1.5)
         beta = synth.uniform(6, 'lzbe', (256,), -0.5, 0.5)
-        pro, prologue = (G.ln_stats(x), gamma, beta), _lib.PRO_LN
         xin = orc.layernorm(x, gamma, beta)
+        xg = G.layernorm(x, gamma, beta)
+        assert np.array_equal(xg.view(np.uint32), xin.view(np.uint32))
     ref = orc.linear(xin, w, bias, act=c['act'], res=r1)
     if r2 is not None:
         ref = ref + r2                                  # second residual: one more fp32 add, in this order
-    got = G.conv2d(x.reshape(1, rows, 1, cin), w.reshape(1, 1, cin, cout), bias, 1, prologue=prologue, pro=pro, act=c['act'],
+    got = G.conv2d(xg.reshape(1, rows, 1, cin), w.reshape(1, 1, cin, cout), bias, 1, act=c['act'],
                    res1=None if r1 is None else r1.reshape(1, rows, 1, cout),
                    res2=None if r2 is None else r2.reshape(1, rows, 1, cout)).reshape(rows, cout)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f'max-abs {np.abs(got - ref).max():.3e}'
@@ -236,13 +237,8 @@ def test_fuzz_gn_and_ln_moments_bit_exact(cuda_device, seed):
     xl = synth.uniform(700 + seed, 'lx', (rows, 256), off - 4, off + 6)
     g2 = synth.uniform(700 + seed, 'lg', (256,), 0.5, 1.5)
     b2 = synth.uniform(700 + seed, 'lb', (256,), -0.5, 0.5)
-    st = G.ln_stats(xl)
-    # LN is pinned through the linear that consumes the stats (identity-like weights would hide nothing: use a real one)
-    wl = synth.uniform(700 + seed, 'lw', (256, 32), -0.1, 0.1)
-    bl = synth.uniform(700 + seed, 'lbias', (32,), -0.5, 0.5)
-    got = G.conv2d(xl.reshape(1, rows, 1, 256), wl.reshape(1, 1, 256, 32), bl, 1, prologue=_lib.PRO_LN,
-                   pro=(st, g2, b2)).reshape(rows, 32)
-    ref = orc.linear(orc.layernorm(xl, g2, b2), wl, bl)
+    got = G.layernorm(xl, g2, b2)
+    ref = orc.layernorm(xl, g2, b2)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 

@@ -108,7 +108,7 @@ def test_gn_moments_large_and_offset(cuda_device):
 
 @pytest.mark.parametrize('cout,act', [(768, 0), (1024, 1), (256, 0)])
 def test_linear_ln_prologue_gelu(cuda_device, cout, act):
-    """Swin linears: LayerNorm-apply on load (qkv / fc1), exact-erf GELU + residual on store."""
+    """Swin linears: LayerNorm pass (norm1 / norm2) -> LDS-DMA GEMM (qkv / fc1), exact-erf GELU + residual on store."""
     import gpu_utils as G
     rows = 300
     x = synth.uniform(4, 'lx', (rows, 256), -4, 6)
@@ -117,10 +117,12 @@ def test_linear_ln_prologue_gelu(cuda_device, cout, act):
     w = synth.uniform(4, 'lw', (256, cout), -0.1, 0.1)
     bias = synth.uniform(4, 'lbias', (cout,), -0.5, 0.5)
     res = synth.uniform(4, 'lres', (rows, cout), -1, 1) if cout == 256 else None
-    stats = G.ln_stats(x)
-    ref = orc.linear(orc.layernorm(x, gamma, beta), w, bias, act=act, res=res)
-    got = G.conv2d(x.reshape(1, rows, 1, 256), w.reshape(1, 1, 256, cout), bias, 1, prologue=_lib.PRO_LN,
-                   pro=(stats, gamma, beta), act=act, res1=None if res is None else res.reshape(1, rows, 1, cout))
+    xn_ref = orc.layernorm(x, gamma, beta)
+    xn = G.layernorm(x, gamma, beta)
+    _same(xn, xn_ref, 'layernorm')
+    ref = orc.linear(xn_ref, w, bias, act=act, res=res)
+    got = G.conv2d(xn.reshape(1, rows, 1, 256), w.reshape(1, 1, 256, cout), bias, 1, act=act,
+                   res1=None if res is None else res.reshape(1, rows, 1, cout))
     _same(got.reshape(rows, cout), ref, f'linear ln cout={cout} act={act}')
 
 
@@ -232,11 +234,40 @@ def test_conv_bf16x3_fused_gn_moments(cuda_device, cin, cout, shape, up):
     assert np.abs(bb - b_ref).max() <= 2e-5 * max(1.0, np.abs(b_ref).max())
 
 
+@pytest.mark.parametrize('cin,cout,shape,up,nres', [(64, 64, (2, 20, 33), False, 1), (128, 128, (1, 13, 10), False, 2),
+                                                    (256, 256, (1, 9, 12), True, 0), (128, 64, (1, 7, 9), True, 0),
+                                                    (64, 32, (1, 17, 40), False, 0), (32, 512, (1, 8, 16), False, 1)])
+def test_conv_fp32_fused_gn_moments_bit_exact(cuda_device, cin, cout, shape, up, nres):
+    """The exact-fp32 halo conv emits per-tile GroupNorm partial moments of its output in the specified summation order:
+    finalising them gives bit-for-bit the oracle's (a, b) of that output, and so does the standalone moments kernel."""
+    import gpu_utils as G
+    b, h, w = shape
+    x = synth.uniform(18, 'egx', (b, h, w, cin), -2.0, 3.0)
+    wt = synth.uniform(18, 'egw', (3, 3, cin, cout), -0.1, 0.1)
+    bias = synth.uniform(18, 'egb', (cout,), 0.5, 1.5)
+    gamma = synth.uniform(18, 'egg', (cout,), 0.5, 1.5)
+    beta = synth.uniform(18, 'egbe', (cout,), -0.5, 0.5)
+    ho, wo = (2 * h, 2 * w) if up else (h, w)
+    res = [synth.uniform(18, f'egr{k}', (b, ho, wo, cout), -1, 1) for k in range(nres)]
+    r1, r2 = (res + [None, None])[:2]
+    y, part = G.conv2d(x, wt, bias, 3, 1, 1, up, res1=r1, res2=r2, gn_part=True)
+    assert not torch.isnan(part).any()
+    y_ref = orc.conv2d(x, wt, bias, 3, 1, 1, up, res1=r1, res2=r2)
+    _same(y, y_ref, 'conv output')
+    a_ref, b_ref = orc.gn_coeffs(y_ref, gamma, beta)
+    a, bb = G.gn_coeffs_from_partials(part, ho, wo, cout, gamma, beta)
+    _same(a, a_ref, 'fused gn a')
+    _same(bb, b_ref, 'fused gn b')
+    a2, b2 = G.gn_coeffs(y_ref, gamma, beta)
+    _same(a2, a_ref, 'standalone gn a')
+    _same(b2, b_ref, 'standalone gn b')
+
+
 def test_repack_oihw_layout(cuda_device):
     """femasr_repack_oihw (what set_weight runs) == the documented K-major layout."""
     import gpu_utils as G
     lib = _lib.load()
-    for (o, i, k) in ((40, 64, 3), (8, 3, 4), (16, 96, 1)):
+    for (o, i, k) in ((40, 64, 3), (8, 3, 4), (16, 96, 1), (16, 24, 1), (300, 256, 1)):
         w = synth.uniform(9, f'rw{o}{i}{k}', (o, i, k, k), -1, 1)
         tw = G.dev(w)
         out = torch.empty(int(lib.femasr_packed_weight_floats(o, i, k, k)), dtype=torch.float32, device='cuda')

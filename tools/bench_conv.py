@@ -1,5 +1,5 @@
 """Micro-benchmark of ONE conv through the C ABI (femasr_conv2d) with device-resident synthetic tensors.
-Usage: python tools/bench_conv.py B H W Cin Cout [--up2] [--gn] [--res] [--fp32] [--iters N] [--gn-part]
+Usage: python tools/bench_conv.py B H W Cin Cout [--up2] [--gn] [--res] [--fp32] [--k1] [--gelu] [--iters N] [--gn-part]
 Prints ms per launch and algorithmic TFLOP/s.  With FEMASR_SO=tools/dbg/libfemasr_hip_tt.so (tools/build_debug.sh) it also
 prints the per-wave cycle shares and honours FEMASR_BF16_CLS (tile class), FEMASR_DBG / FEMASR_DBG16 (ablation switches)."""
 import argparse
@@ -22,7 +22,6 @@ def main():
     ap.add_argument('--fp32', action='store_true')
     ap.add_argument('--gn-part', action='store_true')
     ap.add_argument('--k1', action='store_true', help='1x1 conv / nn.Linear (fp32 igemm path)')
-    ap.add_argument('--ln', action='store_true')
     ap.add_argument('--gelu', action='store_true')
     ap.add_argument('--iters', type=int, default=10)
     a_ = ap.parse_args()
@@ -51,12 +50,6 @@ def main():
         pb = torch.randn(b, cin, device=dev) * 0.1
         args.prologue = _lib.PRO_GN_SILU; args.pro_a = pa.data_ptr(); args.pro_b = pb.data_ptr()
         keep += [pa, pb]
-    if a_.ln:
-        st = torch.rand(b * h * w, 2, device=dev) + 0.5
-        g_ = torch.rand(cin, device=dev) + 0.5
-        be = torch.randn(cin, device=dev) * 0.1
-        args.prologue = _lib.PRO_LN; args.pro_a = st.data_ptr(); args.pro_b = g_.data_ptr(); args.pro_c = be.data_ptr()
-        keep += [st, g_, be]
     if a_.gelu:
         args.act = _lib.ACT_GELU
     if a_.res:
