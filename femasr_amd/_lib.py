@@ -18,10 +18,14 @@ class FemasrError(RuntimeError):
     pass
 
 
+MAX_CODEBOOKS = 3
+
+
 class Config(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in (
-        'in_channel', 'gt_resolution', 'lq_stage', 'scale_factor', 'use_quantize', 'use_residual',
-        'codebook_scale', 'n_e', 'e_dim', 'device')]
+    _fields_ = ([(n, ctypes.c_int32) for n in ('in_channel', 'gt_resolution', 'lq_stage', 'scale_factor', 'use_quantize',
+                                               'use_residual', 'n_codebooks')] +
+                [(n, ctypes.c_int32 * MAX_CODEBOOKS) for n in ('codebook_scale', 'n_e', 'e_dim')] +
+                [('device', ctypes.c_int32)])
 
 
 class ConvArgs(ctypes.Structure):
@@ -53,6 +57,8 @@ SIGNATURES = {
     'femasr_finalize_weights': (c_int, [vp]),
     'femasr_set_streams': (c_int, [vp, c_int]),
     'femasr_workspace_bytes': (c_int, [vp, c_int, c_int, c_int, c_int, ctypes.POINTER(szt)]),
+    'femasr_forward_shapes': (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                      ctypes.POINTER(c_int * MAX_CODEBOOKS), ctypes.POINTER(c_int * MAX_CODEBOOKS)]),
     'femasr_forward': (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, szt]),
     'femasr_decode_workspace_bytes': (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(szt)]),
     'femasr_decode_indices': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, vp, szt]),
@@ -74,6 +80,7 @@ SIGNATURES = {
     'femasr_vq': (c_int, [vp, vp, c_i64, c_int, vp, vp, vp, c_int, vp, vp, vp]),
     'femasr_row_sqsum': (c_int, [vp, vp, c_i64, c_int, vp]),
     'femasr_codebook_gather': (c_int, [vp, vp, c_i64, c_int, vp, c_int, vp]),
+    'femasr_concat_resize': (c_int, [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'femasr_repack_oihw': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'femasr_packed_weight_floats': (szt, [c_int, c_int, c_int, c_int]),
     'femasr_packed_weight_bf16x3_bytes': (szt, [c_int, c_int, c_int, c_int]),

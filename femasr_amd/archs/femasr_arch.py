@@ -109,12 +109,13 @@ class FeMaSRNet(nn.Module):
                  use_semantic_loss=False, use_residual=True, **ignore_kwargs):
         super().__init__()
         codebook_params = np.array(codebook_params)
-        if codebook_params.ndim != 2 or codebook_params.shape[0] != 1:
-            raise NotImplementedError('MI355X path builds single-codebook configs (codebook_params=[[s,n_e,e_dim]])')
+        if codebook_params.ndim != 2 or codebook_params.shape[1] != 3 or not 1 <= codebook_params.shape[0] <= _lib.MAX_CODEBOOKS:
+            raise ValueError(f'codebook_params must be rows of [scale, n_e, e_dim] (1..{_lib.MAX_CODEBOOKS} rows)')
         if norm_type != 'gn' or act_type != 'silu':
             raise NotImplementedError("MI355X path builds norm_type='gn', act_type='silu' (the published configs)")
         self.codebook_scale = codebook_params[:, 0]
-        n_e, e_dim = int(codebook_params[0, 1]), int(codebook_params[0, 2])
+        codebook_emb_num = codebook_params[:, 1].astype(int)
+        codebook_emb_dim = codebook_params[:, 2].astype(int)
         self.use_quantize = use_quantize
         self.in_channel = in_channel
         self.gt_res = gt_resolution
@@ -158,22 +159,30 @@ class FeMaSRNet(nn.Module):
         self.decoder_group = _seq(*dec)
         self.out_conv = nn.Conv2d(out_ch, 3, 3, 1, 1)
 
-        q = _Holder()
-        q.embedding = nn.Embedding(n_e, e_dim)
-        q.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)       # femasr_arch.py:33
-        self.quantize_group = _seq(q)
-        qc = _CHANNELS[int(self.codebook_scale[0])]
-        self.before_quant_group = _seq(nn.Conv2d(qc, e_dim, 1))
-        aq = _Holder()
-        aq.conv = nn.Conv2d(e_dim, qc, 3, 1, 1)
-        self.after_quant_group = _seq(aq)
-        self._n_e, self._e_dim = n_e, e_dim
+        # multi-scale vector quantisers (femasr_arch.py:277-300)
+        quant, before, after = [], [], []
+        for k in range(codebook_params.shape[0]):
+            n_e, e_dim = int(codebook_emb_num[k]), int(codebook_emb_dim[k])
+            q = _Holder()
+            q.embedding = nn.Embedding(n_e, e_dim)
+            q.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)       # femasr_arch.py:33
+            quant.append(q)
+            qc = _CHANNELS[int(self.codebook_scale[k])]
+            before.append(nn.Conv2d(qc if k == 0 else 2 * qc, e_dim, 1))
+            aq = _Holder()                                              # CombineQuantBlock (fema_utils.py:87-99)
+            aq.conv = nn.Conv2d(e_dim if k == 0 else int(codebook_emb_dim[k - 1]) + e_dim, qc, 3, 1, 1)
+            after.append(aq)
+        self.quantize_group = _seq(*quant)
+        self.before_quant_group = _seq(*before)
+        self.after_quant_group = _seq(*after)
+        self._cb = [(int(s_), int(n), int(d)) for s_, n, d in zip(self.codebook_scale, codebook_emb_num, codebook_emb_dim)]
 
         for p in self.parameters():
             p.requires_grad_(False)
         self._handle = None
         self._handle_device = None
         self._pushed = {}
+        self._weights_dirty = True      # set by load_state_dict / .to() / invalidate_weights(): re-scan the state dict
         self._ws = None
         self.max_tile_batch = 16        # tiles per batched test() call inside test_tile
         self.num_streams = 1            # sub-batch streams inside one forward (femasr_set_streams)
@@ -181,6 +190,27 @@ class FeMaSRNet(nn.Module):
         # 'fp32': every layer exact fp32 (bit-identical to the oracle).  'bf16x3': the convs BEHIND the codebook lookup
         # run on the bf16 matrix cores with a 3-term hi/lo split (output within the 1e-3 bound, indices unaffected)
         self.decoder_math = 'fp32'
+
+    # ------------------------------------------------------------------ weight change tracking
+    # The native handle holds REPACKED COPIES of the weights.  Changes made through the nn.Module API are seen
+    # (load_state_dict, .to()/.cuda()/.float(), any in-place op on a parameter, which bumps its version counter);
+    # writes through `.data` (p.data.copy_(...)) are invisible to torch's version counter: call invalidate_weights().
+    def invalidate_weights(self):
+        """Force every weight to be re-pushed to the native handle on the next forward."""
+        self._pushed = {}
+        self._weights_dirty = True
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._weights_dirty = True
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._weights_dirty = True
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._weights_dirty = True
+        return super()._apply(fn, *args, **kwargs)
 
     # ------------------------------------------------------------------ native handle
     def _native(self, device):
@@ -192,30 +222,45 @@ class FeMaSRNet(nn.Module):
         dev_index = device.index if device.index is not None else torch.cuda.current_device()
         if self._handle is None or self._handle_device != dev_index:
             self._release()
-            cfg = _lib.Config(self.in_channel, self.gt_res, int(self.LQ_stage), int(self.scale_factor),
-                              int(self.use_quantize), int(self.use_residual), int(self.codebook_scale[0]),
-                              self._n_e, self._e_dim, dev_index)
+            cfg = _lib.Config()
+            cfg.in_channel, cfg.gt_resolution, cfg.lq_stage = self.in_channel, self.gt_res, int(self.LQ_stage)
+            cfg.scale_factor, cfg.use_quantize, cfg.use_residual = int(self.scale_factor), int(self.use_quantize), int(self.use_residual)
+            cfg.n_codebooks = len(self._cb)
+            for k, (sc, n_e, e_dim) in enumerate(self._cb):
+                cfg.codebook_scale[k], cfg.n_e[k], cfg.e_dim[k] = sc, n_e, e_dim
+            cfg.device = dev_index
             h = ctypes.c_void_p()
             _lib.check(lib.femasr_create(ctypes.byref(cfg), ctypes.byref(h)))
             self._handle, self._handle_device, self._pushed = h, dev_index, {}
-        dirty = False
-        for key, t in self.state_dict().items():
-            if key.endswith('relative_position_index') or key.endswith('attn_mask'):
-                continue
-            if t.device.type != 'cuda':
-                raise _lib.FemasrError(f'parameter {key} is on {t.device}; call .to("cuda") on the module')
-            stamp = (t.data_ptr(), t._version)
-            if self._pushed.get(key) == stamp:
-                continue
-            if not dirty:
-                torch.cuda.synchronize(device)
-                dirty = True
-            src = t.detach().to(torch.float32).contiguous()
-            shape = (ctypes.c_int64 * src.dim())(*src.shape)
-            _lib.check(lib.femasr_set_weight(self._handle, key.encode(), _lib.ptr(src), shape, src.dim()))
-            self._pushed[key] = stamp
-        if dirty:
-            _lib.check(lib.femasr_finalize_weights(self._handle))
+            self._weights_dirty = True
+        # the walk over the (~480-tensor) state dict only runs when something may have changed; otherwise a cheap scan of
+        # the parameters' version counters (in-place updates) decides
+        if not self._weights_dirty:
+            vsum = 0
+            for p_ in self.parameters():
+                vsum += p_._version
+            self._weights_dirty = vsum != self._version_sum
+        if self._weights_dirty:
+            dirty = False
+            for key, t in self.state_dict().items():
+                if key.endswith('relative_position_index') or key.endswith('attn_mask'):
+                    continue
+                if t.device.type != 'cuda':
+                    raise _lib.FemasrError(f'parameter {key} is on {t.device}; call .to("cuda") on the module')
+                stamp = (t.data_ptr(), t._version)
+                if self._pushed.get(key) == stamp:
+                    continue
+                if not dirty:
+                    torch.cuda.synchronize(device)
+                    dirty = True
+                src = t.detach().to(torch.float32).contiguous()
+                shape = (ctypes.c_int64 * src.dim())(*src.shape)
+                _lib.check(lib.femasr_set_weight(self._handle, key.encode(), _lib.ptr(src), shape, src.dim()))
+                self._pushed[key] = stamp
+            if dirty:
+                _lib.check(lib.femasr_finalize_weights(self._handle))
+            self._version_sum = sum(p_._version for p_ in self.parameters())
+            self._weights_dirty = False
         if self._streams_set != (self._handle.value, self.num_streams, self.decoder_math):
             if self.decoder_math not in ('fp32', 'bf16x3'):
                 raise ValueError(f"decoder_math must be 'fp32' or 'bf16x3', got {self.decoder_math!r}")
@@ -264,26 +309,23 @@ class FeMaSRNet(nn.Module):
         lib, h = self._native(x.device)
         x = x.detach().to(torch.float32).contiguous()
         b, _, hh, ww = x.shape
-        s = self.scale_factor
+        oh, ow, nq = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        qh, qw = (ctypes.c_int * _lib.MAX_CODEBOOKS)(), (ctypes.c_int * _lib.MAX_CODEBOOKS)()
+        _lib.check(lib.femasr_forward_shapes(h, hh, ww, pad_mode, ctypes.byref(oh), ctypes.byref(ow), ctypes.byref(nq),
+                                             ctypes.byref(qh), ctypes.byref(qw)))
         nbytes = ctypes.c_size_t()
         _lib.check(lib.femasr_workspace_bytes(h, b, hh, ww, pad_mode, ctypes.byref(nbytes)))
         ws = self._workspace(nbytes.value, x.device)
-        if pad_mode:
-            ph, pw = tiling.padded_hw(hh, ww, s)
-            oh, ow = hh * s, ww * s
-        else:
-            ph, pw = hh, ww
-            oh, ow = hh * s, ww * s
-        down = 2 ** self._encode_depth
-        qh, qw = ph // down, pw // down
-        if not pad_mode and (hh % (down * (8 if self.LQ_stage else 1)) or ww % (down * (8 if self.LQ_stage else 1))):
-            raise ValueError(f'forward(): H,W must be multiples of {down * (8 if self.LQ_stage else 1)}; use test() for '
-                             'arbitrary sizes')
-        out = torch.empty((b, 3, oh, ow), dtype=torch.float32, device=x.device)
-        idx = torch.empty((b, 1, qh, qw), dtype=torch.int64, device=x.device)
+        out = torch.empty((b, 3, oh.value, ow.value), dtype=torch.float32, device=x.device)
+        sizes = [b * qh[k] * qw[k] for k in range(nq.value)]
+        idx_all = torch.empty((sum(sizes),), dtype=torch.int64, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(lib.femasr_forward(h, ctypes.c_void_p(stream), _lib.ptr(x), b, hh, ww, pad_mode,
-                                      _lib.ptr(out), _lib.ptr(idx), _lib.ptr(ws), ws.numel()))
+                                      _lib.ptr(out), _lib.ptr(idx_all), _lib.ptr(ws), ws.numel()))
+        idx, off = [], 0
+        for k in range(nq.value):
+            idx.append(idx_all[off:off + sizes[k]].view(b, 1, qh[k], qw[k]))
+            off += sizes[k]
         return out, idx
 
     @torch.no_grad()
@@ -292,7 +334,7 @@ class FeMaSRNet(nn.Module):
             raise NotImplementedError('gt_indices is a training-time input (femasr_arch.py:339-340)')
         out, idx = self._run(input, 0)
         zero = out.new_zeros(())
-        return out, zero, zero, [idx]
+        return out, zero, zero, idx
 
     @torch.no_grad()
     def forward(self, input, gt_indices=None):
@@ -306,6 +348,12 @@ class FeMaSRNet(nn.Module):
 
     @torch.no_grad()
     def test_with_indices(self, input):
+        """(output, index map of the first codebook) through test()'s pad / crop geometry."""
+        out, idx = self._run(input, 1)
+        return out, idx[0]
+
+    @torch.no_grad()
+    def test_with_all_indices(self, input):
         return self._run(input, 1)
 
     @torch.no_grad()

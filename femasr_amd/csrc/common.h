@@ -37,6 +37,13 @@ bool femasr_conv_halo_eligible(const femasr_conv_args *a);      // 3x3 s1 p1, Ci
 // fused GroupNorm(32) partial moments in a halo conv's epilogue: channels per group a power of two <= 32
 inline bool femasr_gn_fusable(int cout) { const int cg = cout / 32; return cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0; }
 
+// convs with <= 4 output channels and a 3x3 stride-1 halo shape (out_conv) keep a compact [k][4] weight copy behind the
+// fragment-major matrix for the direct VALU kernel (an MFMA tile would compute 32 columns for 3)
+inline size_t femasr_compact_weight_floats(int O, int I, int kh, int kw)
+{
+    return (O <= 4 && kh == 3 && kw == 3 && (I % 32) == 0) ? (size_t)I * 9 * 4 : 0;
+}
+
 // 1x1 convs / nn.Linear / VQ distance matrix on the LDS-DMA GEMM (kernels_gemm.hip)
 bool femasr_gemm_eligible(const femasr_conv_args *a);
 int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_epilogue *vq, int *variant_out, double *flops_out);

@@ -645,6 +645,71 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     }
 }
 
+// =================================================================================================================
+// conv3x3_cout3: 3x3 stride-1 pad-1 conv with 3 output channels (out_conv, femasr_arch.py:273) on the VALU.
+// An MFMA tile would compute 32 output columns to keep 3 (10.7x the algorithmic work: 1.7 ms of the B = 16 step); here one
+// thread owns one pixel and its 3 fmaf chains (same k order as everywhere: 32-channel blocks outermost, then the 9 taps),
+// activations come from an LDS halo patch as 16-byte reads (pitch 36 floats: conflict-free), the weights sit in SGPRs
+// (compact [k][4] array read with scalar loads; `v_fmac_f32 v, s, v`).  8 x 32 pixels per block.
+// =================================================================================================================
+constexpr int C3_TH = 8, C3_TW = 32, C3_PW = C3_TW + 2, C3_PP = (C3_TH + 2) * C3_PW, C3_PITCH = 36;
+
+__global__ __launch_bounds__(256) void conv3x3_cout3_kernel(const ConvParams p, const float *__restrict__ wc)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [C3_PP][C3_PITCH]
+    const int t = threadIdx.x;
+    int tile = blockIdx.x;
+    const int tx = tile % p.tilesX;
+    tile /= p.tilesX;
+    const int ty = tile % p.tilesY;
+    const int n = tile / p.tilesY;
+    const int oy0 = ty * C3_TH, ox0 = tx * C3_TW;
+    const int py = t >> 5, px = t & 31;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    const int ncb = p.Cin >> 5;
+    for (int cb = 0; cb < ncb; ++cb) {
+        if (cb) __syncthreads();
+        // stage the (8+2) x (32+2) halo patch of channel block cb (zero outside the image)
+        for (int u = t; u < C3_PP * 8; u += 256) {
+            const int pix = u >> 3, kq = u & 7;
+            const int sy = oy0 - 1 + pix / C3_PW, sx = ox0 - 1 + pix % C3_PW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+                v = ld4(p.in + (((size_t)n * p.H + sy) * p.W + sx) * p.Cin + cb * 32 + 4 * kq);
+            *reinterpret_cast<float4 *>(smem + pix * C3_PITCH + 4 * kq) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float *src = smem + ((py + tap / 3) * C3_PW + px + tap % 3) * C3_PITCH;
+            const float *w = wc + ((size_t)(cb * 9 + tap) * 32) * 4;      // uniform: scalar loads
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) {
+                const float4 x4 = *reinterpret_cast<const float4 *>(src + 4 * c4);
+                const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float *wk = w + (4 * c4 + e) * 4;
+                    acc0 = __builtin_fmaf(xs[e], wk[0], acc0);
+                    acc1 = __builtin_fmaf(xs[e], wk[1], acc1);
+                    acc2 = __builtin_fmaf(xs[e], wk[2], acc2);
+                }
+            }
+        }
+    }
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy < p.Ho && ox < p.Wo) {
+        const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * 3;
+        float v[3] = {acc0 + p.bias[0], acc1 + p.bias[1], acc2 + p.bias[2]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (p.res1) v[c] = v[c] + p.res1[o + c];
+            if (p.res2) v[c] = v[c] + p.res2[o + c];
+            p.out[o + c] = v[c];
+        }
+    }
+}
+
 template <bool UP2>
 constexpr size_t halo_lds_bytes()
 {
@@ -689,6 +754,7 @@ Variant g_variants[] = {
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, false),               // 15 (out_conv, Cout = 3): 4 waves of 32 px x 32 ch
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_GN_SILU, false),            // 16
     FEMASR_HALO(32, 4, 1, FEMASR_PRO_NONE, true),                // 17
+    { "conv3x3_cout3<8x32,valu>", 256, 4, nullptr, (size_t)C3_PP * C3_PITCH * sizeof(float), 0ull, 256 },      // 18 out_conv (own launcher branch)
 };
 constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr int kFirstHalo = 9;
@@ -758,6 +824,20 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     p.NT32 = (a->Cout + 31) / 32;
     p.gn_part = a->gn_part;
     p.kperm = (a->ksz == 1 && vec) ? 1 : 0;       // weights packed by femasr_repack_oihw in the GEMM layout
+    if (femasr_conv_halo_eligible(a) && a->Cout == 3 && !a->up2 && a->prologue == FEMASR_PRO_NONE && !a->gn_part) {
+        // out_conv: direct VALU kernel on the compact [k][4] weights stored behind the fragment-major matrix
+        const size_t tail = femasr_compact_weight_floats(a->Cout, a->Cin, 3, 3);
+        const float *wc = a->w + (size_t)p.nchunks * p.NT32 * 1024;
+        p.tilesX = (Wo + C3_TW - 1) / C3_TW;
+        p.tilesY = (Ho + C3_TH - 1) / C3_TH;
+        (void)tail;
+        hipLaunchKernelGGL(conv3x3_cout3_kernel, dim3((unsigned)(a->B * p.tilesX * p.tilesY)), dim3(256), (size_t)C3_PP * C3_PITCH * sizeof(float), s,
+                           p, wc);
+        FEMASR_CHECK_HIP(hipGetLastError());
+        if (variant_out) *variant_out = kNumVariants - 1;
+        if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K;
+        return FEMASR_OK;
+    }
     const int vi = pick_variant(a);
     Variant &v = g_variants[vi];
     p.MB = (p.M + v.bm - 1) / v.bm;

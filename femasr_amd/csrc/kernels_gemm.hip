@@ -15,9 +15,15 @@
 //   * One 16-byte fragment feeds 4 MFMA steps: step t multiplies k = 8j + t (lanes 0-31) and k = 8j + 4 + t (lanes 32-63),
 //     i.e. each output is ONE fp32 fmaf chain in the order 0,4,1,5,2,6,3,7 inside every group of 8 channels — the order
 //     oracle/femasr_oracle.c (ORC_KPERM) specifies for these layers, so results stay bit-identical to the CPU oracle.
-//   * 256 threads = 4 waves of 64 x 64 outputs (2 x 2 accumulator tiles of v_mfma_f32_32x32x2_f32); two 32 KB stages
-//     (A 16 KB + W 16 KB), 2 blocks per CU; the DMA of chunk c+2 is issued as soon as every wave has finished reading
-//     chunk c; waits are counted (vmcnt(8): the next chunk's 8 pieces stay in flight across the barrier).
+//   * 256 threads = 4 waves of 64 x 64 outputs (2 x 2 accumulator tiles of v_mfma_f32_32x32x2_f32).  Two pipeline
+//     configurations, chosen per launch by which wastes less of its last round of (equal-cost) tiles:
+//       <KB=4, ST=2>  32-deep chunks, two 32 KB stages, 2 blocks per CU, two barriers per chunk (landed / free again);
+//       <KB=2, ST=3>  16-deep chunks, three 16 KB stages, 3 blocks per CU, one barrier per chunk.
+//     Waits are counted (vmcnt(8) / vmcnt(4): the next chunk's pieces stay in flight across the barrier); fragment
+//     double buffering is pinned with sched_barrier.
+//   * Measured (B = 16, M = 82944): all pipeline shapes tried - these two, 4 blocks per CU, and a persistent block with
+//     cross-tile prefetch - land within 2 % of each other (MFMA busy 0.66-0.74 in the network at 2.4 GHz); ablations
+//     price the epilogue stores at ~10 %, the A and W DMA at 5-8 % each, the barriers at 0.
 //   * Epilogue: bias, exact-erf GELU, up to two residuals (order fixed by the bit-exact contract), each 32 x 32 tile
 //     transposed through a per-wave LDS scratch and stored as float4 rows; or the VQ first-min epilogue.
 #include "conv_common.h"
@@ -124,6 +130,8 @@ __global__ __launch_bounds__(256, (GCfg<KB, ST>::kBlocksPerCU)) void gemm_dma_ke
     issue(0, 0);
     issue(1, nch > 1 ? 1 : 0);
 
+    // Fragment double buffering is PINNED with sched_barrier(0): left alone, the scheduler funnels both fragment sets through
+    // one register set (load -> wait -> 16 MFMAs -> load -> wait ...), exposing an LDS round trip per 8-channel group.
     auto compute = [&](const float *S) {
         f32x4_t af[2][2], bf[2][2];
 #pragma unroll
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(256, (GCfg<KB, ST>::kBlocksPerCU)) void gemm_dma_ke
 #pragma unroll
                 for (int j = 0; j < 2; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4_t *>(S + boff + j * (256 * KB) + (g + 1) * 256);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(256, (GCfg<KB, ST>::kBlocksPerCU)) void gemm_dma_ke
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -298,10 +308,10 @@ struct GVariant {
                                             gemm_dma_kernel<KB, ST, ACT, NRES, VQ>, GCfg<KB, ST>::kLdsBytes, 0ull }
 #define G_CFG(KB, ST) G_VARIANT(KB, ST, 0, 0, false), G_VARIANT(KB, ST, 0, 1, false), G_VARIANT(KB, ST, 0, 2, false), \
                       G_VARIANT(KB, ST, 1, 0, false), G_VARIANT(KB, ST, 1, 1, false), G_VARIANT(KB, ST, 1, 2, false), G_VARIANT(KB, ST, 0, 0, true)
-GVariant g_gv[] = { G_CFG(4, 2), G_CFG(2, 2), G_CFG(2, 3) };
+GVariant g_gv[] = { G_CFG(4, 2), G_CFG(2, 3) };
 constexpr int kPerCfg = 7;
 constexpr int kNumG = sizeof(g_gv) / sizeof(g_gv[0]);
-int g_cfg = -1;          // -1: not read yet, -2: automatic, >= 0: forced by FEMASR_GEMM_CFG (A/B runs)
+int g_cfg = -1;          // -1: not read yet, -2: automatic, 0 / 1: forced by FEMASR_GEMM_CFG (A/B runs)
 
 // [chunk][n/32][j][lane][t] <- W[n][k]  (torch (out,in) / OIHW with 1x1 taps), zero padded in n
 __global__ void repack_k1_kernel(const float *__restrict__ in, int O, int I, float *__restrict__ out, size_t total)
@@ -369,7 +379,7 @@ int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_e
     if (cfg < 0) {
         const double tiles = (double)p.MB * p.NB;
         auto eff = [&](double slots) { const double r = tiles / slots; return r / (double)(long long)(r + 0.999999); };
-        cfg = eff(768.0) > eff(512.0) + 0.02 ? 2 : 0;
+        cfg = eff(768.0) > eff(512.0) + 0.02 ? 1 : 0;
     }
     vi += cfg * kPerCfg;
     GVariant &v = g_gv[vi];

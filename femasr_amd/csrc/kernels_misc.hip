@@ -682,6 +682,20 @@ __global__ void repack_oihw_kernel(const float *__restrict__ in, int O, int I, i
     }
 }
 
+// compact [k][4] weights of a conv with <= 4 output channels, k in the blocked order above (zero padded to 4 columns)
+__global__ void repack_compact_kernel(const float *__restrict__ in, int O, int I, int kh, int kw, float *__restrict__ out, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i & 3), k = (int)(i >> 2);
+        const int cl = k % 32;
+        int r = k / 32;
+        const int x = r % kw;
+        r /= kw;
+        const int y = r % kh, ci = (r / kh) * 32 + cl;
+        out[i] = o < O ? in[(((size_t)o * I + ci) * kh + y) * kw + x] : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // image pre / post-processing on the GPU (the steps either side of the path)
 // ------------------------------------------------------------------------------------------
@@ -714,6 +728,29 @@ __global__ void image_f32_to_u8_kernel(const float *__restrict__ in, int H, int 
         v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);       // NaN -> 1 like neither; NaNs never reach here on finite inputs
         if (!(v == v)) v = 0.f;
         out[i] = (unsigned char)rintf(v * 255.0f);
+    }
+}
+
+// out[n,y,x,:] = cat(a[n,y,x,:Ca], b[n, y*Hb/H, x*Wb/W, :Cb]); one thread per float4 of the output (Ca, Cb % 4 == 0)
+__global__ void concat_resize_kernel(const float *__restrict__ a, int Ca, const float *__restrict__ b, int Hb, int Wb, int Cb,
+                                     int H, int W, float *__restrict__ out, size_t total4)
+{
+    const int C4 = (Ca + Cb) >> 2, Ca4 = Ca >> 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t r = i / C4;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const size_t n = r / H;
+        float4 v;
+        if (c4 < Ca4) {
+            v = ld4(a + ((n * H + y) * W + x) * Ca + 4 * c4);
+        } else {
+            const int sy = (int)(((long long)y * Hb) / H), sx = (int)(((long long)x * Wb) / W);
+            v = ld4(b + ((n * Hb + sy) * Wb + sx) * Cb + 4 * (c4 - Ca4));
+        }
+        *reinterpret_cast<float4 *>(out + i * 4) = v;
     }
 }
 
@@ -886,18 +923,34 @@ int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, c
     return FEMASR_OK;
 }
 
+int femasr_concat_resize(void *stream, const float *a, int Ca, const float *b, int Hb, int Wb, int Cb, int B, int H, int W, float *out)
+{
+    FEMASR_REQUIRE(a && b && out && B > 0 && H > 0 && W > 0 && Hb > 0 && Wb > 0, "concat_resize: bad args");
+    FEMASR_REQUIRE(Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0, "concat_resize: channel counts must be multiples of 4 (%d, %d)", Ca, Cb);
+    const size_t total4 = (size_t)B * H * W * ((Ca + Cb) / 4);
+    hipLaunchKernelGGL(concat_resize_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, a, Ca, b, Hb, Wb, Cb, H, W, out,
+                       total4);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
 size_t femasr_packed_weight_floats(int O, int I, int kh, int kw)
 {
     if (O <= 0 || I <= 0 || kh <= 0 || kw <= 0) return 0;
     const size_t K = (size_t)I * kh * kw;
-    return ((K + 31) / 32) * (size_t)((O + 31) / 32) * 1024;
+    return ((K + 31) / 32) * (size_t)((O + 31) / 32) * 1024 + femasr_compact_weight_floats(O, I, kh, kw);
 }
 
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out)
 {
     FEMASR_REQUIRE(in && out && O > 0 && I > 0 && kh > 0 && kw > 0, "repack: bad args");
     if (kh == 1 && kw == 1 && (I % 32) == 0) return femasr_repack_k1((hipStream_t)stream, in, O, I, out);   // GEMM layout, same size
-    const size_t total = femasr_packed_weight_floats(O, I, kh, kw);
+    const size_t tail = femasr_compact_weight_floats(O, I, kh, kw);
+    const size_t total = femasr_packed_weight_floats(O, I, kh, kw) - tail;
+    if (tail) {      // <= 4 output channels (out_conv): compact [k][4] copy behind the fragment-major matrix (direct VALU kernel)
+        hipLaunchKernelGGL(repack_compact_kernel, dim3(grid_for(tail)), dim3(256), 0, (hipStream_t)stream, in, O, I, kh, kw, out + total, tail);
+        FEMASR_CHECK_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(repack_oihw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, O, I, kh, kw, out,
                        total);
     FEMASR_CHECK_HIP(hipGetLastError());

@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -38,6 +39,19 @@ int femasr_set_error(int code, const char *fmt, ...)
 }
 
 namespace {
+
+// every ABI entry runs on the handle's device and restores the caller's current device on return (a model on cuda:1 must
+// not change torch's current device for the calling thread)
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 int channels_at(int res)   // femasr_arch.py:244-252
 {
@@ -134,7 +148,7 @@ struct femasr_handle {
     int scale = 1, max_depth = 0, encode_depth = 0;
     std::vector<WSpec> specs;
     std::map<std::string, int> index;
-    float *cbT = nullptr, *ee = nullptr;
+    float *cbT[FEMASR_MAX_CODEBOOKS] = {nullptr, nullptr, nullptr}, *ee[FEMASR_MAX_CODEBOOKS] = {nullptr, nullptr, nullptr};
     bool finalized = false;
     // profiling
     bool prof = false;
@@ -151,6 +165,7 @@ struct femasr_handle {
     std::vector<hipStream_t> sub_streams;
     std::vector<hipEvent_t> sub_done;
     hipEvent_t ev_fork = nullptr;
+    std::map<std::array<int, 4>, std::vector<size_t>> plans;      // workspace plans per (B, H, W, pad_mode)
 };
 
 namespace {
@@ -277,12 +292,18 @@ int build_specs(femasr_handle *h)
         out_ch = oc;
     }
     add_conv(h, "out_conv", out_ch, 3, 3);
-    WSpec cb; cb.key = "quantize_group.0.embedding.weight"; cb.kind = W_CODEBOOK; cb.ndim = 2;
-    cb.shape[0] = c.n_e; cb.shape[1] = c.e_dim;
-    h->specs.push_back(cb);
-    const int qc = channels_at(c.codebook_scale);
-    add_conv(h, "before_quant_group.0", qc, c.e_dim, 1);
-    add_conv(h, "after_quant_group.0.conv", c.e_dim, qc, 3);
+    // multi-scale vector quantisers (femasr_arch.py:277-300): group q > 0 quantises cat(enc_feat, prev_dec_feat) and its
+    // CombineQuantBlock convolves cat(z_quant, resized previous z_quant)
+    for (int q = 0; q < c.n_codebooks; ++q) {
+        const std::string qs = std::to_string(q);
+        WSpec cb; cb.key = "quantize_group." + qs + ".embedding.weight"; cb.kind = W_CODEBOOK; cb.ndim = 2;
+        cb.shape[0] = c.n_e[q]; cb.shape[1] = c.e_dim[q];
+        h->specs.push_back(cb);
+        const int qc = channels_at(c.codebook_scale[q]);
+        FEMASR_REQUIRE(qc > 0, "unsupported codebook scale %d", c.codebook_scale[q]);
+        add_conv(h, "before_quant_group." + qs, q == 0 ? qc : 2 * qc, c.e_dim[q], 1);
+        add_conv(h, "after_quant_group." + qs + ".conv", q == 0 ? c.e_dim[0] : c.e_dim[q - 1] + c.e_dim[q], qc, 3);
+    }
     for (size_t i = 0; i < h->specs.size(); ++i) h->index[h->specs[i].key] = (int)i;
     return FEMASR_OK;
 }
@@ -342,7 +363,7 @@ struct Ctx {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) split = h->specs[it->second].split;
         }
-        const bool lowp_on = split != nullptr && femasr_conv_bf16x3_shape_ok(&a);
+        const bool lowp_on = split != nullptr && cout > 4 && femasr_conv_bf16x3_shape_ok(&a);      // out_conv: exact VALU kernel in both modes
         const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
                                    : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
         if (o.want_gn && gn_ok) {
@@ -483,17 +504,133 @@ struct Ctx {
     }
 };
 
-int run_decoder(Ctx &c, T x, T feats[3], bool fuse_skip, float *out_nchw, int crop_h, int crop_w)
+// Shapes of one call (reference geometry; femasr_arch.py:449-468 test(), :470-479 forward(), encoder strides :150-180)
+struct Geometry {
+    int Hp, Wp;            // input after test()'s mirror pad
+    int eh, ew;            // encoder bottom (codebook scale 0) feature map
+    int out_h, out_w;      // decoder output
+    int crop_h, crop_w;    // what the caller receives
+    int nq;                // number of index maps
+    int qh[FEMASR_MAX_CODEBOOKS], qw[FEMASR_MAX_CODEBOOKS];
+};
+
+bool quant_at(const femasr_handle *h, int i, int *which)
+{
+    const int cur_res = h->cfg.gt_resolution / (1 << h->max_depth) * (1 << i);
+    for (int q = 0; q < h->cfg.n_codebooks; ++q)
+        if (h->cfg.codebook_scale[q] == cur_res) { if (which) *which = q; return true; }
+    return false;
+}
+
+int plan_geometry(const femasr_handle *h, int H, int W, int pad_mode, Geometry *g)
+{
+    g->Hp = H; g->Wp = W;
+    if (pad_mode) {
+        const int wsz = 8 / h->scale * 8;
+        g->Hp = (H / wsz + 1) * wsz;
+        g->Wp = (W / wsz + 1) * wsz;
+        if (h->cfg.lq_stage) {
+            FEMASR_REQUIRE(g->Hp - H <= H && g->Wp - W <= W, "test(): image %dx%d smaller than its mirror pad", H, W);
+        } else {            // torch.cat([x, flip(x)])[..., :h+pad] holds at most 2h rows: the reference silently truncates the pad
+            g->Hp = std::min(g->Hp, 2 * H);
+            g->Wp = std::min(g->Wp, 2 * W);
+        }
+    }
+    FEMASR_REQUIRE(g->Hp >= 2 && g->Wp >= 2, "input too small");
+    // in_conv (k4, p1) gives Hp-1; each stride-2 conv gives floor((h-1)/2)+1
+    int eh = g->Hp - 1, ew = g->Wp - 1;
+    for (int i = 0; i < h->encode_depth; ++i) { eh = (eh - 1) / 2 + 1; ew = (ew - 1) / 2 + 1; }
+    FEMASR_REQUIRE(eh >= 1 && ew >= 1, "input too small");
+    if (h->cfg.lq_stage) FEMASR_REQUIRE(eh % 8 == 0 && ew % 8 == 0, "Swin stage needs a feature map divisible by 8, got %dx%d", eh, ew);
+    g->eh = eh; g->ew = ew;
+    g->out_h = eh << h->max_depth; g->out_w = ew << h->max_depth;
+    const int s_out = pad_mode ? h->scale : 1;
+    g->crop_h = pad_mode ? std::min(H * s_out, g->out_h) : g->out_h;      // `output[..., :h*sf, :w*sf]` (a slice never grows)
+    g->crop_w = pad_mode ? std::min(W * s_out, g->out_w) : g->out_w;
+    g->nq = 0;
+    for (int i = 0; i < h->max_depth; ++i) {
+        int q;
+        if (quant_at(h, i, &q)) { g->qh[g->nq] = eh << i; g->qw[g->nq] = ew << i; ++g->nq; }
+    }
+    return FEMASR_OK;
+}
+
+// decoder_group[first..] + out_conv + crop (femasr_arch.py:366-369); quantisation steps of the later scales happen inside
+int run_tail(Ctx &c, T x, std::vector<T> &feats, bool fuse_skip, bool with_encoder, int64_t *const *idx_out, float *out_nchw,
+             int crop_h, int crop_w)
 {
     femasr_handle *h = c.h;
     const femasr_config &cfg = h->cfg;
+    T prev_dec, prev_q;
+    int nq_done = 0;
     for (int i = 0; i < h->max_depth; ++i) {
         const int r = cfg.gt_resolution / (1 << h->max_depth) * (1 << i);
-        const float *skip = (fuse_skip && i + 1 < h->max_depth) ? feats[i + 1].p : nullptr;
+        int q = 0;
+        if (with_encoder && quant_at(h, i, &q)) {       // femasr_arch.py:332-359
+            const std::string qs = std::to_string(q);
+            T zin = feats[i];
+            if (prev_dec.p || (c.dry() && i > 0)) {     // cat((enc_feats[i], prev_dec_feat), dim=1)
+                if (feats[i].H != x.H || feats[i].W != x.W) {
+                    if (!c.rc) c.rc = femasr_set_error(FEMASR_ERR_INVALID, "multi-codebook: encoder feature %dx%d and decoder feature %dx%d differ", feats[i].H, feats[i].W, x.H, x.W);
+                    return c.rc;
+                }
+                zin = c.alloc_t(x.B, x.H, x.W, feats[i].C + x.C);
+                if (!c.rc && !c.dry()) {
+                    Scope sc(h, c.s(), c.dry(), SLOT_LAYOUT, 0.0, (double)zin.numel() * 8.0);
+                    const int rr = femasr_concat_resize(c.s(), feats[i].p, feats[i].C, x.p, x.H, x.W, x.C, x.B, x.H, x.W, zin.p);
+                    if (rr && !c.rc) c.rc = rr;
+                }
+                c.release(feats[i]);
+                c.release(x);
+            }
+            Ctx::ConvOpt oq; oq.ksz = 1; oq.pad = 0;
+            T z = c.conv(zin, "before_quant_group." + qs, cfg.e_dim[q], oq);
+            c.release(zin);
+            const int64_t M = (int64_t)z.B * z.H * z.W;
+            T zq = c.alloc_t(z.B, z.H, z.W, cfg.e_dim[q]);
+            int64_t *idx = idx_out ? idx_out[nq_done] : nullptr, *idx_tmp = nullptr;
+            if (!idx) idx = idx_tmp = (int64_t *)c.arena->alloc((size_t)M * 8);
+            {
+                const int nblk = cfg.n_e[q] / 128;
+                float *scratch = c.alloc_f((size_t)M * nblk * 2 + M + 64);
+                if (!c.rc && !c.dry()) {
+                    Scope sc(h, c.s(), c.dry(), SLOT_VQ, 2.0 * (double)M * cfg.n_e[q] * cfg.e_dim[q],
+                             (double)M * cfg.e_dim[q] * 8.0 + (double)cfg.n_e[q] * cfg.e_dim[q] * 4.0 + M * 8.0);
+                    const int rr = femasr_vq(c.s(), z.p, M, cfg.e_dim[q], c.Wt("quantize_group." + qs + ".embedding.weight"), h->cbT[q], h->ee[q],
+                                             cfg.n_e[q], idx, zq.p, scratch);
+                    if (rr && !c.rc) c.rc = rr;
+                }
+                c.release(scratch);
+            }
+            if (idx_tmp) c.release(idx_tmp);
+            ++nq_done;
+            T qv = cfg.use_quantize ? zq : z;
+            c.release(cfg.use_quantize ? z : zq);
+            T ain = qv;
+            if (prev_q.p || (c.dry() && nq_done > 1)) {     // CombineQuantBlock: cat((z_quant, interpolate(prev_quant, nearest)), 1)
+                ain = c.alloc_t(qv.B, qv.H, qv.W, qv.C + prev_q.C);
+                if (!c.rc && !c.dry()) {
+                    Scope sc(h, c.s(), c.dry(), SLOT_LAYOUT, 0.0, (double)ain.numel() * 8.0);
+                    const int rr = femasr_concat_resize(c.s(), qv.p, qv.C, prev_q.p, prev_q.H, prev_q.W, prev_q.C, qv.B, qv.H, qv.W, ain.p);
+                    if (rr && !c.rc) c.rc = rr;
+                }
+                c.release(prev_q);
+            }
+            Ctx::ConvOpt oa; oa.lowp = true;
+            x = c.conv(ain, "after_quant_group." + qs + ".conv", channels_at(cfg.codebook_scale[q]), oa);
+            if (ain.p != qv.p) c.release(ain);
+            bool later = false;                             // is this z_quant combined into a later scale?
+            for (int k = i + 1; k < h->max_depth; ++k) later = later || quant_at(h, k, nullptr);
+            if (later) prev_q = qv; else c.release(qv);
+        }
+        // `x = x + enc_feats[i+1]` of the NEXT iteration (femasr_arch.py:361-362), folded into this block's last epilogue
+        const bool next_skip = with_encoder && fuse_skip && i + 1 < h->max_depth && !quant_at(h, i + 1, nullptr);
+        const float *skip = next_skip ? feats[i + 1].p : nullptr;
         T y = c.up_block(x, "decoder_group." + std::to_string(i) + ".block", channels_at(r * 2), skip, true);
         c.release(x);
-        if (skip) c.release(feats[i + 1]);
+        if (next_skip) c.release(feats[i + 1]);
         x = y;
+        prev_dec = x;
     }
     Ctx::ConvOpt oo; oo.lowp = true;
     T img = c.conv(x, "out_conv", 3, oo);
@@ -508,29 +645,22 @@ int run_decoder(Ctx &c, T x, T feats[3], bool fuse_skip, float *out_nchw, int cr
 }
 
 int run_forward(femasr_handle *h, Arena *arena, hipStream_t stream, const float *in_nchw, int B, int H, int W, int pad_mode,
-                float *out_nchw, int64_t *indices)
+                float *out_nchw, int64_t *const *idx_out)
 {
     const femasr_config &cfg = h->cfg;
     Ctx c{h, arena, stream};
-    int Hp = H, Wp = W;
-    if (pad_mode) {
-        const int wsz = 8 / h->scale * 8;
-        Hp = (H / wsz + 1) * wsz;
-        Wp = (W / wsz + 1) * wsz;
-        FEMASR_REQUIRE(Hp - H <= H && Wp - W <= W, "test(): image %dx%d smaller than its mirror pad", H, W);
-    }
-    const int down = 1 << h->encode_depth;   // total stride of the encoder's down path
-    FEMASR_REQUIRE(Hp >= 2 && Wp >= 2, "input too small");
-    // geometry checks: in_conv gives Hp-1; each stride-2 conv gives floor((h-1)/2)+1
-    int eh = Hp - 1, ew = Wp - 1;
-    for (int i = 0; i < h->encode_depth; ++i) { eh = (eh - 1) / 2 + 1; ew = (ew - 1) / 2 + 1; }
-    (void)down;
-    if (cfg.lq_stage) FEMASR_REQUIRE(eh % 8 == 0 && ew % 8 == 0, "Swin stage needs a feature map divisible by 8, got %dx%d", eh, ew);
+    Geometry g;
+    int rc = plan_geometry(h, H, W, pad_mode, &g);
+    if (rc) return rc;
+    const bool fuse_skip = cfg.lq_stage && cfg.use_residual;
+    auto needed = [&](int i) {        // is enc_feats[i] read by the decoder side?
+        return i == 0 || quant_at(h, i, nullptr) || fuse_skip;
+    };
 
-    T x0 = c.alloc_t(B, Hp, Wp, cfg.in_channel);
+    T x0 = c.alloc_t(B, g.Hp, g.Wp, cfg.in_channel);
     if (!c.rc && !c.dry()) {
         Scope sc(h, c.s(), c.dry(), SLOT_LAYOUT, 0.0, (double)x0.numel() * 8.0);
-        const int r = femasr_pad_nchw_to_nhwc(c.s(), in_nchw, B, cfg.in_channel, H, W, Hp, Wp, x0.p);
+        const int r = femasr_pad_nchw_to_nhwc(c.s(), in_nchw, B, cfg.in_channel, H, W, g.Hp, g.Wp, x0.p);
         if (r) c.rc = r;
     }
     const std::string enc = "multiscale_encoder";
@@ -539,73 +669,61 @@ int run_forward(femasr_handle *h, Arena *arena, hipStream_t stream, const float 
     T t = c.conv(x0, enc + ".in_conv", channels_at(res), oin);
     c.release(x0);
     int bi = 0;
+    std::vector<T> outs;              // MultiScaleEncoder.forward returns every block's output (femasr_arch.py:184-192)
+    bool t_kept = false;              // t is also held in outs
     for (int i = 0; i < h->encode_depth; ++i, ++bi) {
         const std::string p = enc + ".blocks." + std::to_string(bi);
         Ctx::ConvOpt od; od.stride = 2;
         T d = c.conv(t, p + ".0", channels_at(res / 2), od);
-        c.release(t);
+        if (!t_kept) c.release(t);
         t = c.resblock(d, p + ".1", nullptr, true, false, true);
         t = c.resblock(t, p + ".2", nullptr, true);
         res /= 2;
+        t_kept = false;
+        if (!cfg.lq_stage) {          // HQ stage: enc_feats = outs[::-1]; block i is feats[encode_depth-1-i]
+            const int fi = h->encode_depth - 1 - i;
+            outs.push_back(t);
+            t_kept = fi < h->max_depth && needed(fi) && i + 1 < h->encode_depth;
+        }
     }
-    T feats[3];
-    if (cfg.lq_stage) {
+    std::vector<T> feats(FEMASR_MAX_CODEBOOKS + 1);
+    if (cfg.lq_stage) {               // enc_feats = outs[-3:] = (Swin stage, up-block 1, up-block 2)
         t = c.swin_layers(t, enc + ".blocks." + std::to_string(bi++));
         feats[0] = t;
-        for (int u = 0; u < 2; ++u, ++bi) {
+        int last = 0;                 // up-blocks nobody reads are skipped (the reference computes and discards them)
+        for (int u = 1; u <= 2 && u < h->max_depth; ++u) if (needed(u)) last = u;
+        for (int u = 0; u < last; ++u, ++bi) {
             feats[u + 1] = c.up_block(feats[u], enc + ".blocks." + std::to_string(bi), channels_at(res * 2), nullptr, true);
             res *= 2;
         }
+        for (int u = 1; u < last; ++u)
+            if (!needed(u)) c.release(feats[u]);
     } else {
-        feats[0] = t;
-    }
-    // quantise (femasr_arch.py:332-359)
-    Ctx::ConvOpt oq; oq.ksz = 1; oq.pad = 0;
-    T z = c.conv(feats[0], "before_quant_group.0", cfg.e_dim, oq);
-    c.release(feats[0]);
-    const int64_t M = (int64_t)z.B * z.H * z.W;
-    T zq = c.alloc_t(z.B, z.H, z.W, cfg.e_dim);
-    int64_t *idx_tmp = nullptr;
-    if (!indices) idx_tmp = (int64_t *)c.arena->alloc((size_t)M * 8);
-    {
-        const int nblk = cfg.n_e / 128;
-        float *scratch = c.alloc_f((size_t)M * nblk * 2 + M + 64);
-        if (!c.rc && !c.dry()) {
-            Scope sc(h, c.s(), c.dry(), SLOT_VQ, 2.0 * (double)M * cfg.n_e * cfg.e_dim, (double)M * cfg.e_dim * 8.0 + (double)cfg.n_e * cfg.e_dim * 4.0 + M * 8.0);
-            const int r = femasr_vq(c.s(), z.p, M, cfg.e_dim, c.Wt("quantize_group.0.embedding.weight"), h->cbT, h->ee, cfg.n_e,
-                                    indices ? indices : idx_tmp, zq.p, scratch);
-            if (r && !c.rc) c.rc = r;
+        for (int i = 0; i < h->encode_depth; ++i) {
+            const int fi = h->encode_depth - 1 - i;
+            if (fi < (int)feats.size() && fi < h->max_depth && needed(fi)) feats[fi] = outs[i];
         }
-        c.release(scratch);
     }
-    if (idx_tmp) c.release(idx_tmp);
-    T q = cfg.use_quantize ? zq : z;
-    Ctx::ConvOpt oa; oa.lowp = true;
-    T x = c.conv(q, "after_quant_group.0.conv", channels_at(cfg.codebook_scale), oa);
-    c.release(z);
-    c.release(zq);
-    const int s_out = pad_mode ? h->scale : 1;
-    const int crop_h = pad_mode ? H * s_out : 0, crop_w = pad_mode ? W * s_out : 0;
-    const int full_h = x.H << h->max_depth, full_w = x.W << h->max_depth;
-    return run_decoder(c, x, feats, cfg.lq_stage && cfg.use_residual, out_nchw, pad_mode ? crop_h : full_h, pad_mode ? crop_w : full_w);
+    return run_tail(c, feats[0], feats, fuse_skip, true, idx_out, out_nchw, g.crop_h, g.crop_w);
 }
 
+// decode_indices (femasr_arch.py:376-385): codebook 0 -> after_quant_group[0] -> every decoder block -> out_conv
 int run_decode_indices(femasr_handle *h, Arena *arena, hipStream_t stream, const int64_t *indices, int B, int hq, int wq,
                        float *out_nchw)
 {
     const femasr_config &cfg = h->cfg;
     Ctx c{h, arena, stream};
-    T zq = c.alloc_t(B, hq, wq, cfg.e_dim);
+    T zq = c.alloc_t(B, hq, wq, cfg.e_dim[0]);
     if (!c.rc && !c.dry()) {
         Scope sc(h, c.s(), c.dry(), SLOT_LAYOUT, 0.0, (double)zq.numel() * 8.0);
-        const int r = femasr_codebook_gather(c.s(), indices, (int64_t)B * hq * wq, cfg.e_dim, c.Wt("quantize_group.0.embedding.weight"), cfg.n_e, zq.p);
+        const int r = femasr_codebook_gather(c.s(), indices, (int64_t)B * hq * wq, cfg.e_dim[0], c.Wt("quantize_group.0.embedding.weight"), cfg.n_e[0], zq.p);
         if (r) c.rc = r;
     }
     Ctx::ConvOpt oa; oa.lowp = true;
-    T x = c.conv(zq, "after_quant_group.0.conv", channels_at(cfg.codebook_scale), oa);
+    T x = c.conv(zq, "after_quant_group.0.conv", channels_at(cfg.codebook_scale[0]), oa);
     c.release(zq);
-    T feats[3];
-    return run_decoder(c, x, feats, false, out_nchw, hq << h->max_depth, wq << h->max_depth);
+    std::vector<T> feats(FEMASR_MAX_CODEBOOKS + 1);
+    return run_tail(c, x, feats, false, false, nullptr, out_nchw, hq << h->max_depth, wq << h->max_depth);
 }
 
 int check_ready(const femasr_handle *h)
@@ -629,17 +747,27 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
 {
     FEMASR_REQUIRE(cfg && out, "create: null argument");
     FEMASR_REQUIRE(cfg->in_channel == 3, "create: in_channel must be 3");
-    FEMASR_REQUIRE(cfg->n_e > 0 && cfg->n_e % 128 == 0 && cfg->e_dim > 0 && cfg->e_dim % 32 == 0, "create: codebook %dx%d unsupported (n_e %% 128, e_dim %% 32)", cfg->n_e, cfg->e_dim);
-    FEMASR_REQUIRE(cfg->codebook_scale > 0 && cfg->gt_resolution % cfg->codebook_scale == 0, "create: bad codebook scale");
+    FEMASR_REQUIRE(cfg->n_codebooks >= 1 && cfg->n_codebooks <= FEMASR_MAX_CODEBOOKS, "create: n_codebooks must be 1..%d", FEMASR_MAX_CODEBOOKS);
+    for (int q = 0; q < cfg->n_codebooks; ++q) {
+        FEMASR_REQUIRE(cfg->n_e[q] > 0 && cfg->n_e[q] % 128 == 0 && cfg->e_dim[q] > 0 && cfg->e_dim[q] % 32 == 0,
+                       "create: codebook %dx%d unsupported (n_e %% 128, e_dim %% 32)", cfg->n_e[q], cfg->e_dim[q]);
+        FEMASR_REQUIRE(cfg->codebook_scale[q] > 0 && cfg->gt_resolution % cfg->codebook_scale[q] == 0, "create: bad codebook scale");
+        FEMASR_REQUIRE(q == 0 || cfg->codebook_scale[q] > cfg->codebook_scale[q - 1], "create: codebook scales must ascend");
+    }
     femasr_handle *h = new femasr_handle();
     h->cfg = *cfg;
     h->scale = cfg->lq_stage ? cfg->scale_factor : 1;
     if (!(h->scale == 1 || h->scale == 2 || h->scale == 4)) { delete h; return femasr_set_error(FEMASR_ERR_INVALID, "create: scale_factor %d unsupported", h->scale); }
-    h->max_depth = ilog2(cfg->gt_resolution / cfg->codebook_scale);
-    h->encode_depth = ilog2(cfg->gt_resolution / h->scale / cfg->codebook_scale);
+    h->max_depth = ilog2(cfg->gt_resolution / cfg->codebook_scale[0]);
+    h->encode_depth = ilog2(cfg->gt_resolution / h->scale / cfg->codebook_scale[0]);
     if (h->max_depth < 1 || h->max_depth > 3) { delete h; return femasr_set_error(FEMASR_ERR_INVALID, "create: max_depth %d unsupported", h->max_depth); }
-    hipError_t e = hipSetDevice(cfg->device);
-    if (e != hipSuccess) { delete h; return femasr_set_error(FEMASR_ERR_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e)); }
+    for (int q = 1; q < cfg->n_codebooks; ++q) {
+        bool hit = false;
+        for (int i = 0; i < h->max_depth; ++i) hit = hit || (cfg->gt_resolution / (1 << h->max_depth) * (1 << i)) == cfg->codebook_scale[q];
+        if (!hit) { delete h; return femasr_set_error(FEMASR_ERR_INVALID, "create: codebook scale %d is not a decoder resolution", cfg->codebook_scale[q]); }
+    }
+    DeviceGuard guard(cfg->device);
+    if (!guard.ok) { delete h; return femasr_set_error(FEMASR_ERR_HIP, "hipSetDevice(%d) failed", cfg->device); }
     const int rc = build_specs(h);
     if (rc) { delete h; return rc; }
     const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count();
@@ -655,8 +783,10 @@ void femasr_destroy(femasr_handle *h)
 {
     if (!h) return;
     for (auto &w : h->specs) { if (w.dev) (void)hipFree(w.dev); if (w.split) (void)hipFree(w.split); }
-    if (h->cbT) (void)hipFree(h->cbT);
-    if (h->ee) (void)hipFree(h->ee);
+    for (int q = 0; q < FEMASR_MAX_CODEBOOKS; ++q) {
+        if (h->cbT[q]) (void)hipFree(h->cbT[q]);
+        if (h->ee[q]) (void)hipFree(h->ee[q]);
+    }
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sub_done) (void)hipEventDestroy(e);
     for (auto st : h->sub_streams) (void)hipStreamDestroy(st);
@@ -685,11 +815,12 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
     if (k.size() > 10 && (k.rfind(".attn_mask") == k.size() - 10)) return FEMASR_OK;
     auto it = h->index.find(k);
     if (it == h->index.end()) return femasr_set_error(FEMASR_ERR_WEIGHT, "set_weight: unknown key '%s'", key);
+    DeviceGuard guard(h->cfg.device);
+    FEMASR_REQUIRE(guard.ok, "set_weight: hipSetDevice(%d) failed", h->cfg.device);
     WSpec &w = h->specs[it->second];
     bool same = (ndim == w.ndim);
     for (int i = 0; same && i < ndim; ++i) same = (shape[i] == w.shape[i]);
     if (!same) return femasr_set_error(FEMASR_ERR_WEIGHT, "set_weight: shape mismatch for '%s'", key);
-    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
     const size_t n = w.numel();
     size_t alloc = n;
     if (w.kind == W_CONV) alloc = femasr_packed_weight_floats((int)w.shape[0], (int)w.shape[1], (int)w.shape[2], (int)w.shape[3]);
@@ -726,16 +857,20 @@ int femasr_finalize_weights(femasr_handle *h)
     FEMASR_REQUIRE(h, "finalize: null handle");
     for (const auto &w : h->specs)
         if (!w.set) return femasr_set_error(FEMASR_ERR_WEIGHT, "finalize: weight '%s' was never set", w.key.c_str());
-    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
-    const int n_e = h->cfg.n_e, D = h->cfg.e_dim;
-    if (!h->cbT) FEMASR_CHECK_HIP(hipMalloc((void **)&h->cbT, femasr_packed_weight_floats(n_e, D, 1, 1) * sizeof(float)));
-    if (!h->ee) FEMASR_CHECK_HIP(hipMalloc((void **)&h->ee, (size_t)n_e * sizeof(float)));
-    const float *cb = h->specs[h->index["quantize_group.0.embedding.weight"]].dev;
-    int rc = femasr_repack_oihw(nullptr, cb, n_e, D, 1, 1, h->cbT);     // packed z.e^T operand
-    if (rc) return rc;
-    rc = femasr_row_sqsum(nullptr, cb, n_e, D, h->ee);
-    if (rc) return rc;
+    DeviceGuard guard(h->cfg.device);
+    FEMASR_REQUIRE(guard.ok, "finalize: hipSetDevice(%d) failed", h->cfg.device);
+    for (int q = 0; q < h->cfg.n_codebooks; ++q) {
+        const int n_e = h->cfg.n_e[q], D = h->cfg.e_dim[q];
+        if (!h->cbT[q]) FEMASR_CHECK_HIP(hipMalloc((void **)&h->cbT[q], femasr_packed_weight_floats(n_e, D, 1, 1) * sizeof(float)));
+        if (!h->ee[q]) FEMASR_CHECK_HIP(hipMalloc((void **)&h->ee[q], (size_t)n_e * sizeof(float)));
+        const float *cb = h->specs[h->index["quantize_group." + std::to_string(q) + ".embedding.weight"]].dev;
+        int rc = femasr_repack_oihw(nullptr, cb, n_e, D, 1, 1, h->cbT[q]);     // packed z.e^T operand
+        if (rc) return rc;
+        rc = femasr_row_sqsum(nullptr, cb, n_e, D, h->ee[q]);
+        if (rc) return rc;
+    }
     FEMASR_CHECK_HIP(hipStreamSynchronize(nullptr));
+    h->plans.clear();
     h->finalized = true;
     return FEMASR_OK;
 }
@@ -748,29 +883,66 @@ static void sub_range(int B, int S, int i, int *lo, int *hi)
     *hi = *lo + q + (i < r ? 1 : 0);
 }
 
+// Workspace plan of one call shape: per sub-batch arena peaks (a dry run of the launch schedule), cached per
+// (B, H, W, pad_mode) until the stream count / decoder math / weights change.
+static int plan_for(femasr_handle *h, int B, int H, int W, int pad_mode, const std::vector<size_t> **out)
+{
+    const std::array<int, 4> key{B, H, W, pad_mode};
+    auto it = h->plans.find(key);
+    if (it == h->plans.end()) {
+        const int S = std::min(h->nsub, B);
+        std::vector<size_t> need;
+        for (int i = 0; i < S; ++i) {
+            int lo, hi;
+            sub_range(B, S, i, &lo, &hi);
+            Arena a;
+            a.reset(nullptr, 0, true);
+            const int rc = run_forward(h, &a, nullptr, nullptr, hi - lo, H, W, pad_mode, nullptr, nullptr);
+            if (rc) return rc;
+            need.push_back((a.peak + 255) & ~(size_t)255);
+        }
+        if (h->plans.size() > 64) h->plans.clear();
+        it = h->plans.emplace(key, std::move(need)).first;
+    }
+    *out = &it->second;
+    return FEMASR_OK;
+}
+
 int femasr_workspace_bytes(const femasr_handle *hc, int B, int H, int W, int pad_mode, size_t *bytes)
 {
     femasr_handle *h = const_cast<femasr_handle *>(hc);
     FEMASR_REQUIRE(h && bytes && B > 0 && H > 0 && W > 0, "workspace_bytes: bad args");
-    const int S = std::min(h->nsub, B);
+    const std::vector<size_t> *need = nullptr;
+    const int rc = plan_for(h, B, H, W, pad_mode, &need);
+    if (rc) return rc;
     size_t total = 0;
-    for (int i = 0; i < S; ++i) {
-        int lo, hi;
-        sub_range(B, S, i, &lo, &hi);
-        Arena a;
-        a.reset(nullptr, 0, true);
-        const int rc = run_forward(h, &a, nullptr, nullptr, hi - lo, H, W, pad_mode, nullptr, nullptr);
-        if (rc) return rc;
-        total += (a.peak + 255) & ~(size_t)255;
-    }
+    for (size_t n : *need) total += n;
     *bytes = total + 256;
+    return FEMASR_OK;
+}
+
+int femasr_forward_shapes(const femasr_handle *h, int H, int W, int pad_mode, int *out_h, int *out_w, int *n_index_maps,
+                          int *idx_h, int *idx_w)
+{
+    FEMASR_REQUIRE(h && H > 0 && W > 0, "forward_shapes: bad args");
+    Geometry g;
+    const int rc = plan_geometry(h, H, W, pad_mode, &g);
+    if (rc) return rc;
+    if (out_h) *out_h = g.crop_h;
+    if (out_w) *out_w = g.crop_w;
+    if (n_index_maps) *n_index_maps = g.nq;
+    for (int q = 0; q < g.nq; ++q) {
+        if (idx_h) idx_h[q] = g.qh[q];
+        if (idx_w) idx_w[q] = g.qw[q];
+    }
     return FEMASR_OK;
 }
 
 int femasr_set_streams(femasr_handle *h, int n)
 {
     FEMASR_REQUIRE(h && n >= 1 && n <= 8, "set_streams: n must be in [1, 8]");
-    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
+    DeviceGuard guard(h->cfg.device);
+    FEMASR_REQUIRE(guard.ok, "set_streams: hipSetDevice(%d) failed", h->cfg.device);
     while ((int)h->sub_streams.size() < n) {
         hipStream_t st;
         hipEvent_t ev;
@@ -780,6 +952,7 @@ int femasr_set_streams(femasr_handle *h, int n)
         h->sub_done.push_back(ev);
     }
     if (!h->ev_fork) FEMASR_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    if (h->nsub != n) h->plans.clear();
     h->nsub = n;
     return FEMASR_OK;
 }
@@ -791,50 +964,64 @@ int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, 
     if (rc) return rc;
     FEMASR_REQUIRE(in_nchw && out_nchw && ws && B > 0 && H > 0 && W > 0, "forward: bad args");
     FEMASR_REQUIRE(((uintptr_t)ws & 255) == 0, "forward: workspace must be 256-byte aligned");
-    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
+    DeviceGuard guard(h->cfg.device);
+    FEMASR_REQUIRE(guard.ok, "forward: hipSetDevice(%d) failed", h->cfg.device);
     hipStream_t caller = (hipStream_t)stream;
-    const int S = std::min(h->nsub, B);
+    Geometry g;
+    rc = plan_geometry(h, H, W, pad_mode, &g);
+    if (rc) return rc;
+    // `indices`: the index maps of all codebooks back to back, map q = (B, 1, qh[q], qw[q]) int64
+    int64_t *qbase[FEMASR_MAX_CODEBOOKS] = {nullptr, nullptr, nullptr};
+    size_t qstride[FEMASR_MAX_CODEBOOKS] = {0, 0, 0};
+    {
+        size_t off = 0;
+        for (int q = 0; q < g.nq; ++q) {
+            qstride[q] = (size_t)g.qh[q] * g.qw[q];
+            qbase[q] = indices ? indices + off : nullptr;
+            off += (size_t)B * qstride[q];
+        }
+    }
+    const std::vector<size_t> *need = nullptr;
+    rc = plan_for(h, B, H, W, pad_mode, &need);
+    if (rc) return rc;
+    const int S = (int)need->size();
     if (S <= 1) {
         Arena a;
         a.reset(ws, ws_bytes, false);
-        return run_forward(h, &a, caller, in_nchw, B, H, W, pad_mode, out_nchw, indices);
+        return run_forward(h, &a, caller, in_nchw, B, H, W, pad_mode, out_nchw, indices ? qbase : nullptr);
     }
     // fork: every sub-batch stream waits for the caller's stream; join: the caller's stream waits for all of them.
     // Only event dependencies are added — no host synchronisation.
-    const int s_out = pad_mode ? h->scale : 1;
+    size_t total = 0;
+    for (size_t n : *need) total += n;
+    if (total > ws_bytes) return femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small for %d sub-batches", S);
     const size_t in_stride = (size_t)h->cfg.in_channel * H * W;
-    size_t out_stride, idx_stride;
-    {
-        int Hp = H, Wp = W;
-        if (pad_mode) { const int wsz = 8 / h->scale * 8; Hp = (H / wsz + 1) * wsz; Wp = (W / wsz + 1) * wsz; }
-        const int down = 1 << h->encode_depth;
-        idx_stride = (size_t)(Hp / down) * (Wp / down);
-        out_stride = pad_mode ? (size_t)3 * (H * s_out) * (W * s_out)
-                              : (size_t)3 * ((Hp / down) << h->max_depth) * ((Wp / down) << h->max_depth);
-    }
+    const size_t out_stride = (size_t)3 * g.crop_h * g.crop_w;
     FEMASR_CHECK_HIP(hipEventRecord(h->ev_fork, caller));
     size_t off = 0;
-    for (int i = 0; i < S; ++i) {
+    int forked = 0;
+    for (int i = 0; i < S && !rc; ++i) {
         int lo, hi;
         sub_range(B, S, i, &lo, &hi);
-        Arena dry;
-        dry.reset(nullptr, 0, true);
-        rc = run_forward(h, &dry, nullptr, nullptr, hi - lo, H, W, pad_mode, nullptr, nullptr);
-        if (rc) return rc;
-        const size_t need = (dry.peak + 255) & ~(size_t)255;
-        if (off + need > ws_bytes) return femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small for %d sub-batches", S);
         Arena a;
-        a.reset((char *)ws + off, need, false);
-        off += need;
+        a.reset((char *)ws + off, (*need)[i], false);
+        off += (*need)[i];
         hipStream_t st = h->sub_streams[i];
-        FEMASR_CHECK_HIP(hipStreamWaitEvent(st, h->ev_fork, 0));
+        if (hipStreamWaitEvent(st, h->ev_fork, 0) != hipSuccess) { rc = femasr_set_error(FEMASR_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        forked = i + 1;
+        int64_t *qsub[FEMASR_MAX_CODEBOOKS];
+        for (int q = 0; q < FEMASR_MAX_CODEBOOKS; ++q) qsub[q] = qbase[q] ? qbase[q] + lo * qstride[q] : nullptr;
         rc = run_forward(h, &a, st, in_nchw + lo * in_stride, hi - lo, H, W, pad_mode, out_nchw + lo * out_stride,
-                         indices ? indices + lo * idx_stride : nullptr);
-        if (rc) return rc;
-        FEMASR_CHECK_HIP(hipEventRecord(h->sub_done[i], st));
-        FEMASR_CHECK_HIP(hipStreamWaitEvent(caller, h->sub_done[i], 0));
+                         indices ? qsub : nullptr);
     }
-    return FEMASR_OK;
+    // join every stream that was forked - also on an error, so that nothing still runs on ws / out when the caller's
+    // stream continues
+    for (int i = 0; i < forked; ++i) {
+        if (hipEventRecord(h->sub_done[i], h->sub_streams[i]) != hipSuccess || hipStreamWaitEvent(caller, h->sub_done[i], 0) != hipSuccess) {
+            if (!rc) rc = femasr_set_error(FEMASR_ERR_HIP, "joining sub-batch stream %d failed", i);
+        }
+    }
+    return rc;
 }
 
 int femasr_decode_workspace_bytes(const femasr_handle *hc, int B, int hq, int wq, size_t *bytes)
@@ -856,7 +1043,8 @@ int femasr_decode_indices(femasr_handle *h, void *stream, const int64_t *indices
     if (rc) return rc;
     FEMASR_REQUIRE(indices && out_nchw && ws && B > 0 && hq > 0 && wq > 0, "decode_indices: bad args");
     FEMASR_REQUIRE(((uintptr_t)ws & 255) == 0, "decode_indices: workspace must be 256-byte aligned");
-    FEMASR_CHECK_HIP(hipSetDevice(h->cfg.device));
+    DeviceGuard guard(h->cfg.device);
+    FEMASR_REQUIRE(guard.ok, "decode_indices: hipSetDevice(%d) failed", h->cfg.device);
     Arena a;
     a.reset(ws, ws_bytes, false);
     return run_decode_indices(h, &a, (hipStream_t)stream, indices, B, hq, wq, out_nchw);
@@ -865,6 +1053,7 @@ int femasr_decode_indices(femasr_handle *h, void *stream, const int64_t *indices
 int femasr_set_decoder_math(femasr_handle *h, int mode)
 {
     FEMASR_REQUIRE(h && (mode == 0 || mode == 1), "set_decoder_math: mode must be 0 (fp32) or 1 (bf16x3)");
+    if (h->decoder_math != mode) h->plans.clear();
     h->decoder_math = mode;
     return FEMASR_OK;
 }

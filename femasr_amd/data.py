@@ -3,8 +3,11 @@ single_image_dataset.py) - 'folder' mode, `io_backend: disk`, phase != 'train' o
 
 Each item is {'lq', ['gt'], 'lq_path', ['gt_path']} with float32 CHW RGB tensors in [0,1] (`img2tensor(bgr2rgb=True)`
 of `cv2.imread(...)/255.`).  Files are paired by SORTED path (the reference pairs by `os.walk` order, which is the
-same listing for both folders on one filesystem but is not sorted)."""
+same listing for both folders on one filesystem but is not sorted).  `crop_eval_size` (paired_image_dataset.py:97-104):
+a paired RANDOM crop of the gt to that size (lq to size // scale), positions drawn with `random.randint` like the
+reference's `paired_random_crop` (transforms.py:26-90)."""
 import os
+import random
 
 import numpy as np
 import torch
@@ -35,8 +38,19 @@ class PairedImageDataset(torch.utils.data.Dataset):
         return len(self.gt_paths)
 
     def __getitem__(self, i):
-        return {'lq': _read(self.lq_paths[i]), 'gt': _read(self.gt_paths[i]), 'lq_path': self.lq_paths[i],
-                'gt_path': self.gt_paths[i]}
+        lq, gt = _read(self.lq_paths[i]), _read(self.gt_paths[i])
+        size = self.opt.get('crop_eval_size', None)
+        if size:
+            scale = gt.shape[1] // lq.shape[1]
+            ps = size // scale
+            if gt.shape[1] != lq.shape[1] * scale or gt.shape[2] != lq.shape[2] * scale:
+                raise ValueError(f'Scale mismatches. GT {tuple(gt.shape[1:])} is not {scale}x multiplication of LQ {tuple(lq.shape[1:])}.')
+            if lq.shape[1] < ps or lq.shape[2] < ps:
+                raise ValueError(f'LQ {tuple(lq.shape[1:])} is smaller than patch size ({ps}, {ps}). Please remove {self.gt_paths[i]}.')
+            top, left = random.randint(0, lq.shape[1] - ps), random.randint(0, lq.shape[2] - ps)
+            lq = lq[:, top:top + ps, left:left + ps].contiguous()
+            gt = gt[:, top * scale:top * scale + size, left * scale:left * scale + size].contiguous()
+        return {'lq': lq, 'gt': gt, 'lq_path': self.lq_paths[i], 'gt_path': self.gt_paths[i]}
 
 
 class SingleImageDataset(torch.utils.data.Dataset):

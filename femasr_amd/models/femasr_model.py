@@ -24,6 +24,7 @@ from copy import deepcopy
 import numpy as np
 import torch
 
+from .. import imgproc
 from ..archs import build_network
 from . import MODEL_REGISTRY
 
@@ -138,6 +139,8 @@ class FeMaSRModel:
         self.lq = data['lq'].to(self.device)
         if 'gt' in data:
             self.gt = data['gt'].to(self.device)
+        elif hasattr(self, 'gt'):
+            del self.gt             # never score an image against the previous item's ground truth
 
     @torch.no_grad()
     def test(self):
@@ -170,7 +173,8 @@ class FeMaSRModel:
             img_name = os.path.splitext(os.path.basename(val_data['lq_path'][0]))[0]
             self.feed_data(val_data)
             self.test()
-            sr_img = tensor2img(self.output)
+            # tensor2img (img_util.py:38-94) on the GPU: clamp / x255 / round-half-even in a HIP kernel, uint8 crosses PCIe
+            sr_img = imgproc.output_to_u8(self.output).cpu().numpy()
             if save_img:
                 suffix = val_opt.get('suffix') or self.opt['name']
                 save_img_path = os.path.join(self.opt['path']['visualization'], dataset_name, f'{img_name}_{suffix}.png')
@@ -180,12 +184,14 @@ class FeMaSRModel:
                     os.makedirs(save_as_dir, exist_ok=True)
                     Image.fromarray(sr_img, 'RGB').save(os.path.join(save_as_dir, f'{img_name}.png'))
             if metrics and hasattr(self, 'gt'):
-                gt_img = tensor2img(self.gt)
+                gt_img = imgproc.output_to_u8(self.gt).cpu().numpy()
                 for name, m in metrics.items():
                     fn = _METRICS.get(m.get('type'))
                     if fn is not None:
                         self.metric_results[name] += fn(sr_img, gt_img, **{k: v for k, v in m.items() if k not in ('type', 'better')})
             del self.lq, self.output
+            if hasattr(self, 'gt'):
+                del self.gt
             n += 1
         for name in self.metric_results:
             self.metric_results[name] = self.metric_results[name] / max(n, 1) if name not in skipped else None

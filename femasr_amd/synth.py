@@ -43,10 +43,11 @@ def uniform(seed: int, key: str, shape, lo: float, hi: float) -> np.ndarray:
     return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
 
 
-def synth_tensor(seed: int, key: str, shape, codebook: str = 'init') -> np.ndarray:
+def synth_tensor(seed: int, key: str, shape, codebook: str = 'init', out_conv_scale: float = 1.0 / 16.0) -> np.ndarray:
     """Value rule per state-dict key.  Chosen so activations stay O(1) through
     the network (variance-preserving conv/linear weights, GN/LN affine near
-    identity) — the regime the parity tolerances are stated for."""
+    identity) — the regime the parity tolerances are stated for.  `out_conv_scale`
+    = 1 gives the un-scaled variant (output magnitudes ~16x larger)."""
     shape = tuple(int(s) for s in shape)
     leaf = key.rsplit('.', 1)[-1]
     if key.endswith('embedding.weight'):
@@ -67,21 +68,51 @@ def synth_tensor(seed: int, key: str, shape, codebook: str = 'init') -> np.ndarr
         fan_in = int(np.prod(shape[1:]))
         b = float(np.sqrt(3.0 / fan_in))
         if key == 'out_conv.weight':    # keep the synthetic image O(1), the regime the 1e-3 bound is stated for
-            b *= 1.0 / 16.0
+            b *= out_conv_scale
         return uniform(seed, key, shape, -b, b)
     raise KeyError(f'no synthetic rule for {key} {shape}')
 
 
-def fill_state_dict(state_dict, seed: int = 0, codebook: str = 'init'):
+def torch_default_tensor(seed: int, key: str, shape, shapes) -> np.ndarray:
+    """The distributions torch's default initialisers give each tensor of the architecture (nn.Conv2d / nn.Linear:
+    kaiming_uniform(a=sqrt 5) weights and U(+-1/sqrt(fan_in)) biases; GroupNorm / LayerNorm identity affine; Swin
+    relative-position tables trunc_normal(std .02), network_swinir.py; codebook U(+-1/n_e), femasr_arch.py:33), drawn from
+    a torch CPU generator keyed by (seed, state-dict key) so that both sides regenerate the same values with the same
+    torch build.  `shapes` = {key: shape} of the whole state dict (a bias needs its weight's fan-in)."""
+    import torch
+    shape = tuple(int(s) for s in shape)
+    g = torch.Generator().manual_seed((_fnv1a64(key) ^ (seed * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF)
+    leaf = key.rsplit('.', 1)[-1]
+    if key.endswith('embedding.weight'):
+        return torch.empty(shape).uniform_(-1.0 / shape[0], 1.0 / shape[0], generator=g).numpy()
+    if leaf == 'relative_position_bias_table':
+        return torch.nn.init.trunc_normal_(torch.empty(shape), std=.02, generator=g).numpy()
+    if len(shape) == 1:
+        wkey = key.rsplit('.', 1)[0] + '.weight'
+        wshape = shapes.get(wkey, ())
+        if leaf == 'weight' or len(wshape) < 2:        # norm layers: weight 1, bias 0
+            return (np.ones if leaf == 'weight' else np.zeros)(shape, np.float32)
+        b = 1.0 / float(np.sqrt(int(np.prod(wshape[1:]))))
+        return torch.empty(shape).uniform_(-b, b, generator=g).numpy()
+    b = 1.0 / float(np.sqrt(int(np.prod(shape[1:]))))
+    return torch.empty(shape).uniform_(-b, b, generator=g).numpy()
+
+
+def fill_state_dict(state_dict, seed: int = 0, codebook: str = 'init', variant: str = 'default'):
     """Return {key: np.ndarray} for every floating tensor of a state dict
     (integer / mask buffers such as relative_position_index and attn_mask keep
-    their constructed values and are skipped)."""
+    their constructed values and are skipped).
+    variant: 'default' (synth_tensor), 'unscaled' (out_conv not scaled down), 'torchinit' (torch_default_tensor)."""
     out = {}
+    shapes = {k: tuple(v.shape) for k, v in state_dict.items()}
     for key, val in state_dict.items():
         leaf = key.rsplit('.', 1)[-1]
         if leaf in ('relative_position_index', 'attn_mask'):
             continue
-        out[key] = synth_tensor(seed, key, tuple(val.shape), codebook)
+        if variant == 'torchinit':
+            out[key] = torch_default_tensor(seed, key, tuple(val.shape), shapes)
+        else:
+            out[key] = synth_tensor(seed, key, tuple(val.shape), codebook, 1.0 if variant == 'unscaled' else 1.0 / 16.0)
     return out
 
 

@@ -40,8 +40,10 @@ typedef enum {
 
 typedef struct femasr_handle femasr_handle;
 
-/* Mirrors FeMaSRNet.__init__ keyword arguments (basicsr/archs/femasr_arch.py:216-228);
- * single-codebook configurations only (codebook_params = [[scale, n_e, e_dim]]). */
+/* Mirrors FeMaSRNet.__init__ keyword arguments (basicsr/archs/femasr_arch.py:216-228).  codebook_params rows
+ * [scale, n_e, e_dim] in ascending scale order (femasr_arch.py:231-235); rows after the first are the multi-scale
+ * quantisers of femasr_arch.py:277-300 (before_quant on cat(enc_feat, dec_feat), CombineQuantBlock fema_utils.py:87-99). */
+#define FEMASR_MAX_CODEBOOKS 3
 typedef struct {
     int32_t in_channel;      /* 3 */
     int32_t gt_resolution;   /* 256 */
@@ -49,9 +51,10 @@ typedef struct {
     int32_t scale_factor;    /* 4 / 2 (ignored -> 1 when !lq_stage, femasr_arch.py:241) */
     int32_t use_quantize;
     int32_t use_residual;
-    int32_t codebook_scale;  /* 32 */
-    int32_t n_e;             /* 1024 */
-    int32_t e_dim;           /* 512 */
+    int32_t n_codebooks;     /* 1..FEMASR_MAX_CODEBOOKS */
+    int32_t codebook_scale[FEMASR_MAX_CODEBOOKS];  /* e.g. {32} */
+    int32_t n_e[FEMASR_MAX_CODEBOOKS];             /* e.g. {1024} */
+    int32_t e_dim[FEMASR_MAX_CODEBOOKS];           /* e.g. {512} */
     int32_t device;          /* HIP device ordinal the handle is bound to */
 } femasr_config;
 
@@ -84,9 +87,16 @@ int femasr_set_streams(femasr_handle *h, int n);
  * pad_mode 0 = FeMaSRNet.forward (no pad, output (H*s_out) as produced; femasr_arch.py:470-479)          */
 int femasr_workspace_bytes(const femasr_handle *h, int B, int H, int W, int pad_mode, size_t *bytes);
 
-/* Whole hot path: in NCHW fp32 (B,3,H,W) -> out NCHW fp32 (B,3,H*s,W*s) and, if non-NULL,
- * VQ indices int64 (B,1,h,w).  Replaces FeMaSRNet.encode_and_decode (femasr_arch.py:311-374)
- * inside .test / .forward.  `ws` must be >= femasr_workspace_bytes and 256-byte aligned. */
+/* Shapes of one call: the output image (out_h, out_w), and per codebook the index map (idx_h[q], idx_w[q]) (arrays of
+ * FEMASR_MAX_CODEBOOKS ints).  Follows the reference geometry exactly, including test()'s truncated mirror pad of images
+ * smaller than the pad when there is no Swin stage (femasr_arch.py:454-465). */
+int femasr_forward_shapes(const femasr_handle *h, int H, int W, int pad_mode, int *out_h, int *out_w, int *n_index_maps,
+                          int *idx_h, int *idx_w);
+
+/* Whole hot path: in NCHW fp32 (B,3,H,W) -> out NCHW fp32 (B,3,out_h,out_w) and, if non-NULL, the VQ index maps int64
+ * of all codebooks back to back, map q = (B,1,idx_h[q],idx_w[q]).  Replaces FeMaSRNet.encode_and_decode
+ * (femasr_arch.py:311-374) inside .test / .forward.  `ws` must be >= femasr_workspace_bytes and 256-byte aligned.
+ * Every entry point runs on the handle's device and restores the caller's current device before returning. */
 int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, int H, int W,
                    int pad_mode, float *out_nchw, int64_t *indices, void *ws, size_t ws_bytes);
 
@@ -176,12 +186,19 @@ int femasr_vq(void *stream, const float *z, int64_t M, int D, const float *cb, c
               const float *ee, int n_e, int64_t *idx, float *zq, void *scratch);
 int femasr_row_sqsum(void *stream, const float *x, int64_t rows, int D, float *out);
 int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, const float *cb, int n_e, float *zq);
+/* out (B,H,W,Ca+Cb) = cat(a (B,H,W,Ca), nearest-resize(b (B,Hb,Wb,Cb) -> H x W)) along channels: torch.cat((x, y), 1) of
+ * femasr_arch.py:334 (Hb,Wb == H,W) and CombineQuantBlock's F.interpolate + cat (fema_utils.py:92-99; source index
+ * floor(dst * Hb / H), exact for the integer ratios the architecture produces). */
+int femasr_concat_resize(void *stream, const float *a, int Ca, const float *b, int Hb, int Wb, int Cb, int B, int H, int W,
+                         float *out);
 /* OIHW -> the packed FRAGMENT-MAJOR weight layout of femasr_conv_args.w (also nn.Linear (out,in) with kh=kw=1
  * and the codebook for femasr_vq):  out[q][ntile][lane][kk], zero padded, with
  *   K index k = ((ci/32)*kh*kw + ky*kw + kx)*32 + ci%32 when I % 32 == 0, else (ky*kw + kx)*I + ci;
  *   q = k/32, kk = (k%32)/2, lane = (k&1)*32 + o%32, ntile = o/32.
  * 1x1 layers with I % 32 == 0 (kh = kw = 1: nn.Linear, 1x1 convs, the codebook) get the GEMM layout instead:
  *   out[q][ntile][j][lane][t] = W[o = 32*ntile + lane%32][k = 32q + 8j + 4*(lane/32) + t]   (same size).
+ * 3x3 layers with O <= 4 and I % 32 == 0 (out_conv) additionally carry a compact [k][4] copy behind the matrix (the
+ * direct VALU kernel reads it through scalar loads); femasr_packed_weight_floats includes it.
  * `out` must hold femasr_packed_weight_floats(O,I,kh,kw) floats. */
 size_t femasr_packed_weight_floats(int O, int I, int kh, int kw);
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out);

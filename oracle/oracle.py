@@ -220,8 +220,8 @@ class OracleNet:
 
     def __init__(self, sd, codebook_params=((32, 1024, 512),), gt_resolution=256, LQ_stage=False,
                  scale_factor=4, use_quantize=True, use_residual=True):
-        assert len(codebook_params) == 1, 'single-codebook configs only (SURVEY 8b)'
         self.sd = {k: np.asarray(v) for k, v in sd.items()}
+        self.cb_scales = [int(c[0]) for c in codebook_params]
         self.LQ_stage = bool(LQ_stage)
         self.scale_factor = int(scale_factor) if LQ_stage else 1
         self.gt_res = int(gt_resolution)
@@ -321,35 +321,58 @@ class OracleNet:
         return self._resblock(x, p + '.3', res2=res2)
 
     def encode_and_decode(self, x_nhwc):
-        """femasr_arch.py:311-374; returns (out NHWC, indices (B,1,h,w) int64)."""
+        """femasr_arch.py:311-374; returns (out NHWC, [indices (B,1,h,w) int64 per codebook])."""
         feats = self._encoder(x_nhwc)
         feats = feats[-3:] if self.LQ_stage else feats[::-1]
         fuse_skip = self.LQ_stage and self.use_residual
-        z = self._conv(feats[0], 'before_quant_group.0', 1, 1, 0)
-        self._probe('z', z)
-        b, h, w, d = z.shape
-        idx, zq = vq(z.reshape(-1, d), self.sd['quantize_group.0.embedding.weight'])
-        zq = zq.reshape(b, h, w, d)
-        self._probe('z_q', zq)
-        if not self.use_quantize:
-            zq = z
-        x = self._conv(zq, 'after_quant_group.0.conv', 3)
-        self._probe('after_quant', x)
+        indices = []
+        prev_dec, prev_q, qi = None, None, 0
+        x = feats[0]
         for i in range(self.max_depth):
-            # `x = x + enc_feats[i+1]` (femasr_arch.py:361-362) folded into block i's last conv epilogue
-            skip = feats[i + 1] if (fuse_skip and i + 1 < self.max_depth) else None
-            x = self._decoder_block(x, i, res2=skip)
-            self._probe(f'dec{i}' + ('_plus_skip' if skip is not None else ''), x)
+            cur_res = self.gt_res // 2 ** self.max_depth * 2 ** i
+            if cur_res in self.cb_scales:        # quantise at this scale (femasr_arch.py:332-359)
+                zin = feats[i] if prev_dec is None else np.concatenate((feats[i], prev_dec), axis=-1)
+                z = self._conv(zin, f'before_quant_group.{qi}', 1, 1, 0)
+                if qi == 0:
+                    self._probe('z', z)
+                b, h, w, d = z.shape
+                idx, zq = vq(z.reshape(-1, d), self.sd[f'quantize_group.{qi}.embedding.weight'])
+                zq = zq.reshape(b, h, w, d)
+                if qi == 0:
+                    self._probe('z_q', zq)
+                indices.append(idx.reshape(b, 1, h, w))
+                if not self.use_quantize:
+                    zq = z
+                ain = zq
+                if prev_q is not None:           # CombineQuantBlock: nearest resize of the previous scale + concat (fema_utils.py:92-99)
+                    ys = (np.arange(h) * prev_q.shape[1]) // h
+                    xs = (np.arange(w) * prev_q.shape[2]) // w
+                    ain = np.concatenate((zq, prev_q[:, ys][:, :, xs]), axis=-1)
+                x = self._conv(ain, f'after_quant_group.{qi}.conv', 3)
+                if qi == 0:
+                    self._probe('after_quant', x)
+                prev_q = zq
+                qi += 1
+            elif fuse_skip:
+                # `x = x + enc_feats[i]` (femasr_arch.py:361-362): the kernels fold this add into the previous block's last
+                # conv epilogue (`+ res2`, after `+ res1`); the same fp32 additions in the same order
+                pass
+            nxt_skip = (fuse_skip and i + 1 < self.max_depth and
+                        (self.gt_res // 2 ** self.max_depth * 2 ** (i + 1)) not in self.cb_scales)
+            x = self._decoder_block(x, i, res2=feats[i + 1] if nxt_skip else None)
+            self._probe(f'dec{i}' + ('_plus_skip' if nxt_skip else ''), x)
+            prev_dec = x
         wout, bout = self._conv_w('out_conv')
         out = conv2d(x, wout, bout, 3, 1, 1)
-        return out, idx.reshape(b, 1, h, w)
+        return out, indices
 
     # -- public surface (NCHW in / out like the reference module)
     def forward(self, x_nchw):
         x = _c(x_nchw)
         b, c, h, w = x.shape
         out, idx = self.encode_and_decode(pad_nchw_to_nhwc(x, h, w))
-        return crop_nhwc_to_nchw(out, out.shape[1], out.shape[2]), idx
+        y = crop_nhwc_to_nchw(out, out.shape[1], out.shape[2])
+        return (y, idx[0]) if len(idx) == 1 else (y, idx)
 
     def test(self, x_nchw, return_indices=False):
         x = _c(x_nchw)
@@ -357,9 +380,13 @@ class OracleNet:
         wsz = 8 // self.scale_factor * 8
         hp = (h // wsz + 1) * wsz
         wp = (w // wsz + 1) * wsz
+        if not self.LQ_stage:        # torch.cat([x, flip(x)])[..., :h+pad] holds at most 2h rows (femasr_arch.py:459-460)
+            hp, wp = min(hp, 2 * h), min(wp, 2 * w)
         out, idx = self.encode_and_decode(pad_nchw_to_nhwc(x, hp, wp))
-        y = crop_nhwc_to_nchw(out, h * self.scale_factor, w * self.scale_factor)
-        return (y, idx) if return_indices else y
+        y = crop_nhwc_to_nchw(out, min(h * self.scale_factor, out.shape[1]), min(w * self.scale_factor, out.shape[2]))
+        if not return_indices:
+            return y
+        return (y, idx[0]) if len(idx) == 1 else (y, idx)
 
     def test_tile(self, x_nchw, tile_size=240, tile_pad=16):
         x = _c(x_nchw)

@@ -32,7 +32,12 @@ def lib_weight_layout(w_khwc):
     full[:k, :cout] = rows
     # [q][kk][kslot][ntile][col] -> [q][ntile][kslot][col][kk]
     t = full.reshape(kp // 32, 16, 2, npad // 32, 32).transpose(0, 3, 2, 4, 1)
-    return np.ascontiguousarray(t).reshape(-1)
+    out = np.ascontiguousarray(t).reshape(-1)
+    if cout <= 4 and kh == 3 and kw == 3 and cin % 32 == 0:       # compact [k][4] copy for the direct (VALU) out_conv kernel
+        tail = np.zeros((k, 4), np.float32)
+        tail[:, :cout] = rows
+        out = np.concatenate((out, tail.reshape(-1)))
+    return out
 
 
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,

@@ -43,8 +43,21 @@ def synth_weights(cfg_name, seed, codebook):
 
 def oracle_net(cfg_name, weights):
     from oracle import oracle as orc
-    cfg = CONFIGS[cfg_name]
-    return orc.OracleNet(weights, LQ_stage=cfg['LQ_stage'], scale_factor=cfg.get('scale_factor', 4))
+    cfg = CONFIGS[cfg_name] if isinstance(cfg_name, str) else cfg_name
+    return orc.OracleNet(weights, codebook_params=cfg['codebook_params'], LQ_stage=cfg['LQ_stage'], scale_factor=cfg.get('scale_factor', 4))
+
+
+def golden_cfg(g):
+    """Constructor kwargs of a round-2 golden (tests/golden/make_golden_r2.py)."""
+    return dict(codebook_params=np.asarray(g['codebook_params']).tolist(), LQ_stage=bool(int(g['cfg_LQ_stage'])),
+                scale_factor=int(g['cfg_scale_factor']))
+
+
+def weights_from_arch(cfg, seed, codebook='trained', variant='default'):
+    """{key: ndarray} for any constructor config, key/shape table taken from the build's own arch (CPU construction)."""
+    from femasr_amd.archs import build_network
+    net = build_network(dict(type='FeMaSRNet', **cfg))
+    return synth.fill_state_dict(net.state_dict(), seed, codebook, variant)
 
 
 def ulp_of(x):

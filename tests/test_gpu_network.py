@@ -148,8 +148,21 @@ def test_weight_updates_are_picked_up_and_errors_are_loud(cuda_device):
         net.test(torch.zeros(1, 4, 32, 32, device='cuda'))
     with pytest.raises(FemasrError):
         net.test(torch.zeros(1, 3, 32, 32))            # CPU tensor: no fallback
-    with pytest.raises(ValueError):
-        net(torch.zeros(1, 3, 30, 32, device='cuda'))  # forward() needs /8 sizes (reference would crash in the decoder)
+    # HQ stage (no Swin): like the reference, forward() takes any size (30 -> 29 -> 15 -> 8 -> 4 -> 32 rows out) ...
+    w = dict(w)
+    w['out_conv.bias'] = w['out_conv.bias'] + np.float32(1.0)          # the in-place update made above
+    x30 = synth.synth_input(10, (1, 3, 30, 32))
+    y30 = net(torch.from_numpy(x30).cuda())[0].cpu().numpy()
+    yo, _ = oracle_net('hq', w).forward(x30)
+    assert y30.shape == yo.shape == (1, 3, 32, 32) and np.array_equal(y30, yo)
+    # ... and test() on an image smaller than its mirror pad runs on the truncated flip-concat (femasr_arch.py:459-460)
+    x17 = synth.synth_input(11, (1, 3, 17, 20))
+    y17 = net.test(torch.from_numpy(x17).cuda()).cpu().numpy()
+    assert np.array_equal(y17, oracle_net('hq', w).test(x17))
+    # the LQ stage keeps the Swin divisibility requirement (the reference fails in window_partition)
+    lq = G.build_net('x4', synth_weights('x4', 3, 'trained'))
+    with pytest.raises(FemasrError):
+        lq(torch.zeros(1, 3, 30, 32, device='cuda'))
 
 
 def test_image_pre_post_kernels_exact(cuda_device):

@@ -45,9 +45,17 @@ def test_state_dict_surface_matches_reference(cfg):
     assert net.max_depth == 3 and net.gt_res == 256 and net.use_semantic_loss is False
 
 
-def test_unsupported_variants_raise():
-    with pytest.raises(NotImplementedError):
-        build_network(dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512], [64, 1024, 256]]))
+def test_multi_codebook_keys_and_unsupported_variants():
+    """Two codebooks: the state-dict keys / shapes of femasr_arch.py:277-300 (before_quant on 2x channels, CombineQuantBlock
+    on e_dim[q-1] + e_dim[q]); the reference's own key table for this config is pinned through the hq2 / x4mc goldens, which
+    load synthetic tensors by these keys into the reference with no unexpected key."""
+    net = build_network(dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512], [64, 1024, 256]]))
+    sd = net.state_dict()
+    assert tuple(sd['quantize_group.1.embedding.weight'].shape) == (1024, 256)
+    assert tuple(sd['before_quant_group.1.weight'].shape) == (256, 512, 1, 1)
+    assert tuple(sd['after_quant_group.1.conv.weight'].shape) == (256, 768, 3, 3)
+    with pytest.raises(ValueError):
+        build_network(dict(type='FeMaSRNet', codebook_params=[[32, 1024]]))
     with pytest.raises(NotImplementedError):
         build_network(dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512]], norm_type='bn'))
 

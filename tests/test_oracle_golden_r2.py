@@ -1,0 +1,86 @@
+"""Round-2 pins of the CPU oracle (and of the stock-torch restatement oracle/torch_ref.py) against golden vectors recorded
+from the REFERENCE (tests/golden/make_golden_r2.py): torch-default-init weights, un-scaled out_conv, two-codebook
+configurations (CombineQuantBlock resize + concat), and two images of the reference's testset through the CLI arithmetic.
+Tolerance: 1e-3 max-abs fp32 (north-star); VQ indices exact up to the documented near-tie rule."""
+import io
+
+import numpy as np
+import pytest
+
+from femasr_amd import synth
+from helpers import check_indices_near_tie, golden_cfg, load_golden, oracle_net, weights_from_arch
+
+TOL = 1e-3
+NET_CASES = ['x4_small_torchinit', 'x4_small_unscaled', 'hq2_small_trained', 'x4mc_small_trained']
+
+
+def _setup(name):
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    w = weights_from_arch(cfg, int(g['seed']), str(g['codebook']), str(g['variant']))
+    x = synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))
+    return g, cfg, w, x
+
+
+def _idx_maps(idx):
+    return idx if isinstance(idx, list) else [idx]
+
+
+def check_all_indices(idx_maps, g):
+    """Every codebook's index map vs the reference's, near-tie rule per map. Returns (mismatches, near-tie acceptable)."""
+    bad = acc = 0
+    for q, idx in enumerate(idx_maps):
+        pre = 'vq_' if q == 0 else f'vq{q}_'
+        sub = {'vq_indices': g[pre + 'indices'], 'vq_d_best': g[pre + 'd_best'], 'vq_d_second': g[pre + 'd_second'],
+               'vq_idx_second': g[pre + 'idx_second']}
+        assert np.asarray(idx).shape == sub['vq_indices'].shape
+        b, a = check_indices_near_tie(idx, sub)
+        bad, acc = bad + b, acc + a
+    return bad, acc
+
+
+@pytest.mark.parametrize('name', NET_CASES)
+def test_oracle_matches_reference(name):
+    g, cfg, w, x = _setup(name)
+    net = oracle_net(cfg, w)
+    y, idx = net.test(x, return_indices=True) if str(g['mode']) == 'test' else net.forward(x)
+    assert y.shape == g['output'].shape
+    bad, acc = check_all_indices(_idx_maps(idx), g)
+    assert bad == acc, f'{bad} index mismatches, only {acc} are documented near-ties'
+    if bad == 0:
+        assert np.abs(y - g['output']).max() < TOL, np.abs(y - g['output']).max()
+
+
+@pytest.mark.parametrize('name', NET_CASES)
+def test_torch_ref_is_bit_identical_to_reference(name):
+    """oracle/torch_ref.py (bench.py's stock-torch CPU baseline and second checker) == the reference's own output."""
+    import torch
+    from oracle.torch_ref import TorchRefNet
+    g, cfg, w, x = _setup(name)
+    net = TorchRefNet(w, **cfg)
+    torch.set_num_threads(8)
+    if str(g['mode']) == 'test':
+        y, idx = net.test(x, return_indices=True)
+    else:
+        y, idx = net.forward(x)
+    assert np.array_equal(y.numpy(), g['output'])
+    assert np.array_equal(idx.numpy(), g['vq_indices'])
+
+
+@pytest.mark.parametrize('name', ['png_chip', 'png_comic1'])
+def test_cli_arithmetic_on_testset_png(name):
+    """inference_femasr.py:50-67 + tensor2img on a reference testset image: uint8 in -> uint8 out through the oracle chain."""
+    from PIL import Image
+    from oracle import oracle as orc
+    g = load_golden(name)
+    cfg = dict(codebook_params=[[32, 1024, 512]], LQ_stage=True, scale_factor=4)
+    w = weights_from_arch(cfg, int(g['seed']), 'trained')
+    rgb = np.asarray(Image.open(io.BytesIO(g['png'].tobytes())).convert('RGB'))
+    x = orc.image_u8_to_f32(rgb)
+    y, idx = oracle_net(cfg, w).test(x, return_indices=True)
+    assert np.abs(y[:, :, ::4, ::4] - g['output_f32_stride4']).max() < TOL
+    bad, _ = check_indices_near_tie(idx, g)
+    assert bad == 0
+    out = orc.image_f32_to_u8(y)
+    diff = np.abs(out.astype(np.int16) - g['output_u8'].astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())      # a value within 1e-5 of x.5/255 may round the other way
