@@ -190,6 +190,12 @@ class FeMaSRNet(nn.Module):
         # 'fp32': every layer exact fp32 (bit-identical to the oracle).  'bf16x3': the convs BEHIND the codebook lookup
         # run on the bf16 matrix cores with a 3-term hi/lo split (output within the 1e-3 bound, indices unaffected)
         self.decoder_math = 'fp32'
+        # True: each (shape, mode) class is captured once into a hipGraph (torch.cuda.CUDAGraph around femasr_forward, which
+        # is capture-safe: no allocation / synchronisation inside) and replayed; inputs are copied into the graph's static
+        # buffer and the outputs are copies of its static outputs.  Only pays when the ~330 launches are host-bound (tiny
+        # batches); results are bit-identical.
+        self.use_graph = False
+        self._graphs = {}
 
     # ------------------------------------------------------------------ weight change tracking
     # The native handle holds REPACKED COPIES of the weights.  Changes made through the nn.Module API are seen
@@ -199,6 +205,7 @@ class FeMaSRNet(nn.Module):
         """Force every weight to be re-pushed to the native handle on the next forward."""
         self._pushed = {}
         self._weights_dirty = True
+        self._graphs = {}
 
     def _load_from_state_dict(self, *args, **kwargs):
         self._weights_dirty = True
@@ -303,6 +310,18 @@ class FeMaSRNet(nn.Module):
         return out
 
     # ------------------------------------------------------------------ the path
+    def _launch(self, lib, h, x, pad_mode, oh, ow, sizes):
+        b, _, hh, ww = x.shape
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.femasr_workspace_bytes(h, b, hh, ww, pad_mode, ctypes.byref(nbytes)))
+        ws = self._workspace(nbytes.value, x.device)
+        out = torch.empty((b, 3, oh, ow), dtype=torch.float32, device=x.device)
+        idx_all = torch.empty((sum(sizes),), dtype=torch.int64, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.femasr_forward(h, ctypes.c_void_p(stream), _lib.ptr(x), b, hh, ww, pad_mode,
+                                      _lib.ptr(out), _lib.ptr(idx_all), _lib.ptr(ws), ws.numel()))
+        return out, idx_all, ws
+
     def _run(self, x, pad_mode):
         if x.dim() != 4 or x.shape[1] != self.in_channel:
             raise ValueError(f'expected (B,{self.in_channel},H,W), got {tuple(x.shape)}')
@@ -313,15 +332,28 @@ class FeMaSRNet(nn.Module):
         qh, qw = (ctypes.c_int * _lib.MAX_CODEBOOKS)(), (ctypes.c_int * _lib.MAX_CODEBOOKS)()
         _lib.check(lib.femasr_forward_shapes(h, hh, ww, pad_mode, ctypes.byref(oh), ctypes.byref(ow), ctypes.byref(nq),
                                              ctypes.byref(qh), ctypes.byref(qw)))
-        nbytes = ctypes.c_size_t()
-        _lib.check(lib.femasr_workspace_bytes(h, b, hh, ww, pad_mode, ctypes.byref(nbytes)))
-        ws = self._workspace(nbytes.value, x.device)
-        out = torch.empty((b, 3, oh.value, ow.value), dtype=torch.float32, device=x.device)
         sizes = [b * qh[k] * qw[k] for k in range(nq.value)]
-        idx_all = torch.empty((sum(sizes),), dtype=torch.int64, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(lib.femasr_forward(h, ctypes.c_void_p(stream), _lib.ptr(x), b, hh, ww, pad_mode,
-                                      _lib.ptr(out), _lib.ptr(idx_all), _lib.ptr(ws), ws.numel()))
+        if self.use_graph:
+            key = (b, hh, ww, pad_mode, self.num_streams, self.decoder_math, x.device.index)
+            ent = self._graphs.get(key)
+            if ent is None:
+                if len(self._graphs) > 8:
+                    self._graphs.clear()
+                xs = x.clone()
+                self._launch(lib, h, xs, pad_mode, oh.value, ow.value, sizes)        # warm-up: lazy one-time setup outside capture
+                torch.cuda.synchronize(x.device)
+                g = torch.cuda.CUDAGraph()
+                self._ws = None                                                      # the graph owns its workspace
+                with torch.cuda.graph(g):
+                    so, si, sw = self._launch(lib, h, xs, pad_mode, oh.value, ow.value, sizes)
+                self._ws = None
+                ent = self._graphs[key] = (g, xs, so, si, sw)
+            g, xs, so, si, _ = ent
+            xs.copy_(x)
+            g.replay()
+            out, idx_all = so.clone(), si.clone()
+        else:
+            out, idx_all, _ = self._launch(lib, h, x, pad_mode, oh.value, ow.value, sizes)
         idx, off = [], 0
         for k in range(nq.value):
             idx.append(idx_all[off:off + sizes[k]].view(b, 1, qh[k], qw[k]))

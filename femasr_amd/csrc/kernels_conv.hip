@@ -475,6 +475,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     for (int cc = 0; cc < ncc; ++cc) {
         const float *Pb = Ps + (cc & 1) * PSZ + (lane >> 5);
         const int ccn = cc + 1 < ncc ? cc + 1 : cc;
+        const bool more = cc + 1 < ncc;          // the LOADS stay unconditional (exact wait counters); normalise / activate / store only if needed
         const int nbuf = (cc + 1) & 1;
         float af[2][TM];
         int aidx[TM];
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bc[j] = bn[j];
                 }
-                if (tap == 1 && kk >= 2 && kk < 2 + PUNITS) store_patch_unit(nbuf, kk - 2);
+                if (tap == 1 && kk >= 2 && kk < 2 + PUNITS && more) store_patch_unit(nbuf, kk - 2);      // (uniform) nothing to stage after the last block
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll

@@ -11,6 +11,13 @@ namespace {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// bijective XCD remap (block b runs on XCD b % 8): consecutive logical indices share an XCD
+__device__ __forceinline__ int xcd_remap_misc(int bid, int nblk)
+{
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+}
+
 // ------------------------------------------------------------------------------------------
 // pad / crop (femasr_arch.py:454-465)
 // ------------------------------------------------------------------------------------------
@@ -298,149 +305,31 @@ __global__ void layernorm_kernel(const float *__restrict__ x, long long rows, co
 // ------------------------------------------------------------------------------------------
 // 8x8 (shifted-)window attention (network_swinir.py:114-145,216-237,249-272)
 // ------------------------------------------------------------------------------------------
-// One wave per (batch, window, head); lane i owns query row i.  K and V of the head (64 x 32
-// each) are staged in LDS with a 36-float row pitch (conflict-free b128 stores, broadcast b128
-// reads).  Roll / window partition / reverse are index math; the shift mask is the analytic
-// label test; softmax and both products follow the oracle's sequential orders.
-constexpr int ATT_HD = 32, ATT_N = 64, ATT_LD = 36;
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Packed-fp32 formulation (v_pk_fma_f32: two IEEE fmas per instruction, same rounding as two scalar fmaf):
-//   q.k^T: two KEYS per instruction (K is staged pair-interleaved [j/2][d][j&1]; each score is still ONE fmaf chain over
-//   d = 0..31 from +0), p.V: two output CHANNELS per instruction (each o[d] is still one chain over j = 0..63).
-// The arithmetic per element and its order are unchanged, so the result stays bit-identical to the oracle.
-__global__ __launch_bounds__(64) void window_attention_kernel(const float *__restrict__ qkv, int B, int H, int W, int C,
-                                                              int heads, int shift, const float *__restrict__ table,
-                                                              float *__restrict__ out)
-{
-    __shared__ __attribute__((aligned(16))) float Ks[ATT_N * ATT_HD];          // [j/2][d][2]
-    __shared__ __attribute__((aligned(16))) float Vs[ATT_N * ATT_LD];
-    __shared__ float Ts[225];
-    __shared__ int Ls[ATT_N];
-
-    const int lane = threadIdx.x;
-    const int nwx = W >> 3, nwy = H >> 3;
-    int bid = blockIdx.x;
-    const int h = bid % heads;
-    bid /= heads;
-    const int wx = bid % nwx;
-    bid /= nwx;
-    const int wy = bid % nwy;
-    const int n = bid / nwy;
-
-    const int iy = lane >> 3, ix = lane & 7;
-    const int ys = wy * 8 + iy, xs = wx * 8 + ix;
-    int y = ys + shift, x = xs + shift;
-    if (y >= H) y -= H;
-    if (x >= W) x -= W;
-    const size_t tok = (size_t)n * H * W + (size_t)y * W + x;
-    const int ry = ys < H - 8 ? 0 : (ys < H - shift ? 1 : 2);
-    const int rx = xs < W - 8 ? 0 : (xs < W - shift ? 1 : 2);
-    const int mylab = 3 * ry + rx;
-    Ls[lane] = mylab;
-    for (int i = lane; i < 225; i += 64) Ts[i] = table[i * heads + h];
-
-    const float *base = qkv + tok * 3 * C + h * ATT_HD;
-    const float scale = 0.17677669529663687f;   // (float)(32 ** -0.5)
-    float q[ATT_HD];
-    float *kdst = Ks + (lane >> 1) * (2 * ATT_HD) + (lane & 1);
-#pragma unroll
-    for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
-        const float4 qv = ld4(base + 4 * d4);
-        q[4 * d4 + 0] = qv.x * scale;
-        q[4 * d4 + 1] = qv.y * scale;
-        q[4 * d4 + 2] = qv.z * scale;
-        q[4 * d4 + 3] = qv.w * scale;
-        const float4 kv = ld4(base + C + 4 * d4);
-        kdst[(4 * d4 + 0) * 2] = kv.x;
-        kdst[(4 * d4 + 1) * 2] = kv.y;
-        kdst[(4 * d4 + 2) * 2] = kv.z;
-        kdst[(4 * d4 + 3) * 2] = kv.w;
-        *reinterpret_cast<float4 *>(Vs + lane * ATT_LD + 4 * d4) = ld4(base + 2 * C + 4 * d4);
-    }
-    __syncthreads();
-
-    float s[ATT_N];
-    float m = -INFINITY;
-    // four key pairs (8 scores) at a time: four independent fmaf chains and four LDS reads in flight per step
-#pragma unroll
-    for (int jq = 0; jq < ATT_N / 8; ++jq) {
-        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-        for (int d2 = 0; d2 < ATT_HD / 2; ++d2) {
-            float4 kk[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)      // (k_j[d], k_j+1[d], k_j[d+1], k_j+1[d+1])
-                kk[u] = *reinterpret_cast<const float4 *>(Ks + (4 * jq + u) * (2 * ATT_HD) + 4 * d2);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = __builtin_elementwise_fma(f32x2{q[2 * d2], q[2 * d2]}, f32x2{kk[u].x, kk[u].y}, acc[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                acc[u] = __builtin_elementwise_fma(f32x2{q[2 * d2 + 1], q[2 * d2 + 1]}, f32x2{kk[u].z, kk[u].w}, acc[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = 8 * jq + u;
-            float a1 = acc[u >> 1][u & 1];
-            const int dy = iy - (j >> 3) + 7, dx = ix - (j & 7) + 7;
-            a1 = a1 + Ts[dy * 15 + dx];
-            if (shift > 0) a1 = a1 + (Ls[j] != mylab ? -100.0f : 0.0f);
-            s[j] = a1;
-            m = a1 > m ? a1 : m;
-        }
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < ATT_N; ++j) {
-        s[j] = det_expf(s[j] - m);
-        sum = sum + s[j];
-    }
-    f32x2 o[ATT_HD / 2];
-#pragma unroll
-    for (int d = 0; d < ATT_HD / 2; ++d) o[d] = f32x2{0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < ATT_N; ++j) {
-        const float pj = s[j] / sum;
-        const f32x2 pp = {pj, pj};
-        float4 vv[ATT_HD / 4];
-#pragma unroll
-        for (int d4 = 0; d4 < ATT_HD / 4; ++d4) vv[d4] = *reinterpret_cast<const float4 *>(Vs + j * ATT_LD + 4 * d4);
-#pragma unroll
-        for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
-            o[2 * d4] = __builtin_elementwise_fma(pp, f32x2{vv[d4].x, vv[d4].y}, o[2 * d4]);
-            o[2 * d4 + 1] = __builtin_elementwise_fma(pp, f32x2{vv[d4].z, vv[d4].w}, o[2 * d4 + 1]);
-        }
-    }
-    float *op = out + tok * C + h * ATT_HD;
-#pragma unroll
-    for (int d4 = 0; d4 < ATT_HD / 4; ++d4)
-        *reinterpret_cast<float4 *>(op + 4 * d4) = make_float4(o[2 * d4][0], o[2 * d4][1], o[2 * d4 + 1][0], o[2 * d4 + 1][1]);
-}
-
-// ------------------------------------------------------------------------------------------
-// Window attention on the matrix cores (same arithmetic as window_attention_kernel, bit for bit):
-//   S = (q*scale) K^T  : 2x2 tiles of v_mfma_f32_32x32x2_f32, 16 steps each; step s multiplies d = 2s, 2s+1, i.e. each score
-//                        is the one fmaf chain over d = 0..31 from +0 that the VALU kernel (and the oracle) computes;
-//   S -> LDS -> one ROW per lane: + relative-position bias, + shift mask, sequential max / exp / sum / divide exactly as
-//                        before (the softmax order is per row, so it needs the row in one lane);
-//   O = P V            : 2 tiles x 32 steps; step s multiplies j = 2s, 2s+1: each o[d] is one chain over j = 0..63.
-// One wave per (window, head).  The VALU kernel is bound by the LDS pipe (1040 broadcast ds_read_b128 per wave); here the
-// fragment traffic is 224 ds_read_b32 per wave and the dot products leave the VALU.
-// LDS per wave: Q|K (pitch 33) later re-used for S / P (pitch 68 / 65) and the O transpose, + the bias table: 18.6 KB.
-// ------------------------------------------------------------------------------------------
+// Roll / window partition / reverse are index math; the shift mask is the analytic label test (the reference builds a
+// (nW,64,64) mask tensor); softmax and both products follow the oracle's fixed orders.
+constexpr int ATT_HD = 32, ATT_N = 64;
 typedef float att_f32x16 __attribute__((ext_vector_type(16)));
-constexpr int ATT_QK = 2 * ATT_N * 33;            // floats: Q and K images
-constexpr int ATT_SP = ATT_N * 68;                // floats: score / probability image (>= ATT_QK)
-__global__ __launch_bounds__(64) void window_attention_mfma_kernel(const float *__restrict__ qkv, int B, int H, int W, int C,
-                                                                   int heads, int shift, const float *__restrict__ table,
-                                                                   float *__restrict__ out)
-{
-    __shared__ __attribute__((aligned(16))) float QKs[ATT_SP > ATT_QK ? ATT_SP : ATT_QK];
-    __shared__ float Ts[225];
-    __shared__ int Ls[ATT_N];
 
-    const int lane = threadIdx.x;
+// ------------------------------------------------------------------------------------------
+// Window attention, register-resident form (the one the network runs).  One wave per (sample, window, head).
+// (One 8-wave block per window - all heads of a token read together - measured SLOWER: 173 vs 129 us per launch at B = 16.)
+//   S^T = K (q*scale)^T on v_mfma_f32_32x32x2_f32: tile [32 keys][32 queries], so lane (c = lane&31, half = lane>>5) owns QUERY
+//         row i = 32*ti + c and, in its 16 accumulator registers r of key tile tj, the keys  j = (r&3) + 8(r>>2) + 4*half + 32*tj
+//         - a softmax row lives in ONE lane pair: max / exp / sum need a single cross-half exchange, no LDS transpose;
+//   the probabilities stay in those accumulator registers and ARE the A operand of the P.V MFMA (step (tj, r) multiplies key
+//         j(r,tj,0) in k-slot 0 and j(r,tj,1) in k-slot 1), so each o[d] is one fmaf chain over the keys in the order
+//         0,4,1,5,2,6,3,7 inside every group of 8 - the order oracle/femasr_oracle.c specifies (ORC_KPERM); the partial
+//         sums of the two halves likewise;
+//   K / Q rows are read straight from global (one 128-byte row per lane), V as one float per lane and step (128 contiguous
+//         bytes per half-wave), issued before the softmax so that its VALU work covers their latency; O leaves as 128-byte
+//         row segments.  LDS holds only the 225-entry bias table: no barriers beyond the one after its load.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void window_attention_reg_kernel(const float *__restrict__ qkv, int B, int H, int W, int C,
+                                                                     int heads, int shift, const float *__restrict__ table,
+                                                                     float *__restrict__ out)
+{
+    __shared__ float Ts[232];
+    const int lane = threadIdx.x, c = lane & 31, hf = lane >> 5;
     const int nwx = W >> 3, nwy = H >> 3;
     int bid = blockIdx.x;
     const int h = bid % heads;
@@ -449,136 +338,139 @@ __global__ __launch_bounds__(64) void window_attention_mfma_kernel(const float *
     bid /= nwx;
     const int wy = bid % nwy;
     const int n = bid / nwy;
+    for (int i = lane; i < 225; i += 64) Ts[i] = table[i * heads + h];      // one wave: its own LDS writes are ordered before its reads
 
-    const int iy = lane >> 3, ix = lane & 7;
-    const int ys = wy * 8 + iy, xs = wx * 8 + ix;
-    int y = ys + shift, x = xs + shift;
-    if (y >= H) y -= H;
-    if (x >= W) x -= W;
-    const size_t tok = (size_t)n * H * W + (size_t)y * W + x;
-    const int ry = ys < H - 8 ? 0 : (ys < H - shift ? 1 : 2);
-    const int rx = xs < W - 8 ? 0 : (xs < W - shift ? 1 : 2);
-    const int mylab = 3 * ry + rx;
-    Ls[lane] = mylab;
-    for (int i = lane; i < 225; i += 64) Ts[i] = table[i * heads + h];
-
-    const float *base = qkv + tok * 3 * C + h * ATT_HD;
+    // token offsets of window positions: row part (8 window rows) + column part (8 window columns), roll folded in
+    auto rowtok = [&](int iy) { int y = wy * 8 + iy + shift; if (y >= H) y -= H; return y * W; };
+    auto coltok = [&](int ix) { int x = wx * 8 + ix + shift; if (x >= W) x -= W; return x; };
+    const size_t img = (size_t)n * H * W;
+    const float *qbase = qkv + img * 3 * C + h * ATT_HD;          // this sample / head: 32-bit element offsets from here on
+    float *obase = out + img * C + h * ATT_HD;
     const float scale = 0.17677669529663687f;   // (float)(32 ** -0.5)
-    float *Qs = QKs, *Ks = QKs + ATT_N * 33;
-#pragma unroll
-    for (int d4 = 0; d4 < ATT_HD / 4; ++d4) {
-        const float4 qv = ld4(base + 4 * d4), kv = ld4(base + C + 4 * d4);
-        float *qd = Qs + lane * 33 + 4 * d4, *kd = Ks + lane * 33 + 4 * d4;
-        qd[0] = qv.x * scale; qd[1] = qv.y * scale; qd[2] = qv.z * scale; qd[3] = qv.w * scale;
-        kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-    }
-    // V never touches LDS: its B fragments B[kk][d] = V[j = 2s + (lane>>5)][d = lane&31] are read straight from global
-    // (each half-wave reads one token's 128 contiguous bytes) NOW and consumed in the last phase, so 8 KB per wave stay
-    // in flight across the score and softmax phases (the kernel is HBM-latency bound: more bytes in flight is the lever).
-    float vf[ATT_N / 2];
-    {
-        const float *img = qkv + (size_t)n * H * W * 3 * C + 2 * C + h * ATT_HD + (lane & 31);
-#pragma unroll
-        for (int st = 0; st < ATT_N / 2; ++st) {
-            const int j = 2 * st + (lane >> 5);
-            int yy = wy * 8 + (j >> 3) + shift, xx = wx * 8 + (j & 7) + shift;
-            if (yy >= H) yy -= H;
-            if (xx >= W) xx -= W;
-            vf[st] = img[((size_t)yy * W + xx) * 3 * C];
-        }
-    }
-    __syncthreads();
 
-    // ---- S = Qs K^T on the matrix pipe: A[i][kk] = Qs[32 ti + (lane&31)][2s + (lane>>5)], B[kk][j] = K[32 tj + (lane&31)][2s + (lane>>5)]
-    const int frow = (lane & 31) * 33 + (lane >> 5);
-    att_f32x16 sc[2][2];
+    // ---- operands of S^T: lane (c, hf) holds row (32*t + c) of K / Q, elements d = 2s + hf
+    float ak[2][16], bq[2][16];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int tI = 0; tI < 2; ++tI) {
+        const int w = 32 * tI + c;                     // window position 0..63 of this lane's row
+        const unsigned tok = (unsigned)(rowtok(w >> 3) + coltok(w & 7));
+        const float *kp = qbase + tok * (unsigned)(3 * C) + C, *qp = qbase + tok * (unsigned)(3 * C);
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[ti][tj][r] = 0.f;
-#pragma unroll
-    for (int st = 0; st < ATT_HD / 2; ++st) {
-        float af[2], bf[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            af[u] = Qs[u * 32 * 33 + frow + 2 * st];
-            bf[u] = Ks[u * 32 * 33 + frow + 2 * st];
+        for (int d4 = 0; d4 < 8; ++d4) {
+            const float4 kv = ld4(kp + 4 * d4), qv = ld4(qp + 4 * d4);
+            ak[tI][2 * d4] = hf ? kv.y : kv.x;
+            ak[tI][2 * d4 + 1] = hf ? kv.w : kv.z;
+            bq[tI][2 * d4] = (hf ? qv.y : qv.x) * scale;
+            bq[tI][2 * d4 + 1] = (hf ? qv.w : qv.z) * scale;
         }
+    }
+    att_f32x16 sc[2][2];      // [tj][ti]
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj) sc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ti], bf[tj], sc[ti][tj], 0, 0, 0);
-    }
-    __syncthreads();          // every lane is done with Q / K: their LDS is re-used for the score image
-    float *Ss = QKs;          // [i][68]
+            for (int r = 0; r < 16; ++r) sc[tj][ti][r] = 0.f;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int st = 0; st < 16; ++st)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Ss[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 68 + 32 * tj + (lane & 31)] = sc[ti][tj][r];
-    __syncthreads();
+            for (int ti = 0; ti < 2; ++ti) sc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[tj][st], bq[ti][st], sc[tj][ti], 0, 0, 0);
 
-    // ---- row phase: lane = query i, exactly the VALU kernel's arithmetic
-    float s[ATT_N];
-    float m = -INFINITY;
+    // ---- V operands of O = P V: step (tj, r) needs V[j(r,tj,hf)][d = c]; issued now, consumed after the softmax
+    float vf[2][16];
+    {
+        const float *vb = qbase + 2 * C + c;
+        unsigned cto[4];          // per-lane element offset of the 4 window columns this half touches
 #pragma unroll
-    for (int j4 = 0; j4 < ATT_N / 4; ++j4) {
-        const float4 v4 = *reinterpret_cast<const float4 *>(Ss + lane * 68 + 4 * j4);
-        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        for (int e = 0; e < 4; ++e) cto[e] = (unsigned)coltok(e + 4 * hf) * (unsigned)(3 * C);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = 4 * j4 + u;
-            float a1 = vv[u];
-            const int dy = iy - (j >> 3) + 7, dx = ix - (j & 7) + 7;
-            a1 = a1 + Ts[dy * 15 + dx];
-            if (shift > 0) a1 = a1 + (Ls[j] != mylab ? -100.0f : 0.0f);
-            s[j] = a1;
-            m = a1 > m ? a1 : m;
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(rowtok((r >> 2) + 4 * tj)) * (unsigned)(3 * C);   // uniform
+                vf[tj][r] = vb[ro + cto[r & 3]];
+            }
+    }
+    // ---- softmax per query row (this lane: rows i = 32*ti + c, its half of the keys)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int i = 32 * ti + c, iy = i >> 3, ix = i & 7;
+        const int tb = (iy + 7) * 15 + ix + 7 - 4 * hf;          // bias index of key (jy, jx) is tb - 15*jy - (jx - 4*hf)
+        unsigned rowdiff = 0, coldiff = 0;                         // bit jy / bit (jx - 4*hf): key in another mask region
+        if (shift > 0) {
+            const int ysi = wy * 8 + iy, xsi = wx * 8 + ix;
+            const int ryi = ysi < H - 8 ? 0 : (ysi < H - shift ? 1 : 2), rxi = xsi < W - 8 ? 0 : (xsi < W - shift ? 1 : 2);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ysj = wy * 8 + q, xsj = wx * 8 + q;
+                const int ryj = ysj < H - 8 ? 0 : (ysj < H - shift ? 1 : 2), rxj = xsj < W - 8 ? 0 : (xsj < W - shift ? 1 : 2);
+                rowdiff |= (ryj != ryi ? 1u : 0u) << q;
+                coldiff |= (rxj != rxi ? 1u : 0u) << q;
+            }
+            coldiff >>= 4 * hf;
         }
-    }
-    float sum = 0.f;
+        float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < ATT_N; ++j) {
-        s[j] = det_expf(s[j] - m);
-        sum = sum + s[j];
-    }
-    __syncthreads();          // all rows read: the image is re-used for P, pitch 65 (conflict-free fragment reads)
-    float *Ps = QKs;
+        for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-    for (int j = 0; j < ATT_N; ++j) Ps[lane * 65 + j] = s[j] / sum;
-    __syncthreads();
+            for (int r = 0; r < 16; ++r) {
+                const int jy = (r >> 2) + 4 * tj, jxl = r & 3;
+                float a1 = sc[tj][ti][r] + Ts[tb - 15 * jy - jxl];
+                if (shift > 0) a1 = a1 + ((((rowdiff >> jy) | (coldiff >> jxl)) & 1u) ? -100.0f : 0.0f);
+                sc[tj][ti][r] = a1;
+                m = a1 > m ? a1 : m;
+            }
+        {
+            const float mo = __shfl_xor(m, 32, 64);
+            m = mo > m ? mo : m;
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = det_expf(sc[tj][ti][r] - m);
+                sc[tj][ti][r] = e;
+                part = part + e;
+            }
+        const float other = __shfl_xor(part, 32, 64);
+        const float rinv = 1.0f / (hf ? other + part : part + other);          // half 0 + half 1; one IEEE division per row
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[tj][ti][r] = sc[tj][ti][r] * rinv;
+    }
 
-    // ---- O = P V: A[i][kk] = P[32 ti + (lane&31)][2s + (lane>>5)], B[kk][d] = V[2s + (lane>>5)][d = lane&31]
+    // ---- O = P V: A = probabilities (accumulator registers of S^T), B = V
     att_f32x16 oc[2];
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oc[ti][r] = 0.f;
-    const int prow = (lane & 31) * 65 + (lane >> 5);
 #pragma unroll
-    for (int st = 0; st < ATT_N / 2; ++st) {
-        const float b = vf[st];
-        const float a0 = Ps[prow + 2 * st], a1 = Ps[32 * 65 + prow + 2 * st];
-        oc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, oc[0], 0, 0, 0);
-        oc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, oc[1], 0, 0, 0);
-    }
-    __syncthreads();          // P is dead: transpose O back to one row per lane through the same LDS (pitch 36)
-    float *Os = QKs;
+    for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Os[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = oc[ti][r];
-    __syncthreads();
-    float *op = out + tok * C + h * ATT_HD;
-#pragma unroll
-    for (int d4 = 0; d4 < ATT_HD / 4; ++d4)
-        *reinterpret_cast<float4 *>(op + 4 * d4) = *reinterpret_cast<const float4 *>(Os + lane * 36 + 4 * d4);
-}
+            for (int ti = 0; ti < 2; ++ti) oc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[tj][ti][r], vf[tj][r], oc[ti], 0, 0, 0);
 
+    // ---- store: oc[ti][r] = O[i = 32*ti + (r&3) + 8(r>>2) + 4*hf][d = c]
+    {
+        float *ob = obase + c;
+        unsigned cto[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cto[e] = (unsigned)coltok(e + 4 * hf) * (unsigned)C;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(rowtok((r >> 2) + 4 * ti)) * (unsigned)C;
+                ob[ro + cto[r & 3]] = oc[ti][r];
+            }
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // VQ helpers (femasr_arch.py:35-38,63-66,81-82,95,100,102-112)
@@ -866,16 +758,12 @@ int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W,
 {
     FEMASR_REQUIRE(qkv && table && out && B > 0, "window_attention: bad args");
     FEMASR_REQUIRE(H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8, "window_attention: H,W must be multiples of 8 (%d,%d)", H, W);
-    FEMASR_REQUIRE(heads > 0 && C == heads * ATT_HD, "window_attention: head_dim must be 32 (C=%d heads=%d)", C, heads);
+    FEMASR_REQUIRE(heads > 0 && heads <= 8 && C == heads * ATT_HD, "window_attention: head_dim must be 32, at most 8 heads (C=%d heads=%d)", C, heads);
     FEMASR_REQUIRE(shift >= 0 && shift < 8, "window_attention: bad shift %d", shift);
+    FEMASR_REQUIRE((size_t)H * W * 3 * C < ((size_t)1 << 30), "window_attention: image too large for 32-bit offsets");
     const unsigned grid = (unsigned)((size_t)B * (H / 8) * (W / 8) * heads);
-    static const bool valu = getenv("FEMASR_ATTENTION_VALU") != nullptr;      // the VALU formulation is kept for A/B runs
-    if (valu)
-        hipLaunchKernelGGL(window_attention_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads, shift,
-                           table, out);
-    else
-        hipLaunchKernelGGL(window_attention_mfma_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads,
-                           shift, table, out);
+    hipLaunchKernelGGL(window_attention_reg_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads, shift, table,
+                       out);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

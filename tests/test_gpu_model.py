@@ -1,5 +1,6 @@
-"""GPU end-to-end test of the YAML -> build_model -> validation pipeline against the arch's own
-`test()` and the oracle-backed checks that already pin the arch."""
+"""GPU end-to-end test of the YAML -> build_model -> validation pipeline: the PNGs the pipeline
+saves must equal, bit for bit, the CPU ORACLE chain (uint8 -> /255 -> oracle test() -> clamp / x255 / round -> uint8), and
+the metrics it reports must equal the metric functions evaluated on those oracle images."""
 import os
 
 import numpy as np
@@ -50,15 +51,22 @@ def test_test_pipeline_end_to_end(cuda_device, tmp_path):
     r = results['tiny']
     assert np.isfinite(r['psnr']) and 0.0 < r['ssim'] < 1.0 and r['lpips'] is None       # lpips needs pyiqa: skipped
 
-    net = G.build_net('x4', weights, cuda_device)
     from PIL import Image
+    from helpers import oracle_net
+    from oracle import oracle as orc
+    from femasr_amd.models.femasr_model import calculate_psnr, calculate_ssim
+    onet = oracle_net('x4', weights)
+    psnr = ssim = 0.0
     for name, arr in imgs.items():
-        x = imgproc.u8_to_input(torch.from_numpy(arr).to(cuda_device))
-        want = imgproc.output_to_u8(net.test(x)).cpu().numpy()
+        want = orc.image_f32_to_u8(onet.test(orc.image_u8_to_f32(arr)))         # the oracle chain, CPU
         saved = tmp_path / 'results' / 'pipe' / 'visualization' / 'tiny' / (name[:-4] + '_pipe.png')
         got = np.asarray(Image.open(str(saved)).convert('RGB'))
         assert got.shape == want.shape == (arr.shape[0] * 4, arr.shape[1] * 4, 3)
         assert np.array_equal(got, want), name
+        gt_img = np.asarray(Image.open(str(gt / name)).convert('RGB'))
+        psnr += calculate_psnr(want, gt_img, crop_border=4, test_y_channel=True) / len(imgs)
+        ssim += calculate_ssim(want, gt_img, crop_border=4, test_y_channel=True) / len(imgs)
+    assert abs(r['psnr'] - psnr) < 1e-9 and abs(r['ssim'] - ssim) < 1e-12
 
 
 def test_hq_index_extraction_service(cuda_device, tmp_path):
