@@ -53,10 +53,12 @@ def rocprof_kernel_name(bench_name):
     m = re.match(r'conv3x3_halo_bf16x3<8x16x(\d+),(\w+),up2=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
         return f'conv3x3_halo_bf16x3_kernel<{m.group(1)}, {m.group(4)}, {m.group(5)}, {pro[m.group(2)]}, {m.group(3)}>'
-    m = re.match(r'conv_igemm<(\d+)x(\d+),(\w+),cinvec=(\w+),vq=(\w+),k1=(\w+),waves=(\d)x(\d)>', bench_name)
+    m = re.match(r'conv_igemm<(\d+)x(\d+),(\w+),cinvec=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
-        return (f'conv_igemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(7)}, {m.group(8)}, {pro[m.group(3)]}, '
-                f'{m.group(4)}, {m.group(5)}, {m.group(6)}>')
+        return f'conv_igemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(5)}, {m.group(6)}, {pro[m.group(3)]}, {m.group(4)}>'
+    m = re.match(r'gemm_dma<128x128x(\d)\*8,stages=(\d),act=(\d),nres=(\d),vq=(\w+)>', bench_name)
+    if m:
+        return f'gemm_dma_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>'
     return bench_name
 
 

@@ -668,18 +668,38 @@ __global__ __launch_bounds__(256) void conv3x3_cout3_kernel(const ConvParams p, 
     const int py = t >> 5, px = t & 31;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
     const int ncb = p.Cin >> 5;
-    for (int cb = 0; cb < ncb; ++cb) {
-        if (cb) __syncthreads();
-        // stage the (8+2) x (32+2) halo patch of channel block cb (zero outside the image)
-        for (int u = t; u < C3_PP * 8; u += 256) {
-            const int pix = u >> 3, kq = u & 7;
-            const int sy = oy0 - 1 + pix / C3_PW, sx = ox0 - 1 + pix % C3_PW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
-                v = ld4(p.in + (((size_t)n * p.H + sy) * p.W + sx) * p.Cin + cb * 32 + 4 * kq);
-            *reinterpret_cast<float4 *>(smem + pix * C3_PITCH + 4 * kq) = v;
+    // this thread's patch units (pixel, channel quad): fixed per tile; the next channel block's units are fetched into
+    // registers BEFORE the current block's FMAs and written to LDS after them (one buffer, loads in flight under the math)
+    constexpr int NU = (C3_PP * 8 + 255) / 256;
+    unsigned uoff[NU];
+    unsigned umask = 0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = t + 256 * i, pix = u >> 3, kq = u & 7;
+        const int sy = oy0 - 1 + pix / C3_PW, sx = ox0 - 1 + pix % C3_PW;
+        const bool ok = u < C3_PP * 8 && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+        uoff[i] = ok ? (unsigned)((((size_t)n * p.H + sy) * p.W + sx) * p.Cin + 4 * kq) : 0u;
+        umask |= (ok ? 1u : 0u) << i;
+    }
+    float4 ru[NU];
+    auto fetch = [&](int cb) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) ru[i] = ld4(p.in + (size_t)uoff[i] + cb * 32);
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = t + 256 * i;
+            if (u < C3_PP * 8)
+                *reinterpret_cast<float4 *>(smem + (u >> 3) * C3_PITCH + 4 * (u & 7)) = (umask >> i) & 1u ? ru[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    fetch(0);
+    for (int cb = 0; cb < ncb; ++cb) {
+        if (cb) __syncthreads();          // every wave is done with the previous block's patch
+        stage();
         __syncthreads();
+        fetch(cb + 1 < ncb ? cb + 1 : cb);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float *src = smem + ((py + tap / 3) * C3_PW + px + tap % 3) * C3_PITCH;
