@@ -80,6 +80,14 @@ __device__ __forceinline__ det_f32x2 det_expf2(det_f32x2 x)
     return p * sc;
 }
 
+// SiLU two at a time: the exponential polynomial on the packed ALU, the two IEEE divisions scalar (bit-identical per element)
+__device__ __forceinline__ det_f32x2 det_silu2(det_f32x2 x)
+{
+    const det_f32x2 e = det_expf2(-x);
+    const det_f32x2 d = det_f32x2{1.0f, 1.0f} + e;
+    return det_f32x2{x[0] / d[0], x[1] / d[1]};
+}
+
 __device__ __forceinline__ det_f32x2 det_erff2(det_f32x2 x)
 {
     const det_f32x2 ax = {fminf(fabsf(x[0]), 4.0f), fminf(fabsf(x[1]), 4.0f)};

@@ -407,11 +407,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         const int pix = (t >> 3) + PROWS * i;
         if (PP % PROWS != 0 && i == PUNITS - 1 && pix >= PP) return;     // tail units of the last round
         float4 v = rp[i];
-        if (PRO == FEMASR_PRO_GN_SILU) {
-            v.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
-            v.y = det_silu(__builtin_fmaf(v.y, ga.y, gb.y));
-            v.z = det_silu(__builtin_fmaf(v.z, ga.z, gb.z));
-            v.w = det_silu(__builtin_fmaf(v.w, ga.w, gb.w));
+        if (PRO == FEMASR_PRO_GN_SILU) {     // two elements per instruction on the packed fp32 ALU (IEEE per component: same bits)
+            const det_f32x2 s0 = det_silu2(__builtin_elementwise_fma(det_f32x2{v.x, v.y}, det_f32x2{ga.x, ga.y}, det_f32x2{gb.x, gb.y}));
+            const det_f32x2 s1 = det_silu2(__builtin_elementwise_fma(det_f32x2{v.z, v.w}, det_f32x2{ga.z, ga.w}, det_f32x2{gb.z, gb.w}));
+            v = make_float4(s0[0], s0[1], s1[0], s1[1]);
         }
         if (!(pmask & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding AFTER the activation
         float *dst = Pb + pix * ALD + 4 * kq;

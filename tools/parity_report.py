@@ -1,0 +1,45 @@
+"""Max-abs error table of the HIP path against every reference golden, both math modes (numbers quoted in DESIGN.md)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from femasr_amd import synth  # noqa: E402
+from femasr_amd.archs import build_network  # noqa: E402
+from helpers import CONFIGS, cfg_name_of, golden_cfg, load_golden, synth_weights, weights_from_arch  # noqa: E402
+
+
+def run(name, r2):
+    g = load_golden(name)
+    if r2:
+        cfg = golden_cfg(g)
+        w = weights_from_arch(cfg, int(g['seed']), str(g['codebook']), str(g['variant']))
+    else:
+        cfg = CONFIGS[cfg_name_of(g)]
+        w = synth_weights(cfg_name_of(g), int(g['seed']), str(g['codebook']))
+    net = build_network(dict(type='FeMaSRNet', **cfg))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    net = net.cuda().eval()
+    x = torch.from_numpy(synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))).cuda()
+    st = int(g['out_stride']) if 'out_stride' in g else 1
+    res = {}
+    for math in ('fp32', 'bf16x3'):
+        net.decoder_math = math
+        if str(g['mode']) == 'test':
+            y, idx = net.test_with_all_indices(x)
+        else:
+            y, _, _, idx = net(x)
+        y = y.cpu().numpy()[:, :, ::st, ::st]
+        res[math] = (float(np.abs(y - g['output']).max()), int((idx[0].cpu().numpy().reshape(-1) != g['vq_indices'].reshape(-1)).sum()), y)
+    print(f'{name:22s} |out|max {float(np.abs(g["output"]).max()):8.3f}  fp32 vs reference {res["fp32"][0]:.2e} (idx mismatches {res["fp32"][1]})  '
+          f'bf16x3 vs reference {res["bf16x3"][0]:.2e}  bf16x3 vs fp32 {float(np.abs(res["bf16x3"][2] - res["fp32"][2]).max()):.2e}')
+
+
+for n in ('x4_small_init', 'x4_small_trained', 'x2_small_trained', 'hq_small_trained', 'x4_tile128_init', 'x4_tile128_trained'):
+    run(n, False)
+for n in ('x4_small_torchinit', 'x4_small_unscaled', 'hq2_small_trained', 'x4mc_small_trained'):
+    run(n, True)
