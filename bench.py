@@ -313,11 +313,13 @@ def main():
                 k: {'ms_per_step': round(v[0] / psteps, 3), 'launches_per_step': v[1] // psteps,
                     **({'tflops': round(v[2] / (v[0] * 1e-3) / 1e12, 1)} if v[2] > 0 else {})}
                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-            vq = prof.get('vq(row_sqsum+distance_argmin+finalize)')
+            vq = prof.get('vq(codebook lookup)')
             if vq:          # the north-star's VQ figure: algorithmic HBM bytes (23.37 MB per tile) / time
                 res['roofline']['vq'] = {'ms_per_step': round(vq[0] / psteps, 3), 'algorithmic_GB_per_step': round(vq[3] / psteps / 1e9, 4),
                                          'hbm_GB_s': round(vq[3] / (vq[0] * 1e-3) / 1e9, 1), 'frac_of_8TB_s': round(vq[3] / (vq[0] * 1e-3) / 8e12, 4),
-                                         'tflops': round(vq[2] / (vq[0] * 1e-3) / 1e12, 1)}
+                                         'tflops': round(vq[2] / (vq[0] * 1e-3) / 1e12, 1),
+                                         'search': ('single-pass fp32 MFMA (FEMASR_VQ=gemm)' if os.environ.get('FEMASR_VQ') == 'gemm' else
+                                                    'two-pass exact: bf16 MFMA candidates + fp32 chain re-check (kernels_vq.hip)')}
         if world == 1 and not args.no_second_leg and args.workload == 'tiles16':
             other = 'bf16x3' if args.decoder_math == 'fp32' else 'fp32'
             net.decoder_math = other

@@ -79,6 +79,12 @@ SIGNATURES = {
     'femasr_window_attention': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp]),
     'femasr_vq': (c_int, [vp, vp, c_i64, c_int, vp, vp, vp, c_int, vp, vp, vp]),
     'femasr_row_sqsum': (c_int, [vp, vp, c_i64, c_int, vp]),
+    'femasr_vq_twopass_ok': (c_int, [c_int, c_int]),
+    'femasr_vq_aux_bytes': (szt, [c_int, c_int]),
+    'femasr_vq_prepare': (c_int, [vp, vp, vp, c_int, c_int, vp]),
+    'femasr_vq_scratch_bytes': (szt, [c_i64, c_int]),
+    'femasr_vq_twopass': (c_int, [vp, vp, c_i64, c_int, vp, vp, vp, c_int, vp, vp, vp]),
+    'femasr_vq_candidates': (c_int, [vp, vp, c_i64, c_int, vp, vp, c_int, vp, vp]),
     'femasr_codebook_gather': (c_int, [vp, vp, c_i64, c_int, vp, c_int, vp]),
     'femasr_concat_resize': (c_int, [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'femasr_repack_oihw': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),

@@ -149,6 +149,7 @@ struct femasr_handle {
     std::vector<WSpec> specs;
     std::map<std::string, int> index;
     float *cbT[FEMASR_MAX_CODEBOOKS] = {nullptr, nullptr, nullptr}, *ee[FEMASR_MAX_CODEBOOKS] = {nullptr, nullptr, nullptr};
+    void *vq_aux[FEMASR_MAX_CODEBOOKS] = {nullptr, nullptr, nullptr};       // bf16 codebook image of the two-pass search
     bool finalized = false;
     // profiling
     bool prof = false;
@@ -171,7 +172,7 @@ struct femasr_handle {
 namespace {
 
 enum { SLOT_GN = 0, SLOT_LN, SLOT_ATTN, SLOT_VQ, SLOT_LAYOUT, SLOT_SMALL_COUNT };
-const char *kSmallNames[SLOT_SMALL_COUNT] = {"gn_moments", "layernorm", "window_attention", "vq(row_sqsum+distance_argmin+finalize)",
+const char *kSmallNames[SLOT_SMALL_COUNT] = {"gn_moments", "layernorm", "window_attention", "vq(codebook lookup)",
                                              "pad/crop/gather layout"};
 
 struct Scope {   // event pair around one launch (or a small group of launches)
@@ -591,13 +592,14 @@ int run_tail(Ctx &c, T x, std::vector<T> &feats, bool fuse_skip, bool with_encod
             int64_t *idx = idx_out ? idx_out[nq_done] : nullptr, *idx_tmp = nullptr;
             if (!idx) idx = idx_tmp = (int64_t *)c.arena->alloc((size_t)M * 8);
             {
-                const int nblk = cfg.n_e[q] / 128;
-                float *scratch = c.alloc_f((size_t)M * nblk * 2 + M + 64);
+                float *scratch = c.alloc_f(femasr_vq_scratch_bytes(M, cfg.n_e[q]) / sizeof(float));
                 if (!c.rc && !c.dry()) {
                     Scope sc(h, c.s(), c.dry(), SLOT_VQ, 2.0 * (double)M * cfg.n_e[q] * cfg.e_dim[q],
                              (double)M * cfg.e_dim[q] * 8.0 + (double)cfg.n_e[q] * cfg.e_dim[q] * 4.0 + M * 8.0);
-                    const int rr = femasr_vq(c.s(), z.p, M, cfg.e_dim[q], c.Wt("quantize_group." + qs + ".embedding.weight"), h->cbT[q], h->ee[q],
-                                             cfg.n_e[q], idx, zq.p, scratch);
+                    const float *cbw = c.Wt("quantize_group." + qs + ".embedding.weight");
+                    const int rr = h->vq_aux[q]
+                        ? femasr_vq_twopass(c.s(), z.p, M, cfg.e_dim[q], cbw, h->vq_aux[q], h->ee[q], cfg.n_e[q], idx, zq.p, scratch)
+                        : femasr_vq(c.s(), z.p, M, cfg.e_dim[q], cbw, h->cbT[q], h->ee[q], cfg.n_e[q], idx, zq.p, scratch);
                     if (rr && !c.rc) c.rc = rr;
                 }
                 c.release(scratch);
@@ -786,6 +788,7 @@ void femasr_destroy(femasr_handle *h)
     for (int q = 0; q < FEMASR_MAX_CODEBOOKS; ++q) {
         if (h->cbT[q]) (void)hipFree(h->cbT[q]);
         if (h->ee[q]) (void)hipFree(h->ee[q]);
+        if (h->vq_aux[q]) (void)hipFree(h->vq_aux[q]);
     }
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sub_done) (void)hipEventDestroy(e);
@@ -868,6 +871,17 @@ int femasr_finalize_weights(femasr_handle *h)
         if (rc) return rc;
         rc = femasr_row_sqsum(nullptr, cb, n_e, D, h->ee[q]);
         if (rc) return rc;
+        // two-pass exact search (kernels_vq.hip) where the shape allows; FEMASR_VQ=gemm keeps the single-pass fp32 MFMA
+        const char *mode = getenv("FEMASR_VQ");
+        const bool two = femasr_vq_twopass_ok(n_e, D) && !(mode && !strcmp(mode, "gemm"));
+        if (two) {
+            if (!h->vq_aux[q]) FEMASR_CHECK_HIP(hipMalloc(&h->vq_aux[q], femasr_vq_aux_bytes(n_e, D)));
+            rc = femasr_vq_prepare(nullptr, cb, h->ee[q], n_e, D, h->vq_aux[q]);
+            if (rc) return rc;
+        } else if (h->vq_aux[q]) {
+            (void)hipFree(h->vq_aux[q]);
+            h->vq_aux[q] = nullptr;
+        }
     }
     FEMASR_CHECK_HIP(hipStreamSynchronize(nullptr));
     h->plans.clear();

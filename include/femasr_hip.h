@@ -185,6 +185,20 @@ int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W,
 int femasr_vq(void *stream, const float *z, int64_t M, int D, const float *cb, const float *cbT,
               const float *ee, int n_e, int64_t *idx, float *zq, void *scratch);
 int femasr_row_sqsum(void *stream, const float *x, int64_t rows, int D, float *out);
+/* The same lookup as a two-pass EXACT search (kernels_vq.hip): a bf16-MFMA pass keeps, from a rigorous error bound, the
+ * few codes per row that can be the fp32 first-min; the specified fp32 chain is then evaluated for those only.
+ * Results are bit-identical to femasr_vq.  Shapes: e_dim a power of two in 64..512, n_e % 64 == 0, n_e <= 1024
+ * (femasr_vq_twopass_ok); aux = femasr_vq_prepare(cb, ee) image of femasr_vq_aux_bytes bytes;
+ * scratch >= femasr_vq_scratch_bytes(M, n_e) bytes (covers femasr_vq too). */
+int femasr_vq_twopass_ok(int n_e, int D);
+size_t femasr_vq_aux_bytes(int n_e, int D);
+int femasr_vq_prepare(void *stream, const float *cb, const float *ee, int n_e, int D, void *aux);
+size_t femasr_vq_scratch_bytes(int64_t M, int n_e);
+int femasr_vq_twopass(void *stream, const float *z, int64_t M, int D, const float *cb, const void *aux, const float *ee,
+                      int n_e, int64_t *idx, float *zq, void *scratch);
+/* Pass 1 alone: cand (M,32) uint16 candidate codes, cnt (M) uint16 count (0xFFFF = every code). */
+int femasr_vq_candidates(void *stream, const float *z, int64_t M, int D, const void *aux, const float *ee, int n_e,
+                         uint16_t *cand, uint16_t *cnt);
 int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, const float *cb, int n_e, float *zq);
 /* out (B,H,W,Ca+Cb) = cat(a (B,H,W,Ca), nearest-resize(b (B,Hb,Wb,Cb) -> H x W)) along channels: torch.cat((x, y), 1) of
  * femasr_arch.py:334 (Hb,Wb == H,W) and CombineQuantBlock's F.interpolate + cat (fema_utils.py:92-99; source index

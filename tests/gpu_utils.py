@@ -138,7 +138,8 @@ def window_attention(qkv, b, h, w, c, heads, shift, table):
     return out.cpu().numpy()
 
 
-def vq(z_rows, codebook):
+def vq(z_rows, codebook, mode='gemm'):
+    """mode 'gemm': femasr_vq (single pass, fp32 MFMA); 'twopass': femasr_vq_twopass (bf16 candidates + exact re-check)."""
     lib = _lib.load()
     m, d = z_rows.shape
     n_e = codebook.shape[0]
@@ -149,11 +150,35 @@ def vq(z_rows, codebook):
     _lib.check(lib.femasr_row_sqsum(None, _lib.ptr(tcb), n_e, d, _lib.ptr(ee)))
     idx = torch.full((m,), -1, dtype=torch.int64, device='cuda')
     zq = torch.full((m, d), float('nan'), dtype=torch.float32, device='cuda')
-    scratch = torch.empty(m * (n_e // 128) * 2 + m + 64, dtype=torch.float32, device='cuda')
-    _lib.check(lib.femasr_vq(None, _lib.ptr(tz), m, d, _lib.ptr(tcb), _lib.ptr(cbt), _lib.ptr(ee), n_e,
-                             _lib.ptr(idx), _lib.ptr(zq), _lib.ptr(scratch)))
+    scratch = torch.empty(int(lib.femasr_vq_scratch_bytes(m, n_e)), dtype=torch.uint8, device='cuda')
+    if mode == 'gemm':
+        _lib.check(lib.femasr_vq(None, _lib.ptr(tz), m, d, _lib.ptr(tcb), _lib.ptr(cbt), _lib.ptr(ee), n_e,
+                                 _lib.ptr(idx), _lib.ptr(zq), _lib.ptr(scratch)))
+    else:
+        assert lib.femasr_vq_twopass_ok(n_e, d)
+        aux = torch.empty(int(lib.femasr_vq_aux_bytes(n_e, d)), dtype=torch.uint8, device='cuda')
+        _lib.check(lib.femasr_vq_prepare(None, _lib.ptr(tcb), _lib.ptr(ee), n_e, d, _lib.ptr(aux)))
+        _lib.check(lib.femasr_vq_twopass(None, _lib.ptr(tz), m, d, _lib.ptr(tcb), _lib.ptr(aux), _lib.ptr(ee), n_e,
+                                         _lib.ptr(idx), _lib.ptr(zq), _lib.ptr(scratch)))
     torch.cuda.synchronize()
     return idx.cpu().numpy(), zq.cpu().numpy(), cbt.cpu().numpy(), ee.cpu().numpy()
+
+
+def vq_candidates(z_rows, codebook):
+    """Pass 1 of the two-pass search: (cand (M,32) uint16, cnt (M,) uint16; 0xFFFF = every code)."""
+    lib = _lib.load()
+    m, d = z_rows.shape
+    n_e = codebook.shape[0]
+    tz, tcb = dev(z_rows), dev(codebook)
+    ee = torch.empty((n_e,), dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_row_sqsum(None, _lib.ptr(tcb), n_e, d, _lib.ptr(ee)))
+    aux = torch.empty(int(lib.femasr_vq_aux_bytes(n_e, d)), dtype=torch.uint8, device='cuda')
+    _lib.check(lib.femasr_vq_prepare(None, _lib.ptr(tcb), _lib.ptr(ee), n_e, d, _lib.ptr(aux)))
+    cand = torch.zeros((m, 32), dtype=torch.int16, device='cuda')
+    cnt = torch.zeros((m,), dtype=torch.int16, device='cuda')
+    _lib.check(lib.femasr_vq_candidates(None, _lib.ptr(tz), m, d, _lib.ptr(aux), _lib.ptr(ee), n_e, _lib.ptr(cand), _lib.ptr(cnt)))
+    torch.cuda.synchronize()
+    return cand.cpu().numpy().view('uint16'), cnt.cpu().numpy().view('uint16')
 
 
 def build_net(cfg_name, weights, device='cuda'):
