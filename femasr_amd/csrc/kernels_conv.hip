@@ -349,11 +349,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
 // =================================================================================================================
 // conv3x3_halo: 8 x 16 output pixels of one image x BN channels per block, halo patch per 32-channel block
 // =================================================================================================================
+// UP2: nearest-x2 upsample + conv as FOUR PHASE FILTERS of 2x2 taps on the low-resolution input (oracle/femasr_oracle.c
+// orc_conv_up2_phases): a block takes an 8 x 16 LOW-resolution tile and one phase (a, b); output pixel (2y+a, 2x+b) reads
+// patch rows y+a, y+a+1 and columns x+b, x+b+1 of the ordinary halo patch through the pre-summed weights p.w_up2[phase]
+// (2.25x fewer MFMAs than sweeping the 9 taps over the upsampled image).
 template <int BN, int WM, int WN, int PRO, bool UP2>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_halo_kernel(const ConvParams p)
 {
     constexpr int BM = 128, TW = 16;
-    constexpr int PH = UP2 ? 6 : 10, PW = UP2 ? 10 : 18, PP = PH * PW;     // low-res halo patch when x2 is fused
+    constexpr int PH = 10, PW = 18, PP = PH * PW;
+    constexpr int NTAP = UP2 ? 4 : 9, SC = UP2 ? 2 : 1;
+    static_assert(!(UP2 && PRO != FEMASR_PRO_NONE), "the phase kernel has no prologue");
     constexpr int NT = WM * WN * 64;
     constexpr int PUNITS = (PP * 8 + NT - 1) / NT;
     constexpr int PROWS = NT / 8;
@@ -371,12 +377,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
     const int nb = L % p.NB;
     int tile = L / p.NB;
+    const int pha = UP2 ? (tile >> 1) & 1 : 0, phb = UP2 ? tile & 1 : 0;       // phase innermost: the 4 phases of a tile share its patch in L2
+    if (UP2) tile >>= 2;
     const int tx = tile % p.tilesX;
     tile /= p.tilesX;
     const int ty = tile % p.tilesY;
     const int n = tile / p.tilesY;
-    const int oy0 = ty * 8, ox0 = tx * TW, n0 = nb * BN;
-    const int sy0 = UP2 ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UP2 ? (ox0 >> 1) - 1 : ox0 - 1;
+    const int oy0 = ty * 8, ox0 = tx * TW, n0 = nb * BN;       // tile origin in the conv's own pixel grid (low resolution when UP2)
+    const int sy0 = oy0 - 1, sx0 = ox0 - 1;
 
     // ---- this thread's patch units: (pixel = (t>>3) + PROWS i, channel quad kq)
     const int kq = t & 7;
@@ -428,11 +436,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const size_t wstride = (size_t)p.NT32 << 10;
+    const float *wbase = UP2 ? p.w_up2 + (size_t)(pha * 2 + phb) * ((size_t)(p.Cin / BK) * NTAP) * wstride : p.w;
     const float *wl[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-        wl[j] = p.w + ((((size_t)wtile(n0, wn * TN + j, p.NT32)) * 64 + lane) << 4);
-    const size_t wstride = (size_t)p.NT32 << 10;
+        wl[j] = wbase + ((((size_t)wtile(n0, wn * TN + j, p.NT32)) * 64 + lane) << 4);
 
     const int ncc = p.Cin / BK;
     load_patch(0);
@@ -452,25 +461,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         for (int i = 0; i < TM; ++i) py[i] = (m >> 4) + 2 * i;
     }
 
-    // LDS index of this lane's A-fragment pixel for (tap, row tile i): without the fused x2 upsample ONE per-lane base
-    // plus a compile-time constant (folded into the ds_read offset); with it the halving depends on the lane.
-    const int abase = (py[0] * PW + px) * ALD;
+    // LDS index of this lane's A-fragment pixel for (tap, row tile i): ONE per-lane base (which carries the phase offset)
+    // plus a compile-time constant that folds into the ds_read offset.
+    const int abase = ((py[0] + pha) * PW + px + phb) * ALD;
     auto patch_idx = [&](int tap, int (&idx)[TM]) {
-        const int ky = tap / 3, kx = tap - ky * 3;
+        const int ky = UP2 ? tap >> 1 : tap / 3, kx = UP2 ? tap & 1 : tap - ky * 3;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (UP2) {
-                const int prow = ((py[i] + ky - 1) >> 1) + 1, pcol = ((px + kx - 1) >> 1) + 1;
-                idx[i] = (prow * PW + pcol) * ALD;
-            } else {
-                idx[i] = abase + ((2 * i + ky) * PW + kx) * ALD;
-            }
-        }
+        for (int i = 0; i < TM; ++i) idx[i] = abase + ((2 * i + ky) * PW + kx) * ALD;
     };
 
     // Main loop: unconditional straight-line code (9 taps x 16 k-pair steps unrolled; the last channel block re-stages
     // itself into the idle LDS buffer and re-reads the last weight chunk), so every s_waitcnt the compiler emits is exact.
-    const int nq = ncc * 9;
+    const int nq = ncc * NTAP;
     for (int cc = 0; cc < ncc; ++cc) {
         const float *Pb = Ps + (cc & 1) * PSZ + (lane >> 5);
         const int ccn = cc + 1 < ncc ? cc + 1 : cc;
@@ -482,11 +484,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = Pb[aidx[i]];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int q = cc * 9 + tap;
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int q = cc * NTAP + tap;
             const size_t qn = (size_t)(q + 1 < nq ? q + 1 : nq - 1);
             int nidx[TM];
-            patch_idx(tap < 8 ? tap + 1 : 8, nidx);
+            patch_idx(tap < NTAP - 1 ? tap + 1 : NTAP - 1, nidx);
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
                 const int cur = kk & 1, nxt = cur ^ 1, g = kk >> 2, e = kk & 3;
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
                 if (kk + 1 < BK / 2) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[nxt][i] = Pb[aidx[i] + 2 * (kk + 1)];
-                } else if (tap < 8) {
+                } else if (tap < NTAP - 1) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[nxt][i] = Pb[nidx[i]];
                 }
@@ -525,25 +527,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
 #pragma unroll
             for (int i = 0; i < TM; ++i) aidx[i] = nidx[i];
         }
-        __syncthreads();     // patch buffers swap: ONE barrier per 32-channel block (9 taps x 16 MFMA steps)
+        __syncthreads();     // patch buffers swap: ONE barrier per 32-channel block (NTAP taps x 16 MFMA steps)
     }
 
     // out = (acc + bias) + res1 + res2, in that order (bit-exact contract).  Address = uniform part (SGPRs) + one per-lane
     // offset: element r of row tile i sits at pixel row 2*(wm*TM+i) + (r>>3), pixel column (r&3) + 8*((r>>2)&1) +
     // 4*(lane>>5) of the 8x16 tile.  Full tiles: residual loads are branch-free batches of one 32x32 tile issued one tile
     // ahead of the stores (see conv_igemm_kernel's epilogue for why).
-    const bool full = (oy0 + 8 <= p.Ho) && (ox0 + TW <= p.Wo) && (n0 + BN <= p.Cout);
+    // (UP2: tile pixel (y, x) is stored at (2y + a, 2x + b) of the (Ho, Wo) = (2H, 2W) output: every pixel step doubles)
+    const int Hl = UP2 ? p.H : p.Ho, Wl = UP2 ? p.W : p.Wo;         // extent of the grid the tile indexes
+    const bool full = (oy0 + 8 <= Hl) && (ox0 + TW <= Wl) && (n0 + BN <= p.Cout);
     const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
-    const size_t obase = (((size_t)n * p.Ho + oy0) * p.Wo + ox0) * p.Cout + n0;             // uniform
-    const unsigned loff = (unsigned)(4 * (lane >> 5)) * (unsigned)p.Cout + (unsigned)(lane & 31);
+    const size_t obase = (((size_t)n * p.Ho + SC * oy0 + pha) * p.Wo + SC * ox0 + phb) * p.Cout + n0;             // uniform
+    const unsigned loff = (unsigned)(SC * 4 * (lane >> 5)) * (unsigned)p.Cout + (unsigned)(lane & 31);
     const int wmu = __builtin_amdgcn_readfirstlane(wm), wnu = __builtin_amdgcn_readfirstlane(wn);    // provably uniform copies
     auto uoff = [&](int i, int j, int r) -> size_t {            // uniform
-        return obase + (size_t)((2 * (wmu * TM + i) + (r >> 3)) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1)) * p.Cout + (wnu * TN + j) * 32;
+        return obase + (size_t)(SC * ((2 * (wmu * TM + i) + (r >> 3)) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1))) * p.Cout + (wnu * TN + j) * 32;
     };
     // Fused GroupNorm(32) partial moments of the OUTPUT (consumed by the next conv's GN prologue): fp64 sums of the stored
     // values in the fixed order of oracle/femasr_oracle.c orc_gn_coeffs - per lane over its 16 accumulator registers
     // (level 0), the two lane halves (1), the channels of the group (2), the tile's four 32-pixel blocks (3).
-    const bool gnp = p.gn_part != nullptr;
+    const bool gnp = !UP2 && p.gn_part != nullptr;       // (a phase block's pixels are not an output tile: no fused moments)
     double gs[TM][TN], gss[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -557,12 +561,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
         constexpr int DEPTH = NRES == 1 ? 2 : 1;         // one residual: loads run a tile ahead; two: per-tile batches
         float rbuf[DEPTH][NRES > 0 ? NRES : 1][16];
         auto ok_u = [&](int i, int j, int r) -> bool {
-            return FULL || ((oy0 + 2 * (wmu * TM + i) + (r >> 3)) < p.Ho && (ox0 + (r & 3) + 8 * ((r >> 2) & 1)) < p.Wo &&
+            return FULL || ((oy0 + 2 * (wmu * TM + i) + (r >> 3)) < Hl && (ox0 + (r & 3) + 8 * ((r >> 2) & 1)) < Wl &&
                             (n0 + (wnu * TN + j) * 32) < p.Cout);
         };
         auto ok_l = [&](int i, int j, int r) -> bool {
-            return FULL || ((oy0 + 2 * (wmu * TM + i) + (r >> 3)) < p.Ho &&
-                            (ox0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) < p.Wo &&
+            return FULL || ((oy0 + 2 * (wmu * TM + i) + (r >> 3)) < Hl &&
+                            (ox0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) < Wl &&
                             (n0 + (wnu * TN + j) * 32 + (lane & 31)) < p.Cout);
         };
         auto issue = [&](int tl, int slot) {
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(256) void conv3x3_cout3_kernel(const ConvParams p, 
 template <bool UP2>
 constexpr size_t halo_lds_bytes()
 {
-    return (size_t)(2 * (((((UP2 ? 60 : 180) + 1) * ALD + 3) / 4) * 4)) * sizeof(float);
+    return (size_t)(2 * ((((180 + 1) * ALD + 3) / 4) * 4)) * sizeof(float);
 }
 
 template <int BM>
@@ -767,7 +771,7 @@ Variant g_variants[] = {
     FEMASR_VARIANT(128, 32, 4, 1, FEMASR_PRO_NONE, false),       // 8
     FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, false),              // 9  3x3 s1 halo kernels, 4 waves of 64 px x 64 ch: 9 + cls*3 + (up2 ? 2 : pro)
     FEMASR_HALO(128, 2, 2, FEMASR_PRO_GN_SILU, false),           // 10
-    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, true),               // 11 fused nearest-x2
+    FEMASR_HALO(128, 2, 2, FEMASR_PRO_NONE, true),               // 11 nearest-x2 + conv as 4 phase filters of 2x2 taps
     FEMASR_HALO(64, 2, 2, FEMASR_PRO_NONE, false),               // 12 (64 px x 32 ch per wave)
     FEMASR_HALO(64, 2, 2, FEMASR_PRO_GN_SILU, false),            // 13
     FEMASR_HALO(64, 2, 2, FEMASR_PRO_NONE, true),                // 14
@@ -862,13 +866,16 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     Variant &v = g_variants[vi];
     p.MB = (p.M + v.bm - 1) / v.bm;
     p.NB = (p.Cout + v.bn - 1) / v.bn;
-    if (vi >= kFirstHalo) {   // halo kernels: 2-D tiles of 8 x 16 output pixels per image
-        p.tilesX = (Wo + 15) / 16;
-        p.tilesY = (Ho + 7) / 8;
-        p.MB = a->B * p.tilesX * p.tilesY;
+    const bool phases = vi >= kFirstHalo && a->up2;
+    if (vi >= kFirstHalo) {   // halo kernels: 2-D tiles of 8 x 16 pixels per image (of the low-resolution grid x 4 phases when up2)
+        p.tilesX = ((phases ? a->W : Wo) + 15) / 16;
+        p.tilesY = ((phases ? a->H : Ho) + 7) / 8;
+        p.MB = a->B * p.tilesX * p.tilesY * (phases ? 4 : 1);
     }
-    FEMASR_REQUIRE(!a->gn_part || (vi >= kFirstHalo && femasr_gn_fusable(a->Cout)),
-                   "conv2d: gn_part (fused GroupNorm partial moments) needs a 3x3 stride-1 halo conv and 32 | Cout, Cout/32 a power of two <= 32");
+    FEMASR_REQUIRE(!phases || a->w_up2, "conv2d: a 3x3 nearest-x2 conv with Cin %% 32 == 0 needs w_up2 (femasr_repack_oihw_up2)");
+    p.w_up2 = a->w_up2;
+    FEMASR_REQUIRE(!a->gn_part || (vi >= kFirstHalo && !a->up2 && femasr_gn_fusable(a->Cout)),
+                   "conv2d: gn_part (fused GroupNorm partial moments) needs a 3x3 stride-1 halo conv without x2 and 32 | Cout, Cout/32 a power of two <= 32");
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull)) {
@@ -878,6 +885,7 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), v.lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
-    if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K;
+    // executed multiply-adds: the phase form of an x2 conv runs 4 taps per output pixel where the definition has 9
+    if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K * (phases ? 4.0 / 9.0 : 1.0);
     return FEMASR_OK;
 }

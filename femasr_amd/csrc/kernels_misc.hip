@@ -574,6 +574,37 @@ __global__ void repack_oihw_kernel(const float *__restrict__ in, int O, int I, i
     }
 }
 
+// 3x3 OIHW -> the 4 phase matrices of nearest-x2 + conv (oracle/femasr_oracle.c orc_conv_up2_phases): phase (a, b), slot
+// (ty, tx) holds sum over ky in slot ty (ascending) of (sum over kx in slot tx (ascending) of w[o][ci][ky][kx]), slots
+// a=0: {0},{1,2}; a=1: {0,1},{2}.  Each matrix in the fragment-major layout of a 2x2 conv (k = (cb*4 + ty*2 + tx)*32 + ci%32).
+__global__ void repack_up2_kernel(const float *__restrict__ in, int O, int I, float *__restrict__ out, size_t per_phase)
+{
+    const int K = I * 4, NT32 = (O + 31) / 32;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 4 * per_phase; i += (size_t)gridDim.x * blockDim.x) {
+        const int ph = (int)(i / per_phase);
+        const size_t e = i - (size_t)ph * per_phase;
+        const int kk = (int)(e & 15), lane = (int)((e >> 4) & 63);
+        const size_t rest = e >> 10;
+        const int ntile = (int)(rest % NT32), q = (int)(rest / NT32);
+        const int k = q * 32 + kk * 2 + (lane >> 5), o = ntile * 32 + (lane & 31);
+        float v = 0.f;
+        if (k < K && o < O) {
+            const int a = ph >> 1, b = ph & 1;
+            const int cl = k % 32, r = k / 32, tap = r & 3, ci = (r >> 2) * 32 + cl;
+            const int ty = tap >> 1, tx = tap & 1;
+            const int y0 = ty == 0 ? 0 : (a == 0 ? 1 : 2), y1 = ty == 0 ? (a == 0 ? 0 : 1) : 2;
+            const int x0 = tx == 0 ? 0 : (b == 0 ? 1 : 2), x1 = tx == 0 ? (b == 0 ? 0 : 1) : 2;
+            const float *w = in + ((size_t)o * I + ci) * 9;
+            for (int ky = y0; ky <= y1; ++ky) {
+                float row = w[ky * 3 + x0];
+                for (int kx = x0 + 1; kx <= x1; ++kx) row = row + w[ky * 3 + kx];
+                v = ky == y0 ? row : v + row;
+            }
+        }
+        out[i] = v;
+    }
+}
+
 // compact [k][4] weights of a conv with <= 4 output channels, k in the blocked order above (zero padded to 4 columns)
 __global__ void repack_compact_kernel(const float *__restrict__ in, int O, int I, int kh, int kw, float *__restrict__ out, size_t total)
 {
@@ -841,6 +872,20 @@ int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int 
     }
     hipLaunchKernelGGL(repack_oihw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, O, I, kh, kw, out,
                        total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+size_t femasr_up2_weight_floats(int O, int I)
+{
+    return (I % 32) == 0 ? 4 * femasr_packed_weight_floats(O, I, 2, 2) : 0;
+}
+
+int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *out)
+{
+    FEMASR_REQUIRE(in && out && O > 0 && I > 0 && (I % 32) == 0, "repack_up2: needs a 3x3 OIHW weight with I %% 32 == 0");
+    const size_t per = femasr_packed_weight_floats(O, I, 2, 2);
+    hipLaunchKernelGGL(repack_up2_kernel, dim3(grid_for(4 * per)), dim3(256), 0, (hipStream_t)stream, in, O, I, out, per);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

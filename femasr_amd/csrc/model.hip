@@ -80,6 +80,8 @@ struct WSpec {
     int ndim;
     float *dev = nullptr;   // repacked, owned
     void *split = nullptr;  // bf16x3 hi/lo fragments (decoder-side 3x3 convs only), owned
+    float *up2w = nullptr;  // phase matrices of a nearest-x2 conv (femasr_repack_oihw_up2), owned
+    bool up2 = false;       // the conv behind nn.Upsample(x2) of an up / decoder block
     bool set = false;
     size_t numel() const { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i]; return n; }
 };
@@ -206,10 +208,11 @@ struct Scope {   // event pair around one launch (or a small group of launches)
     }
 };
 
-void add_conv(femasr_handle *h, const std::string &p, int cin, int cout, int k)
+void add_conv(femasr_handle *h, const std::string &p, int cin, int cout, int k, bool up2 = false)
 {
     WSpec w; w.key = p + ".weight"; w.kind = W_CONV; w.ndim = 4;
     w.shape[0] = cout; w.shape[1] = cin; w.shape[2] = k; w.shape[3] = k;
+    w.up2 = up2;
     h->specs.push_back(w);
     WSpec b; b.key = p + ".bias"; b.kind = W_VEC; b.ndim = 1; b.shape[0] = cout;
     h->specs.push_back(b);
@@ -275,7 +278,7 @@ int build_specs(femasr_handle *h)
         for (int u = 0; u < 2; ++u, ++bi) {
             const int ic = channels_at(res), oc = channels_at(res * 2);
             const std::string p = enc + ".blocks." + std::to_string(bi);
-            add_conv(h, p + ".1", ic, oc, 3);
+            add_conv(h, p + ".1", ic, oc, 3, true);
             add_resblock(h, p + ".2", oc);
             add_resblock(h, p + ".3", oc);
             res *= 2;
@@ -287,7 +290,7 @@ int build_specs(femasr_handle *h)
         const int ic = channels_at(r), oc = channels_at(r * 2);
         FEMASR_REQUIRE(ic > 0 && oc > 0, "unsupported decoder resolution %d", r);
         const std::string p = "decoder_group." + std::to_string(i) + ".block";
-        add_conv(h, p + ".1", ic, oc, 3);
+        add_conv(h, p + ".1", ic, oc, 3, true);
         add_resblock(h, p + ".2", oc);
         add_resblock(h, p + ".3", oc);
         out_ch = oc;
@@ -366,7 +369,7 @@ struct Ctx {
         }
         const bool lowp_on = split != nullptr && cout > 4 && femasr_conv_bf16x3_shape_ok(&a);      // out_conv: exact VALU kernel in both modes
         const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
-                                   : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
+                                   : (femasr_conv_halo_eligible(&a) && !o.up2 && femasr_gn_fusable(cout));
         if (o.want_gn && gn_ok) {
             y.gn_tiles = ((Ho + 7) / 8) * ((Wo + 15) / 16);
             y.gn_part = (double *)arena->alloc((size_t)x.B * y.gn_tiles * 32 * 2 * sizeof(double));
@@ -375,6 +378,10 @@ struct Ctx {
         if (rc || dry()) return y;
         a.w = Wt(prefix + ".weight"); a.bias = Wt(prefix + ".bias");
         a.gn_part = y.gn_part;
+        if (o.up2) {
+            auto it = h->index.find(prefix + ".weight");
+            if (it != h->index.end()) a.w_up2 = h->specs[it->second].up2w;
+        }
         if (rc) return y;
         Scope sc(h, s(), dry(), 0, 0.0, 0.0);
         int variant = 0; double flops = 0;
@@ -784,7 +791,7 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
 void femasr_destroy(femasr_handle *h)
 {
     if (!h) return;
-    for (auto &w : h->specs) { if (w.dev) (void)hipFree(w.dev); if (w.split) (void)hipFree(w.split); }
+    for (auto &w : h->specs) { if (w.dev) (void)hipFree(w.dev); if (w.split) (void)hipFree(w.split); if (w.up2w) (void)hipFree(w.up2w); }
     for (int q = 0; q < FEMASR_MAX_CODEBOOKS; ++q) {
         if (h->cbT[q]) (void)hipFree(h->cbT[q]);
         if (h->ee[q]) (void)hipFree(h->ee[q]);
@@ -842,6 +849,11 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
         // feed the codebook lookup either
         const std::string pre = "multiscale_encoder.blocks.";
         if (h->cfg.lq_stage && k.rfind(pre, 0) == 0 && atoi(k.c_str() + pre.size()) > h->encode_depth) dec_side = true;
+    }
+    if (w.kind == W_CONV && w.up2 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {
+        if (!w.up2w) FEMASR_CHECK_HIP(hipMalloc((void **)&w.up2w, femasr_up2_weight_floats((int)w.shape[0], (int)w.shape[1]) * sizeof(float)));
+        rc = femasr_repack_oihw_up2(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.up2w);
+        if (rc) return rc;
     }
     if (w.kind == W_CONV && dec_side && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {
         const size_t nb = femasr_packed_weight_bf16x3_bytes((int)w.shape[0], (int)w.shape[1], 3, 3);

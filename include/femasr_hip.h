@@ -156,7 +156,11 @@ typedef struct {
                              [B][tilesY*tilesX][32][2] doubles, for femasr_gn_coeffs_from_partials (saves the separate
                              moments pass over the tensor).  fp32 path: exactly the partials of the specified
                              summation order (bit-identical coefficients to femasr_gn_coeffs); needs Cout/32 a power of
-                             two <= 32 (bf16x3: <= 8); anything else is refused. */
+                             two <= 32 (bf16x3: <= 8); anything else is refused.  Not with up2. */
+    const float *w_up2;   /* up2 = 1 on a 3x3 stride-1 pad-1 conv with Cin % 32 == 0 (exact fp32 path): the four phase
+                             matrices of femasr_repack_oihw_up2 -- nn.Upsample(x2, nearest) + Conv2d evaluated as four
+                             2x2-tap filters on the low-resolution input (REQUIRED for that shape; other up2 shapes
+                             read the upsampled image through `w`). */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 
@@ -216,6 +220,11 @@ int femasr_concat_resize(void *stream, const float *a, int Ca, const float *b, i
  * `out` must hold femasr_packed_weight_floats(O,I,kh,kw) floats. */
 size_t femasr_packed_weight_floats(int O, int I, int kh, int kw);
 int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int kw, float *out);
+/* 3x3 OIHW -> femasr_conv_args.w_up2: phase (a,b) of nearest-x2 + conv reads input rows {y-1+a, y+a} and columns
+ * {x-1+b, x+b}; slot weights are the fp32 sums of the taps that land on the same input pixel (rows summed over kx first,
+ * ascending; then over ky, ascending).  out: femasr_up2_weight_floats(O, I) floats = 4 x femasr_packed_weight_floats(O,I,2,2). */
+size_t femasr_up2_weight_floats(int O, int I);
+int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *out);
 
 /* Split-bf16 (hi/lo) fragment-major weights for the opt-in bf16x3 conv path (3x3 convs behind the VQ lookup). */
 size_t femasr_packed_weight_bf16x3_bytes(int O, int I, int kh, int kw);

@@ -51,8 +51,13 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
         o_, i_, kh_, kw_ = w_oihw.shape
         wsplit = torch.empty(int(lib.femasr_packed_weight_bf16x3_bytes(o_, i_, kh_, kw_)), dtype=torch.uint8, device='cuda')
         _lib.check(lib.femasr_repack_oihw_bf16x3(None, _lib.ptr(w_oihw), o_, i_, kh_, kw_, _lib.ptr(wsplit)))
-    w_khwc = lib_weight_layout(np.asarray(w_khwc))
     b, h, w, cin = x.shape
+    wup2 = None
+    if up2 and ksz == 3 and stride == 1 and pad == 1 and cin % 32 == 0 and not bf16x3:    # phase-filter form of nearest-x2 + conv
+        w_oihw = dev(np.ascontiguousarray(np.asarray(w_khwc).transpose(3, 2, 0, 1)))
+        wup2 = torch.empty(int(lib.femasr_up2_weight_floats(cout, cin)), dtype=torch.float32, device='cuda')
+        _lib.check(lib.femasr_repack_oihw_up2(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(wup2)))
+    w_khwc = lib_weight_layout(np.asarray(w_khwc))
     hv, wv = (2 * h, 2 * w) if up2 else (h, w)
     ho, wo = (hv + 2 * pad - ksz) // stride + 1, (wv + 2 * pad - ksz) // stride + 1
     tx, tw, tb = dev(x), dev(w_khwc), dev(bias)
@@ -72,6 +77,7 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     a.res2 = None if t2 is None else t2.data_ptr()
     a.out = out.data_ptr(); a.Ho, a.Wo = ho, wo
     a.w_bf16x3 = None if wsplit is None else wsplit.data_ptr()
+    a.w_up2 = None if wup2 is None else wup2.data_ptr()
     part = None
     if gn_part:
         tiles = ((ho + 7) // 8) * ((wo + 15) // 16)

@@ -250,17 +250,41 @@ def test_conv_fp32_fused_gn_moments_bit_exact(cuda_device, cin, cout, shape, up,
     ho, wo = (2 * h, 2 * w) if up else (h, w)
     res = [synth.uniform(18, f'egr{k}', (b, ho, wo, cout), -1, 1) for k in range(nres)]
     r1, r2 = (res + [None, None])[:2]
-    y, part = G.conv2d(x, wt, bias, 3, 1, 1, up, res1=r1, res2=r2, gn_part=True)
-    assert not torch.isnan(part).any()
     y_ref = orc.conv2d(x, wt, bias, 3, 1, 1, up, res1=r1, res2=r2)
-    _same(y, y_ref, 'conv output')
     a_ref, b_ref = orc.gn_coeffs(y_ref, gamma, beta)
-    a, bb = G.gn_coeffs_from_partials(part, ho, wo, cout, gamma, beta)
-    _same(a, a_ref, 'fused gn a')
-    _same(bb, b_ref, 'fused gn b')
+    if up:      # nearest-x2 convs run as four phase filters: a block's pixels are not an output tile, no fused moments
+        with pytest.raises(_lib.FemasrError, match='gn_part'):
+            G.conv2d(x, wt, bias, 3, 1, 1, up, res1=r1, res2=r2, gn_part=True)
+        _same(G.conv2d(x, wt, bias, 3, 1, 1, up, res1=r1, res2=r2), y_ref, 'conv output')
+    else:
+        y, part = G.conv2d(x, wt, bias, 3, 1, 1, up, res1=r1, res2=r2, gn_part=True)
+        assert not torch.isnan(part).any()
+        _same(y, y_ref, 'conv output')
+        a, bb = G.gn_coeffs_from_partials(part, ho, wo, cout, gamma, beta)
+        _same(a, a_ref, 'fused gn a')
+        _same(bb, b_ref, 'fused gn b')
     a2, b2 = G.gn_coeffs(y_ref, gamma, beta)
     _same(a2, a_ref, 'standalone gn a')
     _same(b2, b_ref, 'standalone gn b')
+
+
+@pytest.mark.parametrize('cin,cout,shape,nres', [(32, 64, (1, 8, 16), 0), (64, 96, (2, 11, 19), 1), (128, 40, (1, 5, 33), 2),
+                                                 (256, 128, (1, 16, 16), 0), (64, 3, (1, 9, 7), 0)])
+def test_conv_up2_phase_filters_bit_exact(cuda_device, cin, cout, shape, nres):
+    """nn.Upsample(x2, nearest) + 3x3 conv as four 2x2-tap phase filters with pre-summed fp32 weights: bit-identical to the
+    oracle's restatement of the same form, and within fp32 rounding of the 9-tap definition on the upsampled image."""
+    import gpu_utils as G
+    b, h, w = shape
+    x = synth.uniform(19, 'upx', (b, h, w, cin), -2.0, 2.0)
+    wt = synth.uniform(19, 'upw', (3, 3, cin, cout), -0.1, 0.1)
+    bias = synth.uniform(19, 'upb', (cout,), -0.5, 0.5)
+    res = [synth.uniform(19, f'upr{k}', (b, 2 * h, 2 * w, cout), -1, 1) for k in range(nres)]
+    r1, r2 = (res + [None, None])[:2]
+    y = G.conv2d(x, wt, bias, 3, 1, 1, True, res1=r1, res2=r2)
+    _same(y, orc.conv2d(x, wt, bias, 3, 1, 1, True, res1=r1, res2=r2), 'up2 conv (phase form)')
+    xu = np.repeat(np.repeat(x, 2, axis=1), 2, axis=2)                 # the definition: upsample, then the ordinary conv
+    y_def = orc.conv2d(xu, wt, bias, 3, 1, 1, False, res1=r1, res2=r2)
+    assert np.abs(y - y_def).max() <= 1e-5 * max(1.0, np.abs(y_def).max()), np.abs(y - y_def).max()
 
 
 def test_repack_oihw_layout(cuda_device):
