@@ -38,7 +38,7 @@ class ConvArgs(ctypes.Structure):
         ('act', ctypes.c_int32),
         ('res1', vp), ('res2', vp), ('out', vp),
         ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32),
-        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp),
+        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp), ('w_wino', vp),
     ]
 
 
@@ -90,6 +90,8 @@ SIGNATURES = {
     'femasr_repack_oihw': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'femasr_packed_weight_floats': (szt, [c_int, c_int, c_int, c_int]),
     'femasr_up2_weight_floats': (szt, [c_int, c_int]),
+    'femasr_wino_weight_floats': (szt, [c_int, c_int]),
+    'femasr_repack_oihw_wino': (c_int, [vp, vp, c_int, c_int, vp]),
     'femasr_repack_oihw_up2': (c_int, [vp, vp, c_int, c_int, vp]),
     'femasr_packed_weight_bf16x3_bytes': (szt, [c_int, c_int, c_int, c_int]),
     'femasr_repack_oihw_bf16x3': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),

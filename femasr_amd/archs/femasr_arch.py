@@ -269,10 +269,10 @@ class FeMaSRNet(nn.Module):
             self._version_sum = sum(p_._version for p_ in self.parameters())
             self._weights_dirty = False
         if self._streams_set != (self._handle.value, self.num_streams, self.decoder_math):
-            if self.decoder_math not in ('fp32', 'bf16x3'):
-                raise ValueError(f"decoder_math must be 'fp32' or 'bf16x3', got {self.decoder_math!r}")
+            if self.decoder_math not in ('fp32', 'bf16x3', 'fp32_direct'):
+                raise ValueError(f"decoder_math must be 'fp32', 'bf16x3' or 'fp32_direct', got {self.decoder_math!r}")
             _lib.check(lib.femasr_set_streams(self._handle, int(self.num_streams)))
-            _lib.check(lib.femasr_set_decoder_math(self._handle, 1 if self.decoder_math == 'bf16x3' else 0))
+            _lib.check(lib.femasr_set_decoder_math(self._handle, {'fp32': 0, 'bf16x3': 1, 'fp32_direct': 2}[self.decoder_math]))
             self._streams_set = (self._handle.value, self.num_streams, self.decoder_math)
         return lib, self._handle
 

@@ -51,6 +51,12 @@ int femasr_gemm_variant_count();
 const char *femasr_gemm_variant_name(int v);
 int femasr_repack_k1(hipStream_t s, const float *in, int O, int I, float *out);
 
+// Winograd F(2x2,3x3) 3x3 convs (kernels_wino.hip)
+bool femasr_conv_wino_shape_ok(const femasr_conv_args *a);
+int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out);
+int femasr_conv_wino_variant_count();
+const char *femasr_conv_wino_variant_name(int v);
+
 // bf16x3 3x3 halo convs (kernels_conv_bf16.hip)
 bool femasr_conv_bf16x3_eligible(const femasr_conv_args *a);
 bool femasr_conv_bf16x3_shape_ok(const femasr_conv_args *a);      // the same rule without the w_bf16x3 pointer (planner)

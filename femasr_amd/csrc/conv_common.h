@@ -6,6 +6,7 @@ namespace {
 
 struct ConvParams {
     const float *in, *w, *bias, *pro_a, *pro_b, *pro_c, *res1, *res2;
+    const float *w_wino;  // Winograd-domain weights (femasr_repack_oihw_wino), kernels_wino.hip only
     const float *w_up2;   // 4 phase matrices of a nearest-x2 3x3 conv (femasr_repack_oihw_up2), halo kernels only
     float *out;
     const float *vq_zz, *vq_ee;

@@ -81,6 +81,7 @@ struct WSpec {
     float *dev = nullptr;   // repacked, owned
     void *split = nullptr;  // bf16x3 hi/lo fragments (decoder-side 3x3 convs only), owned
     float *up2w = nullptr;  // phase matrices of a nearest-x2 conv (femasr_repack_oihw_up2), owned
+    float *wino = nullptr;  // Winograd-domain weights (decoder-side 3x3 convs of single-codebook networks), owned
     bool up2 = false;       // the conv behind nn.Upsample(x2) of an up / decoder block
     bool set = false;
     size_t numel() const { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i]; return n; }
@@ -363,11 +364,14 @@ struct Ctx {
         a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
         a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
         const void *split = nullptr;
-        if (o.lowp && h->decoder_math) {
+        if (o.lowp && h->decoder_math == 1) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) split = h->specs[it->second].split;
         }
         const bool lowp_on = split != nullptr && cout > 4 && femasr_conv_bf16x3_shape_ok(&a);      // out_conv: exact VALU kernel in both modes
+        // exact-fp32 mode: convs behind the codebook lookup of a single-codebook network run in the Winograd F(2x2,3x3) form
+        // (they cannot move a VQ index; oracle: OracleNet.wino).  decoder_math 2 = 'fp32_direct' keeps the direct form.
+        const bool wino_on = !lowp_on && o.lowp && h->decoder_math == 0 && h->cfg.n_codebooks == 1 && femasr_conv_wino_shape_ok(&a);
         const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
                                    : (femasr_conv_halo_eligible(&a) && !o.up2 && femasr_gn_fusable(cout));
         if (o.want_gn && gn_ok) {
@@ -386,10 +390,19 @@ struct Ctx {
         Scope sc(h, s(), dry(), 0, 0.0, 0.0);
         int variant = 0; double flops = 0;
         int r;
+        const float *wino_w = nullptr;
+        if (wino_on) {
+            auto it = h->index.find(prefix + ".weight");
+            if (it != h->index.end()) wino_w = h->specs[it->second].wino;
+        }
         if (lowp_on) {
             a.w_bf16x3 = split;
             r = femasr_conv_bf16x3_launch(s(), &a, &variant, &flops);
             variant += femasr_conv_variant_count();
+        } else if (wino_w) {
+            a.w_wino = wino_w;
+            r = femasr_conv_wino_launch(s(), &a, &variant, &flops);
+            variant += femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count();
         } else {
             r = femasr_conv2d_launch(s(), &a, nullptr, &variant, &flops);
         }
@@ -779,11 +792,12 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
     if (!guard.ok) { delete h; return femasr_set_error(FEMASR_ERR_HIP, "hipSetDevice(%d) failed", cfg->device); }
     const int rc = build_specs(h);
     if (rc) { delete h; return rc; }
-    const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count();
+    const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count() + femasr_conv_wino_variant_count();
     h->acc_ms.assign(nslots, 0.0); h->acc_flops.assign(nslots, 0.0); h->acc_bytes.assign(nslots, 0.0); h->acc_n.assign(nslots, 0);
     for (int i = 0; i < SLOT_SMALL_COUNT; ++i) h->slot_names.push_back(kSmallNames[i]);
     for (int i = 0; i < femasr_conv_variant_count(); ++i) h->slot_names.push_back(femasr_conv_variant_name(i));
     for (int i = 0; i < femasr_conv_bf16x3_variant_count(); ++i) h->slot_names.push_back(femasr_conv_bf16x3_variant_name(i));
+    for (int i = 0; i < femasr_conv_wino_variant_count(); ++i) h->slot_names.push_back(femasr_conv_wino_variant_name(i));
     *out = h;
     return FEMASR_OK;
 }
@@ -791,7 +805,7 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
 void femasr_destroy(femasr_handle *h)
 {
     if (!h) return;
-    for (auto &w : h->specs) { if (w.dev) (void)hipFree(w.dev); if (w.split) (void)hipFree(w.split); if (w.up2w) (void)hipFree(w.up2w); }
+    for (auto &w : h->specs) { if (w.dev) (void)hipFree(w.dev); if (w.split) (void)hipFree(w.split); if (w.up2w) (void)hipFree(w.up2w); if (w.wino) (void)hipFree(w.wino); }
     for (int q = 0; q < FEMASR_MAX_CODEBOOKS; ++q) {
         if (h->cbT[q]) (void)hipFree(h->cbT[q]);
         if (h->ee[q]) (void)hipFree(h->ee[q]);
@@ -853,6 +867,12 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
     if (w.kind == W_CONV && w.up2 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {
         if (!w.up2w) FEMASR_CHECK_HIP(hipMalloc((void **)&w.up2w, femasr_up2_weight_floats((int)w.shape[0], (int)w.shape[1]) * sizeof(float)));
         rc = femasr_repack_oihw_up2(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.up2w);
+        if (rc) return rc;
+    }
+    if (w.kind == W_CONV && dec_side && !w.up2 && h->cfg.n_codebooks == 1 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0 &&
+        (w.shape[0] % 64) == 0) {
+        if (!w.wino) FEMASR_CHECK_HIP(hipMalloc((void **)&w.wino, femasr_wino_weight_floats((int)w.shape[0], (int)w.shape[1]) * sizeof(float)));
+        rc = femasr_repack_oihw_wino(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.wino);
         if (rc) return rc;
     }
     if (w.kind == W_CONV && dec_side && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {
@@ -1078,7 +1098,7 @@ int femasr_decode_indices(femasr_handle *h, void *stream, const int64_t *indices
 
 int femasr_set_decoder_math(femasr_handle *h, int mode)
 {
-    FEMASR_REQUIRE(h && (mode == 0 || mode == 1), "set_decoder_math: mode must be 0 (fp32) or 1 (bf16x3)");
+    FEMASR_REQUIRE(h && mode >= 0 && mode <= 2, "set_decoder_math: mode must be 0 (fp32), 1 (bf16x3) or 2 (fp32, direct convs only)");
     if (h->decoder_math != mode) h->plans.clear();
     h->decoder_math = mode;
     return FEMASR_OK;

@@ -161,6 +161,11 @@ typedef struct {
                              matrices of femasr_repack_oihw_up2 -- nn.Upsample(x2, nearest) + Conv2d evaluated as four
                              2x2-tap filters on the low-resolution input (REQUIRED for that shape; other up2 shapes
                              read the upsampled image through `w`). */
+    const float *w_wino;  /* optional: femasr_repack_oihw_wino weights.  When non-NULL the layer (3x3 stride-1 pad-1, no
+                             x2, Cin % 32 == 0, Cout % 64 == 0, no GELU) runs in the Winograd F(2x2,3x3) form: fp32
+                             throughout, 2.25x fewer multiplies, results within fp32 rounding (~1e-6 relative) of the
+                             direct form and bit-identical to oracle/femasr_oracle.c orc_conv3x3_winograd.  The model uses
+                             it for the convs behind the codebook lookup only (they cannot move a VQ index). */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 
@@ -224,15 +229,21 @@ int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int 
  * {x-1+b, x+b}; slot weights are the fp32 sums of the taps that land on the same input pixel (rows summed over kx first,
  * ascending; then over ky, ascending).  out: femasr_up2_weight_floats(O, I) floats = 4 x femasr_packed_weight_floats(O,I,2,2). */
 size_t femasr_up2_weight_floats(int O, int I);
+/* 3x3 OIHW -> femasr_conv_args.w_wino: U = G g G^T per (o, i) with rows then columns, u1 = ((g0 + g1) + g2) * 0.5,
+ * u2 = ((g0 - g1) + g2) * 0.5, packed like a 4x4-tap conv.  out: femasr_wino_weight_floats(O, I) floats. */
+size_t femasr_wino_weight_floats(int O, int I);
+int femasr_repack_oihw_wino(void *stream, const float *in, int O, int I, float *out);
 int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *out);
 
 /* Split-bf16 (hi/lo) fragment-major weights for the opt-in bf16x3 conv path (3x3 convs behind the VQ lookup). */
 size_t femasr_packed_weight_bf16x3_bytes(int O, int I, int kh, int kw);
 int femasr_repack_oihw_bf16x3(void *stream, const float *in, int O, int I, int kh, int kw, void *out);
-/* 0 (default): every layer exact fp32, bit-identical to the oracle.  1: the 3x3 convs that do NOT feed the codebook
- * lookup (after_quant, DecoderBlocks, out_conv, and the encoder's two up-blocks, whose outputs are only the decoder's
- * skip features) use the bf16x3 path: output within the north-star 1e-3 bound of the
- * fp32 result (measured ~1e-4), VQ indices unaffected (everything feeding the argmin stays fp32). */
+/* 0 (default): every layer fp32, bit-identical to the oracle; in single-codebook networks the 3x3 convs that do NOT feed the
+ * codebook lookup (after_quant, DecoderBlocks, the LQ encoder's two up-blocks) run in the Winograd F(2x2,3x3) form (2.25x
+ * fewer multiplies, same fp32 accuracy against the reference, VQ indices unaffected).
+ * 1: those convs (and the x2 convs) use the bf16x3 path instead: output within the north-star 1e-3 bound of the fp32 result
+ *    (measured ~1e-4).
+ * 2: fp32 with every conv in the direct form (the round-1 arithmetic; oracle: OracleNet(winograd=False)). */
 int femasr_set_decoder_math(femasr_handle *h, int mode);
 
 /* ---- image pre / post-processing (the steps either side of the path) ---- */

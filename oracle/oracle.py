@@ -51,7 +51,8 @@ def lib():
         L.orc_window_attention.argtypes = [vp, i, i, i, i, i, i, vp, vp]
         L.orc_vq.argtypes = [vp, i64, i, vp, i, vp, vp, vp, vp]
         L.orc_codebook_gather.argtypes = [vp, i64, i, vp, vp]
-        for fn in ('orc_math_eval', 'orc_pad_nchw_to_nhwc', 'orc_crop_nhwc_to_nchw', 'orc_conv2d',
+        L.orc_conv3x3_winograd.argtypes = [vp, i, i, i, i, vp, vp, i, vp, vp, vp]
+        for fn in ('orc_math_eval', 'orc_pad_nchw_to_nhwc', 'orc_crop_nhwc_to_nchw', 'orc_conv2d', 'orc_conv3x3_winograd',
                    'orc_gn_coeffs', 'orc_scale_shift_silu', 'orc_layernorm', 'orc_window_attention',
                    'orc_vq', 'orc_codebook_gather'):
             getattr(L, fn).restype = None
@@ -101,10 +102,22 @@ def repack_linear_weight(w_oi):
     return _c(np.asarray(w_oi).T)
 
 
-def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, act=0, res1=None, res2=None):
+def winograd_ok(cin, cout, ksz, stride, pad, up2, act=0):
+    """The shapes the kernels run in the Winograd F(2x2,3x3) form when the caller marks the conv as behind the codebook
+    lookup (femasr_conv_args.w_wino): 3x3 stride-1 pad-1, no x2, Cin % 32 == 0, Cout % 64 == 0."""
+    return ksz == 3 and stride == 1 and pad == 1 and not up2 and act == 0 and cin % 32 == 0 and cout % 64 == 0
+
+
+def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, act=0, res1=None, res2=None, wino=False):
     x = _c(x)
     b, h, w, cin = x.shape
     cout = w_khwc.shape[-1]
+    if wino and winograd_ok(cin, cout, ksz, stride, pad, up2, act):
+        out = np.empty((b, h, w, cout), np.float32)
+        res1 = None if res1 is None else _c(res1)
+        res2 = None if res2 is None else _c(res2)
+        lib().orc_conv3x3_winograd(_p(x), b, h, w, cin, _p(_c(w_khwc)), _p(_c(bias)), cout, _p(res1), _p(res2), _p(out))
+        return out
     hv, wv = (2 * h, 2 * w) if up2 else (h, w)
     ho = (hv + 2 * pad - ksz) // stride + 1
     wo = (wv + 2 * pad - ksz) // stride + 1
@@ -219,8 +232,11 @@ class OracleNet:
     """Reference forward restated on the C ops.  `sd` = {key: ndarray} with the reference key names."""
 
     def __init__(self, sd, codebook_params=((32, 1024, 512),), gt_resolution=256, LQ_stage=False,
-                 scale_factor=4, use_quantize=True, use_residual=True):
+                 scale_factor=4, use_quantize=True, use_residual=True, winograd=True):
         self.sd = {k: np.asarray(v) for k, v in sd.items()}
+        # the kernels' default exact-fp32 mode: 3x3 convs behind the codebook lookup of a single-codebook network run in
+        # the Winograd F(2x2,3x3) form (model.hip Ctx::conv `wino`); winograd=False = decoder_math 'fp32_direct'
+        self.wino = bool(winograd) and len(codebook_params) == 1
         self.cb_scales = [int(c[0]) for c in codebook_params]
         self.LQ_stage = bool(LQ_stage)
         self.scale_factor = int(scale_factor) if LQ_stage else 1
@@ -249,16 +265,17 @@ class OracleNet:
             self.probes[name] = val
 
     # -- blocks
-    def _conv(self, x, prefix, ksz, stride=1, pad=1, up2=False, res1=None, res2=None):
+    def _conv(self, x, prefix, ksz, stride=1, pad=1, up2=False, res1=None, res2=None, dec=False):
+        """dec: the conv sits behind the codebook lookup (decoder side)."""
         w, b = self._conv_w(prefix)
-        return conv2d(x, w, b, ksz, stride, pad, up2, 0, res1, res2)
+        return conv2d(x, w, b, ksz, stride, pad, up2, 0, res1, res2, wino=dec and self.wino)
 
-    def _resblock(self, x, prefix, res2=None):
+    def _resblock(self, x, prefix, res2=None, dec=False):
         # fema_utils.py:65-84: conv2(silu(gn2(conv1(silu(gn1(x)))))) + x   (+ optional fused skip add)
         t = gn_silu(x, self.sd[prefix + '.conv.0.norm.weight'], self.sd[prefix + '.conv.0.norm.bias'])
-        t = self._conv(t, prefix + '.conv.2', 3)
+        t = self._conv(t, prefix + '.conv.2', 3, dec=dec)
         t = gn_silu(t, self.sd[prefix + '.conv.3.norm.weight'], self.sd[prefix + '.conv.3.norm.bias'])
-        return self._conv(t, prefix + '.conv.5', 3, res1=x, res2=res2)
+        return self._conv(t, prefix + '.conv.5', 3, res1=x, res2=res2, dec=dec)
 
     def _swin_block(self, x, b, h, w, prefix, shift):
         # network_swinir.py:239-279
@@ -307,8 +324,8 @@ class OracleNet:
             bi += 1
             for _ in range(2):
                 x = self._conv(x, f'{p}.blocks.{bi}.1', 3, 1, 1, up2=True)
-                x = self._resblock(x, f'{p}.blocks.{bi}.2')
-                x = self._resblock(x, f'{p}.blocks.{bi}.3')
+                x = self._resblock(x, f'{p}.blocks.{bi}.2', dec=True)       # the LQ up-blocks only make the decoder's skip features
+                x = self._resblock(x, f'{p}.blocks.{bi}.3', dec=True)
                 self._probe(f'enc_block{bi}', x)
                 outs.append(x)
                 bi += 1
@@ -317,8 +334,8 @@ class OracleNet:
     def _decoder_block(self, x, i, res2=None):
         p = f'decoder_group.{i}.block'
         x = self._conv(x, p + '.1', 3, 1, 1, up2=True)
-        x = self._resblock(x, p + '.2')
-        return self._resblock(x, p + '.3', res2=res2)
+        x = self._resblock(x, p + '.2', dec=True)
+        return self._resblock(x, p + '.3', res2=res2, dec=True)
 
     def encode_and_decode(self, x_nhwc):
         """femasr_arch.py:311-374; returns (out NHWC, [indices (B,1,h,w) int64 per codebook])."""
@@ -348,7 +365,7 @@ class OracleNet:
                     ys = (np.arange(h) * prev_q.shape[1]) // h
                     xs = (np.arange(w) * prev_q.shape[2]) // w
                     ain = np.concatenate((zq, prev_q[:, ys][:, :, xs]), axis=-1)
-                x = self._conv(ain, f'after_quant_group.{qi}.conv', 3)
+                x = self._conv(ain, f'after_quant_group.{qi}.conv', 3, dec=True)
                 if qi == 0:
                     self._probe('after_quant', x)
                 prev_q = zq
@@ -410,7 +427,7 @@ class OracleNet:
         b, _, h, w = indices.shape
         cb = self.sd['quantize_group.0.embedding.weight']
         zq = codebook_gather(indices, cb).reshape(b, h, w, -1)
-        x = self._conv(zq, 'after_quant_group.0.conv', 3)
+        x = self._conv(zq, 'after_quant_group.0.conv', 3, dec=True)
         for i in range(self.max_depth):
             x = self._decoder_block(x, i)
         wout, bout = self._conv_w('out_conv')

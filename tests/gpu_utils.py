@@ -41,7 +41,7 @@ def lib_weight_layout(w_khwc):
 
 
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
-           res1=None, res2=None, bf16x3=False, gn_part=False):
+           res1=None, res2=None, bf16x3=False, gn_part=False, wino=False):
     """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout)."""
     lib = _lib.load()
     cout = np.asarray(w_khwc).shape[-1]
@@ -57,6 +57,11 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
         w_oihw = dev(np.ascontiguousarray(np.asarray(w_khwc).transpose(3, 2, 0, 1)))
         wup2 = torch.empty(int(lib.femasr_up2_weight_floats(cout, cin)), dtype=torch.float32, device='cuda')
         _lib.check(lib.femasr_repack_oihw_up2(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(wup2)))
+    wwino = None
+    if wino:        # Winograd-domain weights, transformed and packed on the GPU from OIHW
+        w_oihw = dev(np.ascontiguousarray(np.asarray(w_khwc).transpose(3, 2, 0, 1)))
+        wwino = torch.empty(int(lib.femasr_wino_weight_floats(cout, cin)), dtype=torch.float32, device='cuda')
+        _lib.check(lib.femasr_repack_oihw_wino(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(wwino)))
     w_khwc = lib_weight_layout(np.asarray(w_khwc))
     hv, wv = (2 * h, 2 * w) if up2 else (h, w)
     ho, wo = (hv + 2 * pad - ksz) // stride + 1, (wv + 2 * pad - ksz) // stride + 1
@@ -78,6 +83,7 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     a.out = out.data_ptr(); a.Ho, a.Wo = ho, wo
     a.w_bf16x3 = None if wsplit is None else wsplit.data_ptr()
     a.w_up2 = None if wup2 is None else wup2.data_ptr()
+    a.w_wino = None if wwino is None else wwino.data_ptr()
     part = None
     if gn_part:
         tiles = ((ho + 7) // 8) * ((wo + 15) // 16)

@@ -287,6 +287,41 @@ def test_conv_up2_phase_filters_bit_exact(cuda_device, cin, cout, shape, nres):
     assert np.abs(y - y_def).max() <= 1e-5 * max(1.0, np.abs(y_def).max()), np.abs(y - y_def).max()
 
 
+@pytest.mark.parametrize('cin,cout,shape,gn,nres,part', [
+    (32, 128, (1, 8, 16), False, 0, False), (64, 128, (2, 16, 32), True, 1, True), (128, 256, (1, 13, 21), True, 2, True),
+    (256, 128, (1, 9, 7), False, 1, False), (64, 64, (1, 24, 40), True, 1, True), (32, 192, (2, 5, 33), False, 0, False),
+    (512, 256, (1, 8, 8), False, 0, False)])
+def test_conv_winograd_bit_exact(cuda_device, cin, cout, shape, gn, nres, part):
+    """3x3 convs in the Winograd F(2x2,3x3) form: bit-identical to the oracle's restatement of the same form (including the
+    fused GroupNorm partial moments of the output), and within fp32 rounding of the direct form."""
+    import gpu_utils as G
+    b, h, w = shape
+    x = synth.uniform(21, 'wix', (b, h, w, cin), -2.0, 2.0)
+    wt = synth.uniform(21, 'wiw', (3, 3, cin, cout), -0.1, 0.1)
+    bias = synth.uniform(21, 'wib', (cout,), -0.5, 0.5)
+    res = [synth.uniform(21, f'wir{k}', (b, h, w, cout), -1, 1) for k in range(nres)]
+    r1, r2 = (res + [None, None])[:2]
+    pro, xin = (None, None, None), x
+    if gn:
+        ga = synth.uniform(21, 'wiga', (b, cin), 0.5, 1.5)
+        gb = synth.uniform(21, 'wigb', (b, cin), -0.5, 0.5)
+        pro, xin = (ga, gb, None), orc.scale_shift_silu(x, ga, gb)
+    got = G.conv2d(x, wt, bias, 3, 1, 1, prologue=_lib.PRO_GN_SILU if gn else 0, pro=pro, res1=r1, res2=r2, wino=True, gn_part=part)
+    y_ref = orc.conv2d(xin, wt, bias, 3, 1, 1, res1=r1, res2=r2, wino=True)
+    y = got[0] if part else got
+    _same(y, y_ref, 'winograd conv')
+    y_dir = orc.conv2d(xin, wt, bias, 3, 1, 1, res1=r1, res2=r2)
+    err = np.abs(y - y_dir).max()
+    assert err <= 2e-5 * max(1.0, np.abs(y_dir).max()), err
+    if part:
+        gamma = synth.uniform(21, 'wigg', (cout,), 0.5, 1.5)
+        beta = synth.uniform(21, 'wigbe', (cout,), -0.5, 0.5)
+        a_ref, b_ref = orc.gn_coeffs(y_ref, gamma, beta)
+        a, bb = G.gn_coeffs_from_partials(got[1], h, w, cout, gamma, beta)
+        _same(a, a_ref, 'fused gn a (winograd)')
+        _same(bb, b_ref, 'fused gn b (winograd)')
+
+
 def test_repack_oihw_layout(cuda_device):
     """femasr_repack_oihw (what set_weight runs) == the documented K-major layout."""
     import gpu_utils as G
