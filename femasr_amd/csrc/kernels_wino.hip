@@ -22,6 +22,17 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef FEMASR_WINO_TT      // tools/build_debug.sh: per-wave cycle shares of the kernel's phases
+__device__ unsigned long long g_wi_tt[8];
+#define WTT(slot) { const unsigned long long now_ = __builtin_readcyclecounter(); tt_acc[slot] += now_ - tt_last; tt_last = now_; }
+#define WTT_INIT unsigned long long tt_acc[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long tt_last = __builtin_readcyclecounter(); const unsigned long long tt_first = tt_last;
+#define WTT_END { if (lane == 0) { for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&g_wi_tt[i_], tt_acc[i_]); atomicAdd(&g_wi_tt[7], __builtin_readcyclecounter() - tt_first); } }
+#else
+#define WTT(slot) {}
+#define WTT_INIT
+#define WTT_END {}
+#endif
+
 namespace {
 
 constexpr int WI_PW = 18, WI_PP = 180;                         // halo patch 10 x 18 pixels
@@ -39,7 +50,7 @@ constexpr size_t wino_lds_bytes()
 }
 static_assert(2 * WI_PSZ + WI_VSZ <= 2 * WI_VSZ, "main-loop buffers fit under the epilogue slabs");
 
-template <int TNW, int PRO>          // TNW: 32-channel tiles per wave and component (BN = 32 TNW)
+template <int TNW, int PRO, int DBG = 0>          // TNW: 32-channel tiles per wave and component (BN = 32 TNW)
 __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams p)
 {
     constexpr int BN = 32 * TNW;
@@ -48,6 +59,7 @@ __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams
     float *Vs = smem + 2 * WI_PSZ;         // [16][32][ALD]
 
     const int t = threadIdx.x, lane = t & 63;
+    WTT_INIT
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c31 = lane & 31, hh = lane >> 5;
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
@@ -141,67 +153,99 @@ __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
 
-    // U fragments: packed like a 4x4-tap conv, K chunk q = cb*16 + component; lane holds 16 consecutive k-pairs of its column
+    // U fragments: [chunk q = cb*16 + component][32-column tile][16-byte group g][lane][4 k-pairs]: one wave load = 1 KiB of
+    // consecutive bytes (8 full cache lines).  Address = uniform pointer + lane * 16 bytes: no per-load VALU arithmetic.
     const size_t wstride = (size_t)p.NT32 << 10;
-    const float *wl[TNW];
+    int wt_[TNW];
 #pragma unroll
-    for (int j = 0; j < TNW; ++j) wl[j] = p.w_wino + ((((size_t)wtile(n0, j, p.NT32)) * 64 + lane) << 4);
+    for (int j = 0; j < TNW; ++j) wt_[j] = wtile(n0, j, p.NT32);
+    const unsigned lw = (unsigned)lane * 16u;
     const int k0 = 2 * wave;
+    auto ldw = [&](size_t q, int g, int j) -> f32x4_t { return ldg4_u32(p.w_wino + q * wstride + ((size_t)wt_[j] * 4 + g) * 256, lw); };
 
     const int ncc = p.Cin / BK;
     load_patch(0);
-    float4 bc[TNW], bn[TNW];
+    f32x4_t bq[2][TNW];          // fragment groups ping-pong between the two sets (8 steps per channel block: parity is stable)
 #pragma unroll
-    for (int j = 0; j < TNW; ++j) bc[j] = ld4(wl[j] + (size_t)k0 * wstride);
+    for (int j = 0; j < TNW; ++j) bq[0][j] = ldw((size_t)k0, 0, j);
     store_patch(0);
     __syncthreads();
 
+    // ---- output-stage geometry (needed early: the residual of the first round is fetched under the last MFMA phase)
+    const bool gnp = p.gn_part != nullptr;
+    const int cg = p.Cout >> 5, gpb = gnp ? BN / cg : 1;
+    const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
+    const size_t obase = (((size_t)n * p.Ho + oy0) * p.Wo + ox0) * p.Cout + n0;
+    const int q = wave & 3, jj = wave >> 2;            // this wave's 32-pixel block and slab in the output stage
+    // element r of (row tile q, column tile j): pixel row 2q + (r>>3), column (r&3) + 8((r>>2)&1) + 4 hh, channel 32 j + c31.
+    // Address = uniform part (SGPRs: q, j come from the wave index) + one per-lane offset, as in conv3x3_halo_kernel.
+    const unsigned loff = (unsigned)(4 * hh) * (unsigned)p.Cout + (unsigned)c31;
+    const bool full = (oy0 + 8 <= p.Ho) && (ox0 + 16 <= p.Wo) && (n0 + BN <= p.Cout);
+    auto uoff = [&](int j, int r) -> size_t {
+        return obase + (size_t)((2 * q + (r >> 3)) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1)) * p.Cout + j * 32;
+    };
+    auto ok_u = [&](int j, int r) -> bool {
+        return full || ((oy0 + 2 * q + (r >> 3)) < p.Ho && (ox0 + (r & 3) + 8 * ((r >> 2) & 1)) < p.Wo && (n0 + j * 32) < p.Cout);
+    };
+    auto ok_l = [&](int j, int r) -> bool {
+        return full || ((oy0 + 2 * q + (r >> 3)) < p.Ho && (ox0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * hh) < p.Wo && (n0 + j * 32 + c31) < p.Cout);
+    };
+    float rv[16];
+    auto fetch_res = [&](const float *src, int j, float (&dst)[16]) {     // branch-free batch; masked elements read the tile origin
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r] = ldg_u32(src + (ok_u(j, r) ? uoff(j, r) : obase), ok_l(j, r) ? 4u * loff : 0u);
+    };
+
     const float *Va = Vs + c31 * ALD + hh;           // A fragment of component k, k-pair kk: Va[k*32*ALD + 2*kk]
+    WTT(0)
     for (int cc = 0; cc < ncc; ++cc) {
-        transform(Ps + (cc & 1) * WI_PSZ);
+        if (!(DBG & 1)) transform(Ps + (cc & 1) * WI_PSZ);
+        WTT(1)
         __syncthreads();                               // V complete; the patch buffer cc&1 is free again
+        WTT(2)
         const int ccn = cc + 1 < ncc ? cc + 1 : cc;
         const bool more = cc + 1 < ncc;
-        load_patch(ccn);
+        if (more) load_patch(ccn);
+        float aq[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aq[0][e] = Va[k0 * 32 * ALD + 2 * e];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {                  // s = component * 4 + 16-byte group of k-pairs
-            const int comp = s >> 2, g = s & 3;
+            const int comp = s >> 2, cur = s & 1, nxt = cur ^ 1;
             {   // next fragment group: this block's next group, or the first group of the next channel block
                 const int sn = s + 1;
                 const size_t qn = sn < 8 ? (size_t)(cc * 16 + k0 + (sn >> 2)) : (size_t)(ccn * 16 + k0);
                 const int gn = sn < 8 ? (sn & 3) : 0;
 #pragma unroll
-                for (int j = 0; j < TNW; ++j) bn[j] = ld4(wl[j] + qn * wstride + 4 * gn);
-            }
-            const float *Vk = Va + (k0 + comp) * 32 * ALD + 8 * g;
-            float a[4];
+                for (int j = 0; j < TNW; ++j) bq[nxt][j] = ldw(qn, gn, j);
+                if (sn < 8) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = Vk[2 * e];
+                    for (int e = 0; e < 4; ++e) aq[nxt][e] = Va[(k0 + (sn >> 2)) * 32 * ALD + 8 * (sn & 3) + 2 * e];
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
+            if (!(DBG & 4))
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < TNW; ++j)
-                    acc[comp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], f4get(bc[j], e), acc[comp][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TNW; ++j) bc[j] = bn[j];
-            if (s == 3 && more) store_patch((cc + 1) & 1);      // (uniform) the loads were issued 64 MFMAs ago
+                    acc[comp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][e], bq[cur][j][e], acc[comp][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (s == 3 && more && !(DBG & 8)) store_patch((cc + 1) & 1);      // (uniform) the loads were issued 64 MFMAs ago
         }
+        WTT(3)
         __syncthreads();                               // every wave is done with V; the next patch is staged
+        WTT(4)
     }
 
     // ---------------------------------------------------------------------------------------------------------------
     // epilogue.  Slabs Ms[jj][k][wt][c] (two 32-channel tiles per round) overlay the patch / V buffers.
     float *Ms = smem;
     double *red = reinterpret_cast<double *>(smem + 2 * WI_VSZ);
-    const bool gnp = p.gn_part != nullptr;
-    const int cg = p.Cout >> 5, gpb = gnp ? BN / cg : 1;
-    const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
-    const size_t obase = (((size_t)n * p.Ho + oy0) * p.Wo + ox0) * p.Cout + n0;
-    const int q = wave & 3, jj = wave >> 2;            // this wave's 32-pixel block and slab in the output stage
+    constexpr int ROUNDS = (TNW + 1) / 2;
+    if (ra && jj < TNW) fetch_res(ra, jj, rv);         // the first round's residual flies under the slab exchange
 #pragma unroll
-    for (int rnd = 0; rnd < (TNW + 1) / 2; ++rnd) {
+    for (int rnd = 0; rnd < ROUNDS; ++rnd) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -212,49 +256,54 @@ __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams
                 for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * hh) * ALD] = acc[c][2 * rnd + sj][r];
             }
         __syncthreads();
+        WTT(5)
         const int j = 2 * rnd + jj;                    // 32-channel tile of the block handled by this wave now
-        if (j < TNW) {
+        if (j < TNW && !(DBG & 2)) {
+            float rn[16], r2[16];
+            const bool next = rnd + 1 < ROUNDS && j + 2 < TNW;
+            if (ra && next) fetch_res(ra, j + 2, rn);  // the next round's residual flies under this round's arithmetic
+            if (rb) fetch_res(rb, j, r2);
             float v[16];
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
                 const int wt = q * 8 + (t4 >> 1) * 4 + 2 * hh + (t4 & 1);
                 const float *src = Ms + ((size_t)(jj * 16) * 32 + wt) * ALD + c31;
-                float m[16], s[2][4];
+                float m[16], sm[2][4];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) m[k] = src[(size_t)k * 32 * ALD];
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    s[0][x] = (m[0 * 4 + x] + m[1 * 4 + x]) + m[2 * 4 + x];
-                    s[1][x] = (m[1 * 4 + x] - m[2 * 4 + x]) - m[3 * 4 + x];
+                    sm[0][x] = (m[0 * 4 + x] + m[1 * 4 + x]) + m[2 * 4 + x];
+                    sm[1][x] = (m[1 * 4 + x] - m[2 * 4 + x]) - m[3 * 4 + x];
                 }
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     const int r0 = dy * 8 + (t4 >> 1) * 4 + (t4 & 1) * 2;
-                    v[r0] = (s[dy][0] + s[dy][1]) + s[dy][2];
-                    v[r0 + 1] = (s[dy][1] - s[dy][2]) - s[dy][3];
+                    v[r0] = (sm[dy][0] + sm[dy][1]) + sm[dy][2];
+                    v[r0 + 1] = (sm[dy][1] - sm[dy][2]) - sm[dy][3];
                 }
             }
             // from here on: the direct halo kernel's epilogue for row tile q, column tile j (same pixel per element r)
             const int col = n0 + j * 32 + c31;
-            const bool cok = col < p.Cout;
-            const float bv = cok ? p.bias[col] : 0.f;
+            const float bv = col < p.Cout ? p.bias[col] : 0.f;
             double gs = 0.0, gss = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int py = 2 * q + (r >> 3), px = (r & 3) + 8 * ((r >> 2) & 1) + 4 * hh;
-                const bool ok = cok && (oy0 + py) < p.Ho && (ox0 + px) < p.Wo;
-                const size_t o = obase + ((size_t)py * p.Wo + px) * p.Cout + j * 32 + c31;
                 float y = v[r] + bv;
-                if (ok) {
-                    if (ra) y = y + ra[o];
-                    if (rb) y = y + rb[o];
-                    p.out[o] = y;
+                if (ra) y = y + rv[r];
+                if (rb) y = y + r2[r];
+                if (ok_l(j, r)) {
+                    stg_u32(p.out + uoff(j, r), 4u * loff, y);
                     if (gnp) {
                         const double d = (double)y;
                         gs = gs + d;
                         gss = __builtin_fma(d, d, gss);
                     }
                 }
+            }
+            if (ra && next) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = rn[r];
             }
             if (gnp) {      // levels 1 and 2 of the moment tree (lane halves, channels of the group), as in conv3x3_halo_kernel
                 double a = gs + __shfl_xor(gs, 32, 64), b = gss + __shfl_xor(gss, 32, 64);
@@ -271,7 +320,9 @@ __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams
             }
         }
         __syncthreads();
+        WTT(6)
     }
+    WTT_END
     if (gnp && t < gpb) {
         const int g = n0 / cg + t;
         if (g < 32) {
@@ -288,24 +339,26 @@ __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams
     }
 }
 
-// 3x3 OIHW -> U = G g G^T as the fragment-major layout of a 4x4-tap conv (k = ((ci/32)*16 + 4 i + j)*32 + ci%32)
+// 3x3 OIHW -> U = G g G^T, K order of a 4x4-tap conv (k = ((ci/32)*16 + 4 i + j)*32 + ci%32), stored as
+// out[q = k/32][ntile][g][lane][t]: column o = 32 ntile + lane%32, k = 32 q + 2 (4 g + t) + lane/32   (same size as the
+// fragment-major layout of femasr_repack_oihw; a wave's 16-byte-per-lane load of one (q, ntile, g) is contiguous)
 __global__ void repack_wino_kernel(const float *__restrict__ in, int O, int I, float *__restrict__ out, size_t total)
 {
     const int K = I * 16, NT32 = (O + 31) / 32;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int kk = (int)(idx & 15), lane = (int)((idx >> 4) & 63);
+        const int tq = (int)(idx & 3), lane = (int)((idx >> 2) & 63), g = (int)((idx >> 8) & 3);
         const size_t rest = idx >> 10;
         const int ntile = (int)(rest % NT32), q = (int)(rest / NT32);
-        const int k = q * 32 + kk * 2 + (lane >> 5), o = ntile * 32 + (lane & 31);
+        const int k = q * 32 + (4 * g + tq) * 2 + (lane >> 5), o = ntile * 32 + (lane & 31);
         float v = 0.f;
         if (k < K && o < O) {
             const int cl = k % 32, r = k / 32, comp = r & 15, ci = (r >> 4) * 32 + cl;
             const int i = comp >> 2, j = comp & 3;
-            const float *g = in + ((size_t)o * I + ci) * 9;
+            const float *gw = in + ((size_t)o * I + ci) * 9;
             float u[3];
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
-                const float g0 = g[x], g1 = g[3 + x], g2 = g[6 + x];
+                const float g0 = gw[x], g1 = gw[3 + x], g2 = gw[6 + x];
                 u[x] = i == 0 ? g0 : (i == 1 ? ((g0 + g1) + g2) * 0.5f : (i == 2 ? ((g0 - g1) + g2) * 0.5f : g2));
             }
             v = j == 0 ? u[0] : (j == 1 ? ((u[0] + u[1]) + u[2]) * 0.5f : (j == 2 ? ((u[0] - u[1]) + u[2]) * 0.5f : u[2]));
@@ -365,7 +418,17 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
         if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
     }
-    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(WI_NT), v.lds, s, p);
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char *e = getenv("FEMASR_WINO_DBG"); dbg = e ? atoi(e) : 0; }
+        void (*k)(const ConvParams) = v.kern;
+        if (dbg && vi == 1) {
+            k = dbg == 1 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 1> : dbg == 2 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 2> : dbg == 3 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 3> :
+                dbg == 4 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 4> : dbg == 8 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 8> : conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 11>;
+            FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+        }
+        hipLaunchKernelGGL(k, dim3((unsigned)(p.MB * p.NB)), dim3(WI_NT), v.lds, s, p);
+    }
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
     // executed multiply-adds: 16 per 2x2 outputs and channel pair (the definition has 36)
@@ -374,6 +437,14 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
 }
 
 extern "C" {
+
+#ifdef FEMASR_WINO_TT
+int femasr_debug_wino_time(unsigned long long *buf, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wi_tt), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_wi_tt), 8 * sizeof(unsigned long long));
+}
+#endif
 
 size_t femasr_wino_weight_floats(int O, int I) { return (I % 32) == 0 ? femasr_packed_weight_floats(O, I, 4, 4) : 0; }
 

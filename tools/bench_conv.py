@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--gn', action='store_true')
     ap.add_argument('--res', action='store_true')
     ap.add_argument('--fp32', action='store_true')
+    ap.add_argument('--wino', action='store_true', help='Winograd F(2x2,3x3) form (fp32)')
     ap.add_argument('--gn-part', action='store_true')
     ap.add_argument('--k1', action='store_true', help='1x1 conv / nn.Linear (fp32 igemm path)')
     ap.add_argument('--gelu', action='store_true')
@@ -55,7 +56,11 @@ def main():
     if a_.res:
         r = torch.randn(b, ho, wo, cout, device=dev)
         args.res1 = r.data_ptr(); keep.append(r)
-    if not a_.fp32 and not a_.k1:
+    if a_.wino:
+        ww = torch.empty(int(lib.femasr_wino_weight_floats(cout, cin)), device=dev)
+        _lib.check(lib.femasr_repack_oihw_wino(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(ww)))
+        args.w_wino = ww.data_ptr(); keep.append(ww)
+    if not a_.fp32 and not a_.k1 and not a_.wino:
         ws = torch.empty(int(lib.femasr_packed_weight_bf16x3_bytes(cout, cin, 3, 3)), dtype=torch.uint8, device=dev)
         _lib.check(lib.femasr_repack_oihw_bf16x3(None, _lib.ptr(w_oihw), cout, cin, 3, 3, _lib.ptr(ws)))
         args.w_bf16x3 = ws.data_ptr(); keep.append(ws)
@@ -66,13 +71,10 @@ def main():
     for _ in range(2):
         _lib.check(lib.femasr_conv2d(None, ctypes.byref(args)))
     torch.cuda.synchronize()
-    tt = os.environ.get('FEMASR_SO') and hasattr(lib._lib if hasattr(lib, '_lib') else lib, 'femasr_debug_taptime')
+    raw = ctypes.CDLL(_lib.SO_PATH) if os.environ.get('FEMASR_SO') else None
+    tt = raw is not None and hasattr(raw, 'femasr_debug_wino_time') and a_.wino
     if tt:
-        raw = lib._lib if hasattr(lib, '_lib') else lib
-        raw.femasr_debug_taptime(None, 1)
-        raw.femasr_debug_set_flags(int(os.environ.get('FEMASR_DBG', '0')))
-        raw.femasr_debug_set_flags16(int(os.environ.get('FEMASR_DBG16', '0')))
-        raw.femasr_debug_igemm_time(None, 1)
+        raw.femasr_debug_wino_time(None, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a_.iters):
@@ -82,15 +84,13 @@ def main():
     ms = e0.elapsed_time(e1) / a_.iters
     fl = 2.0 * b * ho * wo * cout * ks * ks * cin
     if tt:
-        buf = (ctypes.c_ulonglong * 16)()
-        raw.femasr_debug_taptime(buf, 0)
-        tot = float(buf[10]) or 1.0
-        names = ['tap%d' % i for i in range(9)] + ['barrier', 'total', 'prologue', 'epilogue']
-        print('  per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(names) if n != 'total'))
-        print('  total wave-cycles per launch: %.3e' % (tot / a_.iters))
-        raw.femasr_debug_igemm_time(buf, 0)
-        tot = float(buf[5]) or 1.0
-        print('  igemm per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(['mfma', 'store', 'barrier', 'prologue', 'epilogue'])) + '  total/launch %.3e' % (tot / a_.iters))
+        buf = (ctypes.c_ulonglong * 8)()
+        raw.femasr_debug_wino_time(buf, 0)
+        tot = float(buf[7]) or 1.0
+        names = ['prologue', 'transform', 'barrier_T', 'mfma_phase', 'barrier_M', 'slab_exchange', 'output_stage']
+        print('  per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(names)))
+        nwaves = b * ((ho + 7) // 8) * ((wo + 15) // 16) * (cout // (128 if cout % 128 == 0 else 64)) * 8
+        print('  cycles per wave: %.0f' % (tot / (a_.iters + 2) / nwaves))
     print('conv %s dbg=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_DBG', '0') + '/' + os.environ.get('FEMASR_DBG16', '0'),
                                                                     os.environ.get('FEMASR_BF16_CLS', '-'), ms, fl / ms / 1e9))
 

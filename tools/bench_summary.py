@@ -1,8 +1,8 @@
-"""Pretty-print the per-kernel breakdown of a bench.py JSON line (stdin)."""
+"""Pretty-print the per-kernel breakdown of a bench.py JSON line (file argument, or stdin)."""
 import json
 import sys
 
-for line in sys.stdin:
+for line in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
     line = line.strip()
     if not line.startswith('{'):
         print(line[:200])
