@@ -56,6 +56,9 @@ def rocprof_kernel_name(bench_name):
     m = re.match(r'conv_igemm<(\d+)x(\d+),(\w+),cinvec=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
         return f'conv_igemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(5)}, {m.group(6)}, {pro[m.group(3)]}, {m.group(4)}>'
+    m = re.match(r'conv3x3_wino<8x16x(\d)\*32,(\w+),waves=8>', bench_name)
+    if m:
+        return f'conv3x3_wino_kernel<{m.group(1)}, {pro[m.group(2)]}>'
     m = re.match(r'gemm_dma<128x128x(\d)\*8,stages=(\d),act=(\d),nres=(\d),vq=(\w+)>', bench_name)
     if m:
         return f'gemm_dma_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>'
@@ -126,8 +129,9 @@ def main():
     ap.add_argument('--image', type=int, default=2048, help='tile2048: LR image side')
     ap.add_argument('--streams', type=int, default=2, help='sub-batch streams inside one forward (femasr_set_streams)')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra serialized steps (streams=1) for the roofline object')
-    ap.add_argument('--decoder-math', choices=['fp32', 'bf16x3'], default='fp32',
-                    help="'fp32' (bench of record): every layer exact fp32.  'bf16x3': convs behind the VQ lookup on the bf16 "
+    ap.add_argument('--decoder-math', choices=['fp32', 'bf16x3', 'fp32_direct'], default='fp32',
+                    help="'fp32' (bench of record): every layer fp32, bit-identical to the oracle; the 3x3 convs behind the VQ lookup in the "
+                         "Winograd F(2x2,3x3) form.  'fp32_direct': the same with every conv in the direct form.  'bf16x3': convs behind the VQ lookup on the bf16 "
                          'matrix cores (3-term split, within 1e-3) - a secondary mode, reported as such')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default=None)
     ap.add_argument('--dry-net', action='store_true', help='CPU stand-in network (launch-path test; no GPU work, not a measurement)')
@@ -245,7 +249,7 @@ def main():
         'metric': 'SR output megapixels/sec at x4 (128->512)', 'value': round(value, 4), 'unit': 'MPix/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
-        'dtype': 'f32' if args.decoder_math == 'fp32' else 'f32 + bf16x3 split (secondary mode, not the bench of record)',
+        'dtype': 'f32' if args.decoder_math in ('fp32', 'fp32_direct') else 'f32 + bf16x3 split (secondary mode, not the bench of record)',
         'data': 'synthetic' if not dry else 'dry-net stand-in on CPU (launch-path check, NOT a measurement)',
         'config': {'workload': workload, 'workload_name': args.workload,
                    'global_batch': units_per_step, 'tile': '128x128->512x512', 'parallelism': f'tile-parallel x{world}',
@@ -281,6 +285,13 @@ def main():
             psteps = args.profile_steps
             pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
 
+            def issued_share(name):      # MFMA flops issued / algorithmic flops of the layer definition
+                if name.startswith('conv3x3_wino'):
+                    return 16.0 / 36.0
+                if name.startswith('conv3x3_halo<') and 'up2=true' in name:
+                    return 4.0 / 9.0
+                return 1.0
+
             def roof(name):
                 ms, n, fl, _ = convs[name]
                 split = name.startswith('conv3x3_halo_bf16x3')
@@ -296,6 +307,13 @@ def main():
                                      'fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)'}
                 if split:
                     out['mfma_issue_frac'] = round(3 * ach / peak, 4)
+                elif issued_share(name) != 1.0:
+                    out['mfma_issue_frac'] = round(issued_share(name) * ach / peak, 4)
+                    out['peak_basis'] = ('fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32); ALGORITHMIC flops of the layer definition (9 taps per '
+                                         'output pixel) - this kernel issues only %s of them (%s), so the MFMA issue fraction is '
+                                         'mfma_issue_frac and frac can exceed 1' % (
+                                             '16/36' if 'wino' in name else '4/9',
+                                             'Winograd F(2x2,3x3), all fp32' if 'wino' in name else 'nearest-x2 folded into four 2x2-tap phase filters'))
                 if rec:
                     out['traffic_source'] = ('GB per launch, rocprofv3 --pmc FETCH_SIZE (doubled per MI355X_MICROARCH.md HBM '
                                              'section) + WRITE_SIZE passes of this command (profiles/pmc_traffic.json)')
@@ -304,8 +322,10 @@ def main():
             res['roofline'] = roof(dom)
             tot_ms = sum(v[0] for v in convs.values())
             tot_fl = sum(v[2] for v in convs.values())
+            iss_fl = sum(v[2] * (3.0 if k.startswith('conv3x3_halo_bf16x3') else issued_share(k)) for k, v in convs.items())
             res['roofline']['all_mfma_conv_kernels'] = {
                 'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                'issued_tflops': round(iss_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'share_of_serialized_step_time': round(tot_ms / psteps / prof_ms_per_step, 4)}
             res['roofline']['measured_in'] = (f'{psteps} serialized steps (streams=1, {prof_ms_per_step:.1f} ms/step, batch {B} of 128x128 tiles, '
                                               f"decoder_math={args.decoder_math}) right after the timed region")
@@ -321,22 +341,26 @@ def main():
                                          'search': ('single-pass fp32 MFMA (FEMASR_VQ=gemm)' if os.environ.get('FEMASR_VQ') == 'gemm' else
                                                     'two-pass exact: bf16 MFMA candidates + fp32 chain re-check (kernels_vq.hip)')}
         if world == 1 and not args.no_second_leg and args.workload == 'tiles16':
-            other = 'bf16x3' if args.decoder_math == 'fp32' else 'fp32'
-            net.decoder_math = other
-            net.test(x16)
-            sync()
-            te0 = time.perf_counter()
-            for _ in range(args.steps):
-                ye = net.test(x16)
-            sync()
-            te = (time.perf_counter() - te0) / args.steps
-            leg = {'value': round(B * 512 * 512 / 1e6 / te, 4), 'unit': 'MPix/s', 'ms_per_step': round(te * 1e3, 3),
-                   'max_abs_vs_timed_mode': float((ye - y).abs().max()),
-                   'end_to_end_tflops': round(TILE_GFLOP * B / te / 1e3, 2)}
-            if other == 'bf16x3':
-                leg['note'] = ('secondary mode: 698 of 964 GFLOP per tile as 3-pass split-bf16 MFMA (products narrower than fp32); '
-                               'everything feeding the VQ argmin stays exact fp32; NOT the bench of record')
-            res['bf16x3_mode' if other == 'bf16x3' else 'exact_fp32_mode'] = leg
+            legs = ['bf16x3', 'fp32_direct'] if args.decoder_math == 'fp32' else ['fp32']
+            for other in legs:
+                net.decoder_math = other
+                net.test(x16)
+                sync()
+                te0 = time.perf_counter()
+                for _ in range(args.steps):
+                    ye = net.test(x16)
+                sync()
+                te = (time.perf_counter() - te0) / args.steps
+                leg = {'value': round(B * 512 * 512 / 1e6 / te, 4), 'unit': 'MPix/s', 'ms_per_step': round(te * 1e3, 3),
+                       'max_abs_vs_timed_mode': float((ye - y).abs().max()),
+                       'end_to_end_tflops': round(TILE_GFLOP * B / te / 1e3, 2)}
+                if other == 'bf16x3':
+                    leg['note'] = ('secondary mode: 698 of 964 GFLOP per tile as 3-pass split-bf16 MFMA (products narrower than fp32); '
+                                   'everything feeding the VQ argmin stays exact fp32; NOT the bench of record')
+                if other == 'fp32_direct':
+                    leg['note'] = ('the same fp32 network with every 3x3 conv in the direct form (no Winograd behind the VQ lookup): '
+                                   'the arithmetic of rounds 1-2; VQ indices identical, output within fp32 rounding of the timed mode')
+                res[{'bf16x3': 'bf16x3_mode', 'fp32_direct': 'fp32_direct_mode', 'fp32': 'exact_fp32_mode'}[other]] = leg
             net.decoder_math = args.decoder_math
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(net, x16, y if args.workload == 'tiles16' else None, B)

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
     // Fused GroupNorm(32) partial moments of the OUTPUT (consumed by the next conv's GN prologue): fp64 sums of the stored
     // values in the fixed order of oracle/femasr_oracle.c orc_gn_coeffs - per lane over its 16 accumulator registers
     // (level 0), the two lane halves (1), the channels of the group (2), the tile's four 32-pixel blocks (3).
-    const bool gnp = !UP2 && p.gn_part != nullptr;       // (a phase block's pixels are not an output tile: no fused moments)
+    const bool gnp = p.gn_part != nullptr;               // (UP2: the partial of this half-resolution tile and phase, index tile*4 + phase)
     double gs[TM][TN], gss[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -641,7 +641,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv3x3_
                     S = S + red[((size_t)q * gpb + t) * 2];
                     SS = SS + red[((size_t)q * gpb + t) * 2 + 1];
                 }
-                double *dst = p.gn_part + (((size_t)n * p.tilesY * p.tilesX + (size_t)ty * p.tilesX + tx) * 32 + g) * 2;
+                const size_t tidx = (size_t)n * p.tilesY * p.tilesX + (size_t)ty * p.tilesX + tx;
+                double *dst = p.gn_part + ((UP2 ? tidx * 4 + (pha * 2 + phb) : tidx) * 32 + g) * 2;
                 dst[0] = S;
                 dst[1] = SS;
             }
@@ -874,8 +875,8 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     }
     FEMASR_REQUIRE(!phases || a->w_up2, "conv2d: a 3x3 nearest-x2 conv with Cin %% 32 == 0 needs w_up2 (femasr_repack_oihw_up2)");
     p.w_up2 = a->w_up2;
-    FEMASR_REQUIRE(!a->gn_part || (vi >= kFirstHalo && !a->up2 && femasr_gn_fusable(a->Cout)),
-                   "conv2d: gn_part (fused GroupNorm partial moments) needs a 3x3 stride-1 halo conv without x2 and 32 | Cout, Cout/32 a power of two <= 32");
+    FEMASR_REQUIRE(!a->gn_part || (vi >= kFirstHalo && femasr_gn_fusable(a->Cout)),
+                   "conv2d: gn_part (fused GroupNorm partial moments) needs a 3x3 stride-1 halo conv and 32 | Cout, Cout/32 a power of two <= 32");
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull)) {
@@ -885,7 +886,7 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
     hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), v.lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
-    // executed multiply-adds: the phase form of an x2 conv runs 4 taps per output pixel where the definition has 9
-    if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K * (phases ? 4.0 / 9.0 : 1.0);
+    // ALGORITHMIC flops (the definition: 9 taps per output pixel); the phase form of an x2 conv issues 4/9 of them
+    if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K;
     return FEMASR_OK;
 }

@@ -50,7 +50,7 @@ constexpr size_t wino_lds_bytes()
 }
 static_assert(2 * WI_PSZ + WI_VSZ <= 2 * WI_VSZ, "main-loop buffers fit under the epilogue slabs");
 
-template <int TNW, int PRO, int DBG = 0>          // TNW: 32-channel tiles per wave and component (BN = 32 TNW)
+template <int TNW, int PRO>          // TNW: 32-channel tiles per wave and component (BN = 32 TNW)
 __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams p)
 {
     constexpr int BN = 32 * TNW;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams
     const float *Va = Vs + c31 * ALD + hh;           // A fragment of component k, k-pair kk: Va[k*32*ALD + 2*kk]
     WTT(0)
     for (int cc = 0; cc < ncc; ++cc) {
-        if (!(DBG & 1)) transform(Ps + (cc & 1) * WI_PSZ);
+        transform(Ps + (cc & 1) * WI_PSZ);
         WTT(1)
         __syncthreads();                               // V complete; the patch buffer cc&1 is free again
         WTT(2)
@@ -224,14 +224,13 @@ __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (!(DBG & 4))
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < TNW; ++j)
                     acc[comp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][e], bq[cur][j][e], acc[comp][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (s == 3 && more && !(DBG & 8)) store_patch((cc + 1) & 1);      // (uniform) the loads were issued 64 MFMAs ago
+            if (s == 3 && more) store_patch((cc + 1) & 1);      // (uniform) the loads were issued 64 MFMAs ago
         }
         WTT(3)
         __syncthreads();                               // every wave is done with V; the next patch is staged
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams
         __syncthreads();
         WTT(5)
         const int j = 2 * rnd + jj;                    // 32-channel tile of the block handled by this wave now
-        if (j < TNW && !(DBG & 2)) {
+        if (j < TNW) {
             float rn[16], r2[16];
             const bool next = rnd + 1 < ROUNDS && j + 2 < TNW;
             if (ra && next) fetch_res(ra, j + 2, rn);  // the next round's residual flies under this round's arithmetic
@@ -418,21 +417,11 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
         if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
     }
-    {
-        static int dbg = -1;
-        if (dbg < 0) { const char *e = getenv("FEMASR_WINO_DBG"); dbg = e ? atoi(e) : 0; }
-        void (*k)(const ConvParams) = v.kern;
-        if (dbg && vi == 1) {
-            k = dbg == 1 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 1> : dbg == 2 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 2> : dbg == 3 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 3> :
-                dbg == 4 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 4> : dbg == 8 ? conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 8> : conv3x3_wino_kernel<4, FEMASR_PRO_GN_SILU, 11>;
-            FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
-        }
-        hipLaunchKernelGGL(k, dim3((unsigned)(p.MB * p.NB)), dim3(WI_NT), v.lds, s, p);
-    }
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(WI_NT), v.lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
-    // executed multiply-adds: 16 per 2x2 outputs and channel pair (the definition has 36)
-    if (flops_out) *flops_out = 2.0 * (double)a->B * p.tilesX * p.tilesY * 32.0 * 16.0 * (double)a->Cin * (double)a->Cout;
+    // ALGORITHMIC flops (the definition's 9 taps per output pixel, like every other conv launcher); the kernel issues 16/36 of them
+    if (flops_out) *flops_out = 2.0 * (double)a->B * a->H * a->W * 9.0 * (double)a->Cin * (double)a->Cout;
     return FEMASR_OK;
 }
 

@@ -373,9 +373,10 @@ struct Ctx {
         // (they cannot move a VQ index; oracle: OracleNet.wino).  decoder_math 2 = 'fp32_direct' keeps the direct form.
         const bool wino_on = !lowp_on && o.lowp && h->decoder_math == 0 && h->cfg.n_codebooks == 1 && femasr_conv_wino_shape_ok(&a);
         const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
-                                   : (femasr_conv_halo_eligible(&a) && !o.up2 && femasr_gn_fusable(cout));
+                                   : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
         if (o.want_gn && gn_ok) {
-            y.gn_tiles = ((Ho + 7) / 8) * ((Wo + 15) / 16);
+            // exact x2 convs (phase filters) emit one partial per half-resolution tile and phase
+            y.gn_tiles = (o.up2 && !lowp_on) ? 4 * ((x.H + 7) / 8) * ((x.W + 15) / 16) : ((Ho + 7) / 8) * ((Wo + 15) / 16);
             y.gn_part = (double *)arena->alloc((size_t)x.B * y.gn_tiles * 32 * 2 * sizeof(double));
             if (!y.gn_part && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
         }

@@ -156,7 +156,9 @@ typedef struct {
                              [B][tilesY*tilesX][32][2] doubles, for femasr_gn_coeffs_from_partials (saves the separate
                              moments pass over the tensor).  fp32 path: exactly the partials of the specified
                              summation order (bit-identical coefficients to femasr_gn_coeffs); needs Cout/32 a power of
-                             two <= 32 (bf16x3: <= 8); anything else is refused.  Not with up2. */
+                             two <= 32 (bf16x3: <= 8); anything else is refused.  With up2 on the exact path (phase filters) the
+                             partials are per HALF-resolution tile and phase: [B][4*ceil(H/8)*ceil(W/16)][32][2], index
+                             tile*4 + 2a + b (oracle: orc_gn_coeffs(..., phases = 1)). */
     const float *w_up2;   /* up2 = 1 on a 3x3 stride-1 pad-1 conv with Cin % 32 == 0 (exact fp32 path): the four phase
                              matrices of femasr_repack_oihw_up2 -- nn.Upsample(x2, nearest) + Conv2d evaluated as four
                              2x2-tap filters on the low-resolution input (REQUIRED for that shape; other up2 shapes

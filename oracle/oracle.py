@@ -45,7 +45,7 @@ def lib():
         L.orc_pad_nchw_to_nhwc.argtypes = [vp, i, i, i, i, i, i, vp]
         L.orc_crop_nhwc_to_nchw.argtypes = [vp, i, i, i, i, i, i, vp]
         L.orc_conv2d.argtypes = [vp, i, i, i, i, vp, vp, i, i, i, i, i, i, vp, vp, vp, i, i]
-        L.orc_gn_coeffs.argtypes = [vp, i, i, i, i, i, vp, vp, f, vp, vp]
+        L.orc_gn_coeffs.argtypes = [vp, i, i, i, i, i, vp, vp, f, vp, vp, i]
         L.orc_scale_shift_silu.argtypes = [vp, i, i64, i, vp, vp, vp]
         L.orc_layernorm.argtypes = [vp, i64, i, vp, vp, f, vp]
         L.orc_window_attention.argtypes = [vp, i, i, i, i, i, i, vp, vp]
@@ -144,13 +144,21 @@ def linear(x_tokens, w_io, bias, act=0, res=None):
     return y.reshape(shp[:-1] + (w_io.shape[-1],))
 
 
-def gn_coeffs(x, gamma, beta, eps=1e-6, groups=32):
+def gn_fusable(c):
+    """Channel counts whose GroupNorm(32) partial moments the 3x3 kernels emit from their epilogue (csrc/common.h)."""
+    cg = c // 32
+    return c % 32 == 0 and 1 <= cg <= 32 and (cg & (cg - 1)) == 0
+
+
+def gn_coeffs(x, gamma, beta, eps=1e-6, groups=32, phases=False):
+    """phases: x is the output of a phase-filter x2 conv whose epilogue produced the partial moments (per half-resolution tile
+    and phase) -- only the ORDER of the fp64 partial sums differs."""
     x = _c(x)
     b, h, w, c = x.shape
     a = np.empty((b, c), np.float32)
     bb = np.empty((b, c), np.float32)
     gamma, beta = _c(gamma), _c(beta)
-    lib().orc_gn_coeffs(_p(x), b, h, w, c, groups, _p(gamma), _p(beta), eps, _p(a), _p(bb))
+    lib().orc_gn_coeffs(_p(x), b, h, w, c, groups, _p(gamma), _p(beta), eps, _p(a), _p(bb), int(bool(phases)))
     return a, bb
 
 
@@ -163,8 +171,8 @@ def scale_shift_silu(x, a, b):
     return y
 
 
-def gn_silu(x, gamma, beta):
-    a, b = gn_coeffs(x, gamma, beta)
+def gn_silu(x, gamma, beta, phases=False):
+    a, b = gn_coeffs(x, gamma, beta, phases=phases)
     return scale_shift_silu(x, a, b)
 
 
@@ -270,9 +278,11 @@ class OracleNet:
         w, b = self._conv_w(prefix)
         return conv2d(x, w, b, ksz, stride, pad, up2, 0, res1, res2, wino=dec and self.wino)
 
-    def _resblock(self, x, prefix, res2=None, dec=False):
+    def _resblock(self, x, prefix, res2=None, dec=False, from_up2=None):
         # fema_utils.py:65-84: conv2(silu(gn2(conv1(silu(gn1(x)))))) + x   (+ optional fused skip add)
-        t = gn_silu(x, self.sd[prefix + '.conv.0.norm.weight'], self.sd[prefix + '.conv.0.norm.bias'])
+        # from_up2 = Cin of the x2 conv that produced x: its phase-filter kernel emitted the moments (phase-tile order)
+        ph = from_up2 is not None and from_up2 % 32 == 0 and gn_fusable(x.shape[-1])
+        t = gn_silu(x, self.sd[prefix + '.conv.0.norm.weight'], self.sd[prefix + '.conv.0.norm.bias'], phases=ph)
         t = self._conv(t, prefix + '.conv.2', 3, dec=dec)
         t = gn_silu(t, self.sd[prefix + '.conv.3.norm.weight'], self.sd[prefix + '.conv.3.norm.bias'])
         return self._conv(t, prefix + '.conv.5', 3, res1=x, res2=res2, dec=dec)
@@ -323,8 +333,9 @@ class OracleNet:
             outs.append(x)
             bi += 1
             for _ in range(2):
+                cin = x.shape[-1]
                 x = self._conv(x, f'{p}.blocks.{bi}.1', 3, 1, 1, up2=True)
-                x = self._resblock(x, f'{p}.blocks.{bi}.2', dec=True)       # the LQ up-blocks only make the decoder's skip features
+                x = self._resblock(x, f'{p}.blocks.{bi}.2', dec=True, from_up2=cin)       # the LQ up-blocks only make the decoder's skip features
                 x = self._resblock(x, f'{p}.blocks.{bi}.3', dec=True)
                 self._probe(f'enc_block{bi}', x)
                 outs.append(x)
@@ -333,8 +344,9 @@ class OracleNet:
 
     def _decoder_block(self, x, i, res2=None):
         p = f'decoder_group.{i}.block'
+        cin = x.shape[-1]
         x = self._conv(x, p + '.1', 3, 1, 1, up2=True)
-        x = self._resblock(x, p + '.2', dec=True)
+        x = self._resblock(x, p + '.2', dec=True, from_up2=cin)
         return self._resblock(x, p + '.3', res2=res2, dec=True)
 
     def encode_and_decode(self, x_nhwc):

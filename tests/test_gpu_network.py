@@ -249,3 +249,30 @@ def test_decoder_bf16x3_mode(cuda_device):
         assert torch.equal(y32b, y32)
         del net
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('name', ['x4_small_trained', 'x2_small_trained'])
+def test_fp32_direct_mode_vs_oracle(cuda_device, name):
+    """decoder_math='fp32_direct': every conv in the direct form (no Winograd behind the codebook lookup) -- bit-identical to
+    OracleNet(winograd=False), same VQ indices as the default mode, output within fp32 rounding of it, and the default mode
+    is restored bit-for-bit afterwards."""
+    from oracle import oracle as orc
+    from helpers import CONFIGS
+    g, cn, w, x, net = _case(name)
+    xt = torch.from_numpy(x).cuda()
+    y0, i0 = net.test_with_indices(xt)
+    net.decoder_math = 'fp32_direct'
+    y1, i1 = net.test_with_indices(xt)
+    assert torch.equal(i0, i1)
+    assert not torch.equal(y0, y1)                       # the other kernels really ran
+    assert float((y0 - y1).abs().max()) < 1e-4
+    cfg = CONFIGS[cn]
+    ref = orc.OracleNet(w, codebook_params=cfg['codebook_params'], LQ_stage=cfg['LQ_stage'], scale_factor=cfg.get('scale_factor', 4),
+                        winograd=False)
+    yo, io = ref.test(x, return_indices=True)
+    assert np.array_equal(i1.cpu().numpy(), io)
+    assert np.array_equal(y1.cpu().numpy(), yo), f'max-abs {np.abs(y1.cpu().numpy() - yo).max():.3e}'
+    assert np.abs(y1.cpu().numpy() - g['output']).max() < TOL
+    net.decoder_math = 'fp32'
+    y2, _ = net.test_with_indices(xt)
+    assert torch.equal(y2, y0)

@@ -12,7 +12,7 @@ for line in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
     print('MPix/s', d['value'], 'ms/step', d['ms_per_step'], '| dominant', r.get('kernel'), r.get('achieved'), r.get('frac'), '|', r.get('measured_in', '')[:60])
     for k, v in r.get('per_kernel', {}).items():
         print('   %8.3f ms  %3d x  %6s TF  %s' % (v['ms_per_step'], v['launches_per_step'], v.get('tflops', ''), k))
-    for key in ('bf16x3_mode', 'exact_fp32_mode'):
+    for key in ('bf16x3_mode', 'fp32_direct_mode', 'exact_fp32_mode'):
         if key in d:
             print('  ', key, d[key]['value'], 'MPix/s', d[key]['ms_per_step'], 'ms')
     if 'cpu_baseline' in d:
