@@ -257,7 +257,10 @@ def main():
                    'gather': bool(do_gather), 'streams': args.streams, 'decoder_math': args.decoder_math,
                    'algorithmic_gflop_per_tile': TILE_GFLOP,
                    'end_to_end_tflops': None if dry else round(TILE_GFLOP * units_per_step * args.steps / dt / 1e3, 2),
-                   'fp32_mfma_ceiling_mpix_s_per_gpu': round(0.262144 / (TILE_GFLOP / (PEAK_FP32_MFMA_TFLOPS * 1e3)), 2)},
+                   'fp32_mfma_ceiling_mpix_s_per_gpu': round(0.262144 / (TILE_GFLOP / (PEAK_FP32_MFMA_TFLOPS * 1e3)), 2),
+                   'ceiling_note': ('ceiling = the layer DEFINITIONS\' flops (964.47 GFLOP per tile, direct form) at the fp32 MFMA peak; the '
+                                    'default fp32 mode issues ~577 of them (Winograd F(2x2,3x3) behind the VQ lookup, phase-filter x2 '
+                                    'convs), so end_to_end_tflops counts algorithmic, not issued, flops')},
     }
     if args.workload == 'tiles16' and do_gather:
         res['config']['gather_overlap'] = 'all-gather of step k overlaps step k+1'
