@@ -52,6 +52,57 @@ def test_conv_variants_match_torch():
         assert np.abs(y - ref).max() < 2e-5, (i, np.abs(y - ref).max())
 
 
+def test_conv_winograd_and_phase_forms_match_torch():
+    """The two algebraic restatements the kernels use (Winograd F(2x2,3x3) behind the codebook lookup; nearest-x2 + conv as
+    four phase filters) against stock torch ops of the plain definition, and against the oracle's own direct form."""
+    cases = [(1, 8, 16, 32, 64, 0), (2, 13, 9, 64, 128, 1), (1, 7, 21, 128, 64, 2), (1, 16, 16, 256, 128, 1)]
+    for i, (b, h, w, ci, co, nres) in enumerate(cases):
+        x = synth.uniform(40 + i, 'wx', (b, h, w, ci), -2, 2)
+        wt = synth.uniform(40 + i, 'ww', (co, ci, 3, 3), -0.1, 0.1)
+        bias = synth.uniform(40 + i, 'wb', (co,), -0.5, 0.5)
+        res = [synth.uniform(40 + i, f'wr{k}', (b, h, w, co), -1, 1) for k in range(nres)]
+        r1, r2 = (res + [None, None])[:2]
+        assert orc.winograd_ok(ci, co, 3, 1, 1, False)
+        y = orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, res1=r1, res2=r2, wino=True)
+        yd = orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, res1=r1, res2=r2)
+        ref = _torch_conv(x, wt, bias, 1, 1, False)
+        for r in res:
+            ref = ref + r
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(y - ref).max() < 2e-5 * scale, (i, np.abs(y - ref).max())
+        assert np.abs(y - yd).max() < 2e-5 * scale and not np.array_equal(y, yd)
+    # shapes outside the Winograd rule fall through to the direct form, bit for bit
+    x = synth.uniform(50, 'wx', (1, 6, 6, 32, ), -1, 1).reshape(1, 6, 6, 32)
+    wt = synth.uniform(50, 'ww', (48, 32, 3, 3), -0.1, 0.1)
+    bias = synth.uniform(50, 'wb', (48,), -0.5, 0.5)
+    assert not orc.winograd_ok(32, 48, 3, 1, 1, False)
+    assert np.array_equal(orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, wino=True),
+                          orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1))
+    # x2 + conv: the phase form (Cin % 32 == 0) and the plain sweep over the upsampled image (Cin = 48) both match torch
+    for ci in (64, 48):
+        x = synth.uniform(51, 'ux', (2, 5, 9, ci), -1, 1)
+        wt = synth.uniform(51, 'uw', (40, ci, 3, 3), -0.1, 0.1)
+        bias = synth.uniform(51, 'ub', (40,), -0.5, 0.5)
+        y = orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, True)
+        assert np.abs(y - _torch_conv(x, wt, bias, 1, 1, True)).max() < 2e-5
+
+
+def test_groupnorm_phase_tile_order():
+    """Moments of a phase-filter x2 conv's output are summed per half-resolution tile and phase: another order of the same
+    fp64 sums, so the coefficients agree with the plain order to fp32 rounding and with torch's group_norm."""
+    for c, hw in ((128, (16, 32)), (64, (10, 36)), (256, (18, 14))):
+        x = synth.uniform(60, 'px', (2,) + hw + (c,), -3, 5)
+        g = synth.uniform(60, 'pg', (c,), 0.5, 1.5)
+        b = synth.uniform(60, 'pb', (c,), -0.5, 0.5)
+        a0, b0 = orc.gn_coeffs(x, g, b)
+        a1, b1 = orc.gn_coeffs(x, g, b, phases=True)
+        assert np.abs(a1 - a0).max() <= 2e-7 * np.abs(a0).max() and np.abs(b1 - b0).max() <= 1e-6 * max(1.0, np.abs(b0).max())
+        y = orc.scale_shift_silu(x, a1, b1)
+        t = torch.from_numpy(x).permute(0, 3, 1, 2)
+        ref = F.silu(F.group_norm(t, 32, torch.from_numpy(g), torch.from_numpy(b), eps=1e-6))
+        assert np.abs(y - ref.permute(0, 2, 3, 1).numpy()).max() < 2e-5
+
+
 def test_conv_epilogue_order():
     x = synth.uniform(3, 'ex', (1, 4, 4, 32), -1, 1)
     wt = synth.uniform(3, 'ew', (32, 32, 3, 3), -0.2, 0.2)
