@@ -86,6 +86,8 @@ SIGNATURES = {
     'femasr_vq_twopass': (c_int, [vp, vp, c_i64, c_int, vp, vp, vp, c_int, vp, vp, vp]),
     'femasr_vq_candidates': (c_int, [vp, vp, c_i64, c_int, vp, vp, c_int, vp, vp]),
     'femasr_codebook_gather': (c_int, [vp, vp, c_i64, c_int, vp, c_int, vp]),
+    'femasr_extract_tiles': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, vp]),
+    'femasr_paste_tiles': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, vp]),
     'femasr_concat_resize': (c_int, [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'femasr_repack_oihw': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'femasr_packed_weight_floats': (szt, [c_int, c_int, c_int, c_int]),

@@ -422,8 +422,7 @@ class FeMaSRNet(nn.Module):
             outs = []
             for i in range(0, len(tl), max(1, self.max_tile_batch // batch)):
                 chunk = tl[i:i + max(1, self.max_tile_batch // batch)]
-                crops = torch.cat([input[:, :, t.y0p:t.y1p, t.x0p:t.x1p] for t in chunk], 0)
-                outs.append(self.test(crops))
+                outs.append(self.test(self._extract_tiles(input, chunk, hw)))
             results[hw] = torch.cat(outs, 0) if outs else input.new_zeros((0, channel, hw[0] * s, hw[1] * s))
         if world_size > 1:
             if gather is None:
@@ -435,9 +434,46 @@ class FeMaSRNet(nn.Module):
         for r, res in enumerate(per_rank):
             owned = tiling.partition(classes, r, world_size)
             for hw, tl in owned.items():
-                block = res[hw]
-                for k, t in enumerate(tl):
-                    ys, ye, xs, xe = t.out_src(s)
-                    dy0, dy1, dx0, dx1 = t.out_dst(s)
-                    output[:, :, dy0:dy1, dx0:dx1] = block[k * batch:(k + 1) * batch, :, ys:ye, xs:xe]
+                if tl:
+                    self._paste_tiles(output, res[hw], tl, batch, s)
         return output
+
+    @staticmethod
+    def _extract_tiles(input, chunk, hw):
+        """torch.cat of the reference's crops `input[:, :, y0p:y1p, x0p:x1p]` (femasr_arch.py:412-426) for the tiles of one
+        shape class: one femasr_extract_tiles launch on the GPU (host tensors: plain slicing, used by the CPU-side tests of
+        the partition / gather logic only)."""
+        if not input.is_cuda:
+            return torch.cat([input[:, :, t.y0p:t.y1p, t.x0p:t.x1p] for t in chunk], 0)
+        lib = _lib.load()
+        b, c, h, w = input.shape
+        x = input.contiguous().float()
+        yx = torch.tensor([v for t in chunk for v in (t.y0p, t.x0p)], dtype=torch.int32).to(x.device, non_blocking=True)
+        out = torch.empty((len(chunk) * b, c, hw[0], hw[1]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.femasr_extract_tiles(torch.cuda.current_stream().cuda_stream, x.data_ptr(), b, c, h, w, yx.data_ptr(),
+                                                len(chunk), hw[0], hw[1], out.data_ptr()))
+        return out
+
+    @staticmethod
+    def _paste_tiles(output, block, tl, batch, s):
+        """`output[:, :, dst] = output_tile[:, :, src]` (femasr_arch.py:443-446) for all tiles of one shape class and rank."""
+        if not output.is_cuda:
+            for k, t in enumerate(tl):
+                ys, ye, xs, xe = t.out_src(s)
+                dy0, dy1, dx0, dx1 = t.out_dst(s)
+                output[:, :, dy0:dy1, dx0:dx1] = block[k * batch:(k + 1) * batch, :, ys:ye, xs:xe]
+            return
+        lib = _lib.load()
+        block = block.contiguous().float()
+        rects, hmax = [], 0
+        for t in tl:
+            ys, ye, xs, xe = t.out_src(s)
+            dy0, _, dx0, _ = t.out_dst(s)
+            rects += [ys, xs, dy0, dx0, ye - ys, xe - xs]
+            hmax = max(hmax, ye - ys)
+        rd = torch.tensor(rects, dtype=torch.int32).to(output.device, non_blocking=True)
+        with torch.cuda.device(output.device):
+            _lib.check(lib.femasr_paste_tiles(torch.cuda.current_stream().cuda_stream, block.data_ptr(), batch, output.shape[1], len(tl),
+                                              block.shape[2], block.shape[3], rd.data_ptr(), hmax, output.shape[2], output.shape[3],
+                                              output.data_ptr()))

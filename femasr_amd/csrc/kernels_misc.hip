@@ -654,6 +654,43 @@ __global__ void image_f32_to_u8_kernel(const float *__restrict__ in, int H, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// test_tile (femasr_arch.py:387-447): crops of one shape class -> one batch; upscaled tile bodies -> the canvas
+// ------------------------------------------------------------------------------------------
+// out[(k*B + b), c, y, x] = in[b, c, yx[2k] + y, yx[2k+1] + x]   (NCHW; the reference's input[:, :, y0p:y1p, x0p:x1p])
+__global__ void extract_tiles_kernel(const float *__restrict__ in, int B, int C, int H, int W, const int *__restrict__ yx, int n,
+                                     int th, int tw, float *__restrict__ out, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % tw);
+        size_t r = i / tw;
+        const int y = (int)(r % th);
+        r /= th;
+        const int c = (int)(r % C);
+        r /= C;
+        const int b = (int)(r % B), k = (int)(r / B);
+        out[i] = in[(((size_t)b * C + c) * H + yx[2 * k] + y) * W + yx[2 * k + 1] + x];
+    }
+}
+
+// canvas[b, c, dy + y, dx + x] = tiles[(k*B + b), c, sy + y, sx + x] for y < h, x < w; rect k = (sy, sx, dy, dx, h, w)
+// (`output[:, :, dst] = output_tile[:, :, src]`, femasr_arch.py:443-446).  One block row per (tile, image, channel, row).
+__global__ void paste_tiles_kernel(const float *__restrict__ tiles, int B, int C, int th, int tw, const int *__restrict__ rects,
+                                   int n, int Ho, int Wo, float *__restrict__ out, int hmax)
+{
+    size_t r = blockIdx.x;
+    const int y = (int)(r % hmax);
+    r /= hmax;
+    const int c = (int)(r % C);
+    r /= C;
+    const int b = (int)(r % B), k = (int)(r / B);
+    const int *rc = rects + 6 * k;
+    if (y >= rc[4]) return;
+    const float *src = tiles + ((((size_t)k * B + b) * C + c) * th + rc[0] + y) * tw + rc[1];
+    float *dst = out + (((size_t)b * C + c) * Ho + rc[2] + y) * Wo + rc[3];
+    for (int x = threadIdx.x; x < rc[5]; x += blockDim.x) dst[x] = src[x];
+}
+
 // out[n,y,x,:] = cat(a[n,y,x,:Ca], b[n, y*Hb/H, x*Wb/W, :Cb]); one thread per float4 of the output (Ca, Cb % 4 == 0)
 __global__ void concat_resize_kernel(const float *__restrict__ a, int Ca, const float *__restrict__ b, int Hb, int Wb, int Cb,
                                      int H, int W, float *__restrict__ out, size_t total4)
@@ -838,6 +875,26 @@ int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, c
     FEMASR_REQUIRE(idx && cb && zq && M > 0 && D % 4 == 0 && n_e > 0, "codebook_gather: bad args");
     hipLaunchKernelGGL(codebook_gather_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const long long *)idx, (long long)M, D, cb, n_e, zq);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_extract_tiles(void *stream, const float *in, int B, int C, int H, int W, const int32_t *yx_dev, int n, int th, int tw, float *out)
+{
+    FEMASR_REQUIRE(in && yx_dev && out && B > 0 && C > 0 && n > 0 && th > 0 && tw > 0 && th <= H && tw <= W, "extract_tiles: bad args");
+    const size_t total = (size_t)n * B * C * th * tw;
+    hipLaunchKernelGGL(extract_tiles_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, B, C, H, W, yx_dev, n, th, tw, out, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_paste_tiles(void *stream, const float *tiles, int B, int C, int n, int th, int tw, const int32_t *rects_dev, int hmax,
+                       int Ho, int Wo, float *out)
+{
+    FEMASR_REQUIRE(tiles && rects_dev && out && B > 0 && C > 0 && n > 0 && th > 0 && tw > 0 && hmax > 0 && hmax <= th, "paste_tiles: bad args");
+    const size_t rows = (size_t)n * B * C * hmax;
+    FEMASR_REQUIRE(rows < ((size_t)1 << 31), "paste_tiles: too many rows");
+    hipLaunchKernelGGL(paste_tiles_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, tiles, B, C, th, tw, rects_dev, n, Ho, Wo, out, hmax);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

@@ -216,6 +216,16 @@ int femasr_codebook_gather(void *stream, const int64_t *idx, int64_t M, int D, c
  * floor(dst * Hb / H), exact for the integer ratios the architecture produces). */
 int femasr_concat_resize(void *stream, const float *a, int Ca, const float *b, int Hb, int Wb, int Cb, int B, int H, int W,
                          float *out);
+/* test_tile (femasr_arch.py:387-447) on the device.  extract: the n input windows of ONE shape class (th x tw, top-left corners
+ * yx_dev[2k], yx_dev[2k+1], int32 on the device) of a (B,C,H,W) image -> a (n*B, C, th, tw) batch (tile-major, as
+ * torch.cat of the reference's crops).  paste: the upscaled tile bodies -> the (B,C,Ho,Wo) canvas;
+ * rects_dev[6k..] = (src_y, src_x, dst_y, dst_x, h, w) in upscaled pixels, hmax = max h.  Tiles of different ranks are pasted
+ * after the all-gather, which stays in the host's torch.distributed (RCCL) group: see INTEGRATION.md. */
+int femasr_extract_tiles(void *stream, const float *in, int B, int C, int H, int W, const int32_t *yx_dev, int n, int th, int tw,
+                         float *out);
+int femasr_paste_tiles(void *stream, const float *tiles, int B, int C, int n, int th, int tw, const int32_t *rects_dev, int hmax,
+                       int Ho, int Wo, float *out);
+
 /* OIHW -> the packed FRAGMENT-MAJOR weight layout of femasr_conv_args.w (also nn.Linear (out,in) with kh=kw=1
  * and the codebook for femasr_vq):  out[q][ntile][lane][kk], zero padded, with
  *   K index k = ((ci/32)*kh*kw + ky*kw + kx)*32 + ci%32 when I % 32 == 0, else (ky*kw + kx)*I + ci;
