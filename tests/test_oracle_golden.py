@@ -66,3 +66,22 @@ def test_full_tile_128_matches_reference():
     assert abs(float(y.astype(np.float64).mean()) - float(g['out_mean'])) < 1e-5
     nbad, _ = check_indices_near_tie(idx, g)
     assert nbad == 0
+
+
+@pytest.mark.parametrize('name', ['x4_small_trained', 'x2_small_trained'])
+def test_direct_form_oracle_matches_reference(name):
+    """OracleNet(winograd=False) -- the arithmetic of decoder_math='fp32_direct' (every conv in the direct form) -- against the
+    same reference goldens, and the two restatements against each other: identical VQ indices, outputs within fp32 rounding."""
+    from oracle import oracle as orc
+    from helpers import CONFIGS
+    g, net, x = _run(name)
+    cn = cfg_name_of(g)
+    cfg = CONFIGS[cn]
+    direct = orc.OracleNet(synth_weights(cn, int(g['seed']), str(g['codebook'])), codebook_params=cfg['codebook_params'],
+                           LQ_stage=cfg['LQ_stage'], scale_factor=cfg.get('scale_factor', 4), winograd=False)
+    yd, idd = direct.test(x, return_indices=True)
+    yw, idw = net.test(x, return_indices=True)
+    assert np.abs(yd - g['output']).max() < TOL
+    assert check_indices_near_tie(idd, g)[0] == 0
+    assert np.array_equal(idd, idw)
+    assert 0 < np.abs(yd - yw).max() < 1e-4
