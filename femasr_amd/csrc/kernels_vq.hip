@@ -17,9 +17,11 @@
 //   bf16 RNE rounding of both operands       |z~e~ - ze| <= (2^-8 + 2^-18) |z||e|      per product
 //   fp32 accumulation inside the MFMA        <= K * 2^-23 * sum|z~e~|                  (any order, any rounding mode)
 //   the specified chain vs the real dot      <= K * 2^-24 * sum|ze|
-//   sum|ze| <= |z| |e| (Cauchy-Schwarz)  =>  |dot~ - dot_spec| <= 0.004004 |z| |e|;  VQ_EPS = 0.0042 with |z|, |e| taken
-//   from the fp32 row norms inflated by 1.001.  d differs from (ee - 2 dot~) + zz by at most 2*that plus three fp32
+//   sum|ze| <= |z| |e| (Cauchy-Schwarz)  =>  |dot~ - dot_spec| <= 0.004004 |z| |e|;  VQ_EPS = 0.0042 with
+//   |e| <= max_j sqrt(ee_j) * 1.001 (one bound per row: the largest code norm) and |z| <= |z~| * 1.004 (the norm of the
+//   bf16 image in LDS; |z~| >= |z| (1 - 2^-9)).  d differs from (ee - 2 dot~) + zz by at most 2*that plus three fp32
 //   roundings of magnitude <= 2^-24 (zz + ee + 2|dot|), covered by the per-row slack gz = 2^-20 (zz + ee_max + 2|z||e|max).
+//   A code survives iff  s_j <= min_j s_j + 2 E_row,  s = ee - 2 dot~,  E_row = 2 VQ_EPS |z| |e|max + gz.
 //
 // Rows whose candidate list overflows (more than VQ_CMAX = 32 entries) are marked VQ_ALL and pass 2 evaluates every code
 // for them: slow, still exact.
