@@ -1,26 +1,35 @@
-// kernels_wino.hip — 3x3 stride-1 pad-1 convs in the Winograd F(2x2, 3x3) form on the fp32 matrix cores.
+// kernels_wino.hip — 3x3 stride-1 pad-1 convs in the Winograd F(4x4, 3x3) form on the fp32 matrix cores.
 //
 // Used for the convs BEHIND the codebook lookup of single-codebook networks (after_quant, decoder ResBlocks, the LQ
 // encoder's up-blocks that only make skip features; fema_utils.py:65-84, femasr_arch.py:196-207,298): they cannot move a VQ
-// index, and the form needs 16 multiplies per 2x2 outputs where the direct sweep needs 36 (2.25x fewer MFMAs).  All fp32;
-// the order of every addition is the one of oracle/femasr_oracle.c orc_conv3x3_winograd, so the result is bit-identical to
-// that restatement (and within fp32 rounding, ~1e-6 relative, of the direct form).
+// index, and the form needs 36 multiplies per 4x4 outputs where the direct sweep needs 144 (4x fewer MFMAs; round 2 ran
+// F(2x2,3x3): 2.25x).  All fp32; the order of every addition is the one of oracle/femasr_oracle.c orc_conv3x3_winograd, so
+// the result is bit-identical to that restatement (measured against the reference goldens: <= 6e-6 max-abs on outputs of
+// magnitude 2, 4.4e-5 on the +-49 un-scaled case - the same class as the direct form).
 //
-// Block = 8 waves, one 8 x 16 output tile (= 4 x 8 Winograd tiles = ONE 32-row MFMA tile) x BN channels:
-//   per 32-channel block of the input:
-//     T phase  every thread transforms two (Winograd tile, channel) 4x4 input patches from the staged halo patch
-//              (GN + SiLU already applied while staging, zeros outside the image) into V[16][32 tiles][32 ch] in LDS
-//     M phase  wave w owns frequency components 2w, 2w+1: M_k[32 tiles][BN] += V_k[32][32] . U_k[32][BN]
-//              (v_mfma_f32_32x32x2_f32, A from LDS, U fragments from L2 in the fragment-major layout of a 4x4-tap conv);
-//              the next channel block's patch is fetched and staged underneath
-//   epilogue   accumulators -> LDS by component, one wave per (32-pixel block, 32-channel tile) applies A^T M A and lands
-//              on exactly the register layout of the direct halo kernel (element r of a lane = the same pixel), so bias /
-//              residual adds / stores / the fused GroupNorm partial moments are the same code in the same order.
+// What shapes the kernel (tools/ubench/coexec.hip, round 3): a VALU instruction of ANY wave on a SIMD takes its 2 cycles
+// out of that SIMD's fp32 MFMA time (v_mfma_f32_32x32x2_f32 runs on the vector lanes: 4 MFMA waves + 4 VALU waves take
+// exactly the SUM of the two alone), while LDS traffic and global loads overlap freely.  So: one MFMA stream per CU that
+// never waits for memory, as few VALU instructions as possible, and every latency hidden behind the partner wave.
+//
+// Block = 8 waves (2 per SIMD), two 16x16-pixel sub-blocks (consecutive in (n, y, x) order; 2 x 16 Winograd tiles = ONE
+// 32-row MFMA tile) x 64 output channels.  K is walked in steps of 8 input channels; per step
+//   staging   the 2 x 18x18 halo patches of step s+2: global -> registers (under the MFMAs) -> GroupNorm-apply + SiLU ->
+//             LDS (zeros outside the image, AFTER the activation)
+//   T phase   thread = (Winograd tile, channel, half of the 6 transform rows): V = B^T d B for step s+1 into
+//             V[36 components][32 tiles][8 channels] (channel order = the MFMA A fragment of 4 k-pairs: one ds_read_b128)
+//   M phase   wave w owns 9 (component, 32-column tile) pairs - components 4w..4w+3 x both column tiles, and column tile w&1
+//             of component 32 + w/2: M += V_k[32 x 8] . U_k[8 x 32], 4 MFMAs per pair,
+//             U fragments stream from L2 through a register ring (1 KiB contiguous per wave load, issued one pair-group ahead)
+//   one barrier per step; waves 0-3 run M then T, waves 4-7 T then M, so each SIMD always has one wave in its MFMAs.
+// Epilogue: accumulators -> LDS per 32-column tile; thread = (Winograd tile, channel) applies A^T M A, bias, residuals,
+// stores, and accumulates the fused GroupNorm partial moments (fp64) per 16x16 sub-block in the order of orc_gn_coeffs mode 2.
 #include "conv_common.h"
 #include "detmath.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 #ifdef FEMASR_WINO_TT      // tools/build_debug.sh: per-wave cycle shares of the kernel's phases
 __device__ unsigned long long g_wi_tt[8];
@@ -35,332 +44,418 @@ __device__ unsigned long long g_wi_tt[8];
 
 namespace {
 
-constexpr int WI_PW = 18, WI_PP = 180;                         // halo patch 10 x 18 pixels
-constexpr int WI_NT = 512;
-constexpr int WI_PUNITS = (WI_PP * 8 + WI_NT - 1) / WI_NT;     // 3
-constexpr int WI_PROWS = WI_NT / 8;                            // 64
-constexpr int WI_PSZ = (((WI_PP + 1) * ALD + 3) / 4) * 4;      // floats per patch buffer (pixel 180 = write-only dummy)
-constexpr int WI_VSZ = 16 * 32 * ALD;                          // floats of V / of one epilogue slab
-constexpr int WI_RED = 4 * 64 * 2 * 2;                         // floats: [4 q][<= 64 groups][2] doubles
+struct WinoParams {
+    const float *in, *u, *bias, *pro_a, *pro_b, *res1, *res2;
+    float *out;
+    double *gn_part;
+    int B, H, W, Cin, Cout;
+    int sbX, sbY, nsb;       // 16x16-pixel sub-blocks per row / per column / in the batch
+    int MB, NB, nsteps, NT32;
+};
 
-template <int TNW>
-constexpr size_t wino_lds_bytes()
+constexpr int W4_NT = 512;
+constexpr int W4_PS = 10;                         // floats per patch pixel: 8 channels + 2 (tiles 4 pixels apart land 8 banks apart)
+constexpr int W4_PW = 18;
+constexpr int W4_PPIX = W4_PW * W4_PW;            // 324
+constexpr int W4_PSZ = 2 * W4_PPIX * W4_PS;       // floats per patch buffer (two sub-blocks)
+constexpr int W4_VSZ = 36 * 32 * 8;               // floats per V buffer
+constexpr int W4_MAIN = 2 * W4_PSZ + 2 * W4_VSZ;  // main-loop floats ahead of the GN coefficient table
+constexpr int W4_MX = 36 * 32 * 32;               // epilogue: one 32-column tile of all components
+constexpr int W4_RED = 8 * 2 * 16 * 2 * 2;        // floats: [8 waves][2 sub-blocks][<= 16 groups][2] doubles
+constexpr int W4_UNITS_SB = W4_PPIX * 2;          // float4 staging units per sub-block and step (648)
+
+inline size_t wino_lds_bytes(int cin, bool gn)
 {
-    return (size_t)(2 * WI_VSZ + WI_RED) * sizeof(float);      // epilogue: 2 slabs + moments; main loop: 2 patches + V (smaller)
+    const size_t main_f = (size_t)W4_MAIN + (gn ? 4 * (size_t)cin : 0), epi_f = (size_t)W4_MX + W4_RED;
+    return (main_f > epi_f ? main_f : epi_f) * sizeof(float);
 }
-static_assert(2 * WI_PSZ + WI_VSZ <= 2 * WI_VSZ, "main-loop buffers fit under the epilogue slabs");
 
-template <int TNW, int PRO>          // TNW: 32-channel tiles per wave and component (BN = 32 TNW)
-__global__ __launch_bounds__(WI_NT, 2) void conv3x3_wino_kernel(const ConvParams p)
+// 6-point transforms of F(4x4,3x3).  Input rows of B^T (Lavin & Gray), written so that each value is one fixed sequence of
+// IEEE operations (the oracle restates them literally):
+//   r0 = 4 d0 - 5 d2 + d4          r1 = (d4 - 4 d2) + (d3 - 4 d1)      r2 = (d4 - 4 d2) - (d3 - 4 d1)
+//   r3 = (d4 - d2) + 2 (d3 - d1)   r4 = (d4 - d2) - 2 (d3 - d1)        r5 = 4 d1 - 5 d3 + d5
+__device__ __forceinline__ void bt_lo(float d0, float d1, float d2, float d3, float d4, float &r0, float &r1, float &r2)
 {
-    constexpr int BN = 32 * TNW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Ps = smem;                      // [2][WI_PSZ]
-    float *Vs = smem + 2 * WI_PSZ;         // [16][32][ALD]
+    r0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
+    const float a = __builtin_fmaf(-4.0f, d2, d4), b = __builtin_fmaf(-4.0f, d1, d3);
+    r1 = a + b;
+    r2 = a - b;
+}
+__device__ __forceinline__ void bt_hi(float d1, float d2, float d3, float d4, float d5, float &r3, float &r4, float &r5)
+{
+    const float c = d4 - d2, e = d3 - d1;
+    r3 = __builtin_fmaf(2.0f, e, c);
+    r4 = __builtin_fmaf(-2.0f, e, c);
+    r5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
+}
+// output rows of A^T:  y0 = (m0 + (m1 + m2)) + (m3 + m4),  y1 = (m1 - m2) + 2 (m3 - m4),  y2 = (m1 + m2) + 4 (m3 + m4),
+//                      y3 = ((m1 - m2) + 8 (m3 - m4)) + m5
+__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1, float &y2, float &y3)
+{
+    const float pp = m1 + m2, qq = m1 - m2, rr = m3 + m4, ss = m3 - m4;
+    y0 = (m0 + pp) + rr;
+    y1 = __builtin_fmaf(2.0f, ss, qq);
+    y2 = __builtin_fmaf(4.0f, rr, pp);
+    y3 = __builtin_fmaf(8.0f, ss, qq) + m5;
+}
+
+template <int PRO, int RING>
+__global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParams p)
+{
+        extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ps = smem;                        // [2][W4_PSZ]
+    float *Vs = smem + 2 * W4_PSZ;           // [2][W4_VSZ]
+    float *ABs = smem + W4_MAIN;             // [2 sub-blocks][a | b][Cin]
 
     const int t = threadIdx.x, lane = t & 63;
     WTT_INIT
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c31 = lane & 31, hh = lane >> 5;
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
-    const int nb = L % p.NB;
-    int tile = L / p.NB;
-    const int tx = tile % p.tilesX;
-    tile /= p.tilesX;
-    const int ty = tile % p.tilesY;
-    const int n = tile / p.tilesY;
-    const int oy0 = ty * 8, ox0 = tx * 16, n0 = nb * BN;
-    const int sy0 = oy0 - 1, sx0 = ox0 - 1;
+    const int nb = L % p.NB, mb = L / p.NB;
+    const int n0 = nb * 64;
 
-    // ---- patch staging units: (pixel = (t>>3) + 64 i, channel quad kq)
-    const int kq = t & 7;
-    unsigned poff[WI_PUNITS];
+    // ---- the two sub-blocks (uniform)
+    int sn[2], sy0[2], sx0[2], sbi[2];
+    bool sval[2];
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+        const int sb = 2 * mb + z, per = p.sbY * p.sbX;
+        sval[z] = sb < p.nsb;
+        const int sbc = sval[z] ? sb : 0;
+        sn[z] = sbc / per;
+        sbi[z] = sbc - sn[z] * per;
+        const int by = sbi[z] / p.sbX, bx = sbi[z] - by * p.sbX;
+        sy0[z] = 16 * by;
+        sx0[z] = 16 * bx;
+    }
+
+    // ---- staging units: float4 = (pixel of the 18x18 patch, channel quad t&1); units t, t + 512, and 34 lanes per wave of a third round
+    const int quad = t & 1;
+    unsigned goff[3];
     unsigned pmask = 0;
 #pragma unroll
-    for (int i = 0; i < WI_PUNITS; ++i) {
-        const int pix = (t >> 3) + WI_PROWS * i;
-        const int ppy = pix / WI_PW, ppx = pix - ppy * WI_PW;
-        const int sy = sy0 + ppy, sx = sx0 + ppx;
-        const bool ok = (pix < WI_PP) & (sy >= 0) & (sy < p.H) & (sx >= 0) & (sx < p.W);
-        poff[i] = ok ? (unsigned)((((size_t)n * p.H + sy) * p.W + sx) * p.Cin + 4 * kq) : 0u;
+    for (int i = 0; i < 3; ++i) {
+        const int u = i < 2 ? t + 512 * i : 1024 + wave * 34 + lane;
+        const bool real = i < 2 || lane < 34;
+        const int z = u >= W4_UNITS_SB ? 1 : 0;
+        const int pix = (u - W4_UNITS_SB * z) >> 1;
+        const int py = pix / W4_PW, px = pix - py * W4_PW;
+        const int y = (z ? sy0[1] : sy0[0]) - 1 + py, x = (z ? sx0[1] : sx0[0]) - 1 + px;
+        const bool ok = real && (z ? sval[1] : sval[0]) && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        // byte offset from the first sub-block's image (the second one lies in the same or the next image)
+        goff[i] = ok ? (unsigned)((((size_t)(z ? sn[1] - sn[0] : 0) * p.H + y) * p.W + x) * p.Cin + 4 * quad) * 4u : 0u;
         pmask |= (ok ? 1u : 0u) << i;
     }
-    float4 rp[WI_PUNITS], ga, gb;
-    auto load_patch = [&](int cc) {
+    // LDS offset / sub-block of unit i, recomputed per use (registers are the scarce resource here; ~3 VALU each)
+    auto unit_loff = [&](int i) -> int {
+        int tq = t;
+        asm volatile("" : "+v"(tq));         // opaque: keeps the compiler from hoisting the offsets out of the K loop into (spilled) registers
+        const int u = i < 2 ? tq + 512 * i : 1024 + wave * 34 + (tq & 63), z = u >= W4_UNITS_SB ? 1 : 0;
+        return z * W4_PPIX * W4_PS + ((u - W4_UNITS_SB * z) >> 1) * W4_PS + 4 * (tq & 1);
+    };
+    auto unit_z = [&](int i) -> int { return i == 0 ? 0 : (i == 1 ? (t >= W4_UNITS_SB - 512 ? 1 : 0) : 1); };
+    // buffer loads: descriptor + uniform byte offset in SGPRs, ONE 32-bit per-lane offset register per load (no 64-bit VALU adds)
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void *)(p.in + (size_t)sn[0] * p.H * p.W * p.Cin), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, 0x7fffffff, 0x00020000);
+    float4 rp[3];
+    auto load_patch = [&](int s) {       // unconditional (steps past the end re-read the last one): the wait counters stay static
+        const int sc = s < p.nsteps ? s : p.nsteps - 1;
 #pragma unroll
-        for (int i = 0; i < WI_PUNITS; ++i) rp[i] = ld4(p.in + (size_t)poff[i] + (size_t)cc * BK);
-        if (PRO == FEMASR_PRO_GN_SILU) {
-            ga = ld4(p.pro_a + (size_t)n * p.Cin + cc * BK + 4 * kq);
-            gb = ld4(p.pro_b + (size_t)n * p.Cin + cc * BK + 4 * kq);
+        for (int i = 0; i < 3; ++i) {
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[i], sc * 32, 0);
+            rp[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
-    auto store_patch = [&](int buf) {
-        float *Pb = Ps + buf * WI_PSZ;
+    auto store_patch = [&](int s, int buf) {
+        float *Pb = Ps + buf * W4_PSZ;
 #pragma unroll
-        for (int i = 0; i < WI_PUNITS; ++i) {
-            const int pix = (t >> 3) + WI_PROWS * i;
-            if (i == WI_PUNITS - 1 && pix >= WI_PP) continue;
+        for (int i = 0; i < 3; ++i) {
+            if (i == 2 && lane >= 34) continue;
             float4 v = rp[i];
             if (PRO == FEMASR_PRO_GN_SILU) {
-                const det_f32x2 s0 = det_silu2(__builtin_elementwise_fma(det_f32x2{v.x, v.y}, det_f32x2{ga.x, ga.y}, det_f32x2{gb.x, gb.y}));
-                const det_f32x2 s1 = det_silu2(__builtin_elementwise_fma(det_f32x2{v.z, v.w}, det_f32x2{ga.z, ga.w}, det_f32x2{gb.z, gb.w}));
-                v = make_float4(s0[0], s0[1], s1[0], s1[1]);
+                const int z = unit_z(i);
+                const float4 ga = ld4(ABs + z * 2 * p.Cin + s * 8 + 4 * quad), gb = ld4(ABs + z * 2 * p.Cin + p.Cin + s * 8 + 4 * quad);
+                v.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
+                v.y = det_silu(__builtin_fmaf(v.y, ga.y, gb.y));
+                v.z = det_silu(__builtin_fmaf(v.z, ga.z, gb.z));
+                v.w = det_silu(__builtin_fmaf(v.w, ga.w, gb.w));
             }
             if (!(pmask & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding AFTER the activation
-            float *dst = Pb + pix * ALD + 4 * kq;
-            dst[0] = v.x;
-            dst[1] = v.y;
-            dst[2] = v.z;
-            dst[3] = v.w;
+            float *dst = Pb + unit_loff(i);
+            *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
+            __builtin_amdgcn_sched_barrier(0);          // one unit at a time: the four SiLU chains of a unit already fill the VALU
         }
     };
 
-    // ---- input transform items: channel t&31, Winograd tiles (t>>5) and (t>>5) + 16
-    const int tci = t & 31;
-    auto transform = [&](const float *Pb) {
+    // ---- input transform item: tile tm, channel lane&7, rows 3*thalf .. 3*thalf+2 of B^T d (uniform per wave)
+    const int thalf = wave & 1;
+    const int tm = (wave >> 1) * 8 + (lane >> 3), tch = lane & 7;
+    const int tsrc = (tm >> 4) * W4_PPIX * W4_PS + ((4 * ((tm & 15) >> 2) + thalf) * W4_PW + 4 * (tm & 3)) * W4_PS + tch;
+    const int tdst = thalf * 18 * 256 + tm * 8 + (tch & 1) * 4 + (tch >> 1);
+    auto transform = [&](int pbuf, int vbuf) {
+        const float *src = Ps + pbuf * W4_PSZ + tsrc;
+        float *dst = Vs + vbuf * W4_VSZ + tdst;
+        float d[5][6];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int wt = (t >> 5) + 16 * u, wr = wt >> 3, wc = wt & 7;
-            const float *src = Pb + ((2 * wr) * WI_PW + 2 * wc) * ALD + tci;
-            float d[4][4], tt[4][4];
+        for (int a = 0; a < 5; ++a)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int b = 0; b < 6; ++b) d[a][b] = src[(a * W4_PW + b) * W4_PS];
+        float r[3][6];
+        if (thalf == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = src[(i * WI_PW + j) * ALD];
+            for (int b = 0; b < 6; ++b) bt_lo(d[0][b], d[1][b], d[2][b], d[3][b], d[4][b], r[0][b], r[1][b], r[2][b]);
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tt[0][j] = d[0][j] - d[2][j];
-                tt[1][j] = d[1][j] + d[2][j];
-                tt[2][j] = d[2][j] - d[1][j];
-                tt[3][j] = d[1][j] - d[3][j];
-            }
-            float *dst = Vs + wt * ALD + tci;
+            for (int b = 0; b < 6; ++b) bt_hi(d[0][b], d[1][b], d[2][b], d[3][b], d[4][b], r[0][b], r[1][b], r[2][b]);
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dst[(i * 4 + 0) * 32 * ALD] = tt[i][0] - tt[i][2];
-                dst[(i * 4 + 1) * 32 * ALD] = tt[i][1] + tt[i][2];
-                dst[(i * 4 + 2) * 32 * ALD] = tt[i][2] - tt[i][1];
-                dst[(i * 4 + 3) * 32 * ALD] = tt[i][1] - tt[i][3];
-            }
+        for (int i = 0; i < 3; ++i) {
+            float v0, v1, v2, v3, v4, v5;
+            bt_lo(r[i][0], r[i][1], r[i][2], r[i][3], r[i][4], v0, v1, v2);
+            bt_hi(r[i][1], r[i][2], r[i][3], r[i][4], r[i][5], v3, v4, v5);
+            float *o = dst + i * 6 * 256;
+            o[0 * 256] = v0;
+            o[1 * 256] = v1;
+            o[2 * 256] = v2;
+            o[3 * 256] = v3;
+            o[4 * 256] = v4;
+            o[5 * 256] = v5;
         }
     };
 
-    f32x16 acc[2][TNW];
+    // ---- M phase: pair q < 8 = (component 4 wave + q/2, column tile q&1); pair 8 = (component 32 + wave/2, column tile wave&1)
+    f32x16 acc[9];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int q = 0; q < 9; ++q)
 #pragma unroll
-        for (int j = 0; j < TNW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
-
-    // U fragments: [chunk q = cb*16 + component][32-column tile][16-byte group g][lane][4 k-pairs]: one wave load = 1 KiB of
-    // consecutive bytes (8 full cache lines).  Address = uniform pointer + lane * 16 bytes: no per-load VALU arithmetic.
-    const size_t wstride = (size_t)p.NT32 << 10;
-    int wt_[TNW];
-#pragma unroll
-    for (int j = 0; j < TNW; ++j) wt_[j] = wtile(n0, j, p.NT32);
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     const unsigned lw = (unsigned)lane * 16u;
-    const int k0 = 2 * wave;
-    auto ldw = [&](size_t q, int g, int j) -> f32x4_t { return ldg4_u32(p.w_wino + q * wstride + ((size_t)wt_[j] * 4 + g) * 256, lw); };
-
-    const int ncc = p.Cin / BK;
-    load_patch(0);
-    f32x4_t bq[2][TNW];          // fragment groups ping-pong between the two sets (8 steps per channel block: parity is stable)
-#pragma unroll
-    for (int j = 0; j < TNW; ++j) bq[0][j] = ldw((size_t)k0, 0, j);
-    store_patch(0);
-    __syncthreads();
-
-    // ---- output-stage geometry (needed early: the residual of the first round is fetched under the last MFMA phase)
-    const bool gnp = p.gn_part != nullptr;
-    const int cg = p.Cout >> 5, gpb = gnp ? BN / cg : 1;
-    const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
-    const size_t obase = (((size_t)n * p.Ho + oy0) * p.Wo + ox0) * p.Cout + n0;
-    const int q = wave & 3, jj = wave >> 2;            // this wave's 32-pixel block and slab in the output stage
-    // element r of (row tile q, column tile j): pixel row 2q + (r>>3), column (r&3) + 8((r>>2)&1) + 4 hh, channel 32 j + c31.
-    // Address = uniform part (SGPRs: q, j come from the wave index) + one per-lane offset, as in conv3x3_halo_kernel.
-    const unsigned loff = (unsigned)(4 * hh) * (unsigned)p.Cout + (unsigned)c31;
-    const bool full = (oy0 + 8 <= p.Ho) && (ox0 + 16 <= p.Wo) && (n0 + BN <= p.Cout);
-    auto uoff = [&](int j, int r) -> size_t {
-        return obase + (size_t)((2 * q + (r >> 3)) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1)) * p.Cout + j * 32;
+    const int aoff = c31 * 8 + hh * 4;
+    auto pcomp = [&](int q) -> int { return q < 8 ? 4 * wave + (q >> 1) : 32 + (wave >> 1); };
+    auto pntl = [&](int q) -> int { return q < 8 ? (q & 1) : (wave & 1); };
+    auto ldU = [&](int s, int q) -> f32x4_t {       // unconditional, like load_patch
+        const int sc = s < p.nsteps ? s : p.nsteps - 1;
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, lw, (((sc * 36 + pcomp(q)) * p.NT32 + 2 * nb + pntl(q)) << 10), 0);
+        return __builtin_bit_cast(f32x4_t, v);
     };
-    auto ok_u = [&](int j, int r) -> bool {
-        return full || ((oy0 + 2 * q + (r >> 3)) < p.Ho && (ox0 + (r & 3) + 8 * ((r >> 2) & 1)) < p.Wo && (n0 + j * 32) < p.Cout);
+    // U fragments.  ring: pairs 0-2 of the NEXT step, loaded behind this step's pairs 0-2 (live across the T phase).
+    // early: pairs 3-5, issued at the end of the T phase (the registers are free again): in flight across the barrier for
+    // waves 0-3, whose M phase follows it.
+    // late: pairs 6-8, issued at the start of the M phase (6 pairs = 1536 MFMA cycles ahead of their use).
+    f32x4_t ring[3], early[3], late[3];
+    auto issue_early = [&](int s) {
+#pragma unroll
+        for (int q = 3; q < 6; ++q) early[q - 3] = ldU(s, q);
     };
-    auto ok_l = [&](int j, int r) -> bool {
-        return full || ((oy0 + 2 * q + (r >> 3)) < p.Ho && (ox0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * hh) < p.Wo && (n0 + j * 32 + c31) < p.Cout);
-    };
-    float rv[16];
-    auto fetch_res = [&](const float *src, int j, float (&dst)[16]) {     // branch-free batch; masked elements read the tile origin
+    auto mphase = [&](int s) {
+        const float *Vb = Vs + (s & 1) * W4_VSZ + aoff;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[r] = ldg_u32(src + (ok_u(j, r) ? uoff(j, r) : obase), ok_l(j, r) ? 4u * loff : 0u);
-    };
-
-    const float *Va = Vs + c31 * ALD + hh;           // A fragment of component k, k-pair kk: Va[k*32*ALD + 2*kk]
-    WTT(0)
-    for (int cc = 0; cc < ncc; ++cc) {
-        transform(Ps + (cc & 1) * WI_PSZ);
-        WTT(1)
-        __syncthreads();                               // V complete; the patch buffer cc&1 is free again
-        WTT(2)
-        const int ccn = cc + 1 < ncc ? cc + 1 : cc;
-        const bool more = cc + 1 < ncc;
-        if (more) load_patch(ccn);
-        float aq[2][4];
+        for (int q = 6; q < 9; ++q) late[q - 6] = ldU(s, q);
+        f32x4_t an = *reinterpret_cast<const f32x4_t *>(Vb + pcomp(0) * 256);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) aq[0][e] = Va[k0 * 32 * ALD + 2 * e];
+        for (int q = 0; q < 9; ++q) {
+            const f32x4_t a = an;
+            if ((q & 1) && q + 1 < 9) an = *reinterpret_cast<const f32x4_t *>(Vb + pcomp(q + 1) * 256);      // one A fragment per component
+            const f32x4_t b = q < 3 ? ring[q] : (q < 6 ? early[q - 3] : late[q - 6]);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {                  // s = component * 4 + 16-byte group of k-pairs
-            const int comp = s >> 2, cur = s & 1, nxt = cur ^ 1;
-            {   // next fragment group: this block's next group, or the first group of the next channel block
-                const int sn = s + 1;
-                const size_t qn = sn < 8 ? (size_t)(cc * 16 + k0 + (sn >> 2)) : (size_t)(ccn * 16 + k0);
-                const int gn = sn < 8 ? (sn & 3) : 0;
-#pragma unroll
-                for (int j = 0; j < TNW; ++j) bq[nxt][j] = ldw(qn, gn, j);
-                if (sn < 8) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) aq[nxt][e] = Va[(k0 + (sn >> 2)) * 32 * ALD + 8 * (sn & 3) + 2 * e];
-                }
-            }
+            for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
+            if (q < 3) ring[q] = ldU(s + 1, q);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int j = 0; j < TNW; ++j)
-                    acc[comp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][e], bq[cur][j][e], acc[comp][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s == 3 && more) store_patch((cc + 1) & 1);      // (uniform) the loads were issued 64 MFMAs ago
         }
-        WTT(3)
-        __syncthreads();                               // every wave is done with V; the next patch is staged
-        WTT(4)
+    };
+
+    // ---- prologue
+    if (PRO == FEMASR_PRO_GN_SILU) {
+        for (int i = t; i < 4 * p.Cin; i += W4_NT) {
+            const int z = i / (2 * p.Cin), r = i - z * 2 * p.Cin;
+            const float *src = r < p.Cin ? p.pro_a : p.pro_b;
+            ABs[i] = src[(size_t)(z ? sn[1] : sn[0]) * p.Cin + (r < p.Cin ? r : r - p.Cin)];
+        }
+    }
+    load_patch(0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ring[q] = ldU(0, q);
+    __syncthreads();
+    store_patch(0, 0);
+    load_patch(1);
+    __syncthreads();
+    transform(0, 0);
+    if (1 < p.nsteps) store_patch(1, 1);
+    const int tfirst = wave >> 2;
+    if (tfirst) load_patch(2);
+    else issue_early(0);
+    __syncthreads();
+    WTT(0)
+
+    // ---- main loop over half-steps: waves 0-3 run M(s) T(s), waves 4-7 T(s) M(s); the patch of step s+2 is loaded right
+    //      before the wave's M phase and stored by its next T phase
+    for (int hs = 0; hs < 2 * p.nsteps; ++hs) {
+        const int s = hs >> 1;
+        if (((hs & 1) ^ tfirst) == 0) {
+            load_patch(s + 2 + tfirst);
+            mphase(s);
+            WTT(1)
+        } else {
+            if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);          // first: frees the staging registers ahead of the transform
+            WTT(2)
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < p.nsteps) transform((s + 1) & 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_early(s + 1 - tfirst);        // waves 0-3: in flight across the barrier; waves 4-7: right ahead of their M phase
+            WTT(3)
+        }
+        if (hs & 1) { __syncthreads(); WTT(4) }
     }
 
     // ---------------------------------------------------------------------------------------------------------------
-    // epilogue.  Slabs Ms[jj][k][wt][c] (two 32-channel tiles per round) overlay the patch / V buffers.
-    float *Ms = smem;
-    double *red = reinterpret_cast<double *>(smem + 2 * WI_VSZ);
-    constexpr int ROUNDS = (TNW + 1) / 2;
-    if (ra && jj < TNW) fetch_res(ra, jj, rv);         // the first round's residual flies under the slab exchange
+    // epilogue: Mx[component][tile][32 channels] of one column tile at a time overlays the main-loop buffers
+    float *Mx = smem;
+    double *red = reinterpret_cast<double *>(smem + W4_MX);
+    const bool gnp = p.gn_part != nullptr;
+    const int cg = p.Cout >> 5;                      // channels per GroupNorm group (>= 2: Cout % 64 == 0)
+    const int gpt = 32 / (cg < 32 ? cg : 32);        // groups per 32-channel tile (<= 16)
+    const int tl = t >> 5;                           // Winograd tile inside the sub-block: 2 wave + hh
+    const int ety = tl >> 2, etx = tl & 3;
+    // the thread's two output items (sub-block z, tile tl, channel c31 of the round's column tile): validity of the 16 pixels
+    // (bit 4a + b) and the element offset of pixel (0, 0); masked pixels read / address the first valid element instead
+    unsigned vmask[2];
+    size_t obase[2];
 #pragma unroll
-    for (int rnd = 0; rnd < ROUNDS; ++rnd) {
+    for (int z = 0; z < 2; ++z) {
+        const int oy = (z ? sy0[1] : sy0[0]) + 4 * ety, ox = (z ? sx0[1] : sx0[0]) + 4 * etx;
+        unsigned m = 0;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int k = 0; k < 16; ++k) m |= ((z ? sval[1] : sval[0]) && oy + (k >> 2) < p.H && ox + (k & 3) < p.W ? 1u : 0u) << k;
+        vmask[z] = m;
+        obase[z] = (m ? (((size_t)(z ? sn[1] : sn[0]) * p.H + oy) * p.W + ox) * p.Cout : (size_t)0) + n0 + c31;
+    }
+    auto eoff = [&](int k) -> unsigned { return (unsigned)((k >> 2) * p.W + (k & 3)) * (unsigned)p.Cout; };      // uniform
+    auto fetch = [&](const float *src, int z, int r, float (&dst)[16]) {       // branch-free batch of 16 loads
+        const float *bp = src + obase[z] + 32 * r;
 #pragma unroll
-            for (int sj = 0; sj < 2; ++sj) {
-                if (2 * rnd + sj >= TNW) continue;
-                float *dst = Ms + ((size_t)(sj * 16 + k0 + c) * 32) * ALD + c31;
+        for (int k = 0; k < 16; ++k) dst[k] = bp[(vmask[z] >> k) & 1u ? eoff(k) : 0u];
+    };
+    auto item = [&](int z, int r, float bv, const float (&r1)[16], const float (&r2)[16]) {
+        const float *src = Mx + (z * 16 + tl) * 32 + c31;
+        float tt[4][6];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * hh) * ALD] = acc[c][2 * rnd + sj][r];
+        for (int j = 0; j < 6; ++j)
+            at6(src[(0 * 6 + j) * 1024], src[(1 * 6 + j) * 1024], src[(2 * 6 + j) * 1024], src[(3 * 6 + j) * 1024], src[(4 * 6 + j) * 1024],
+                src[(5 * 6 + j) * 1024], tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
+        float *bo = p.out + obase[z] + 32 * r;
+        double gs = 0.0, gss = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float y[4];
+            at6(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int k = 4 * a + b;
+                const bool ok = (vmask[z] >> k) & 1u;
+                float v = y[b] + bv;
+                if (p.res1) v = v + r1[k];
+                if (p.res2) v = v + r2[k];
+                if (ok) bo[eoff(k)] = v;
+                if (gnp) {                                   // a masked pixel adds +0 (the oracle skips it: same sums)
+                    const double dv = ok ? (double)v : 0.0;
+                    gs = gs + dv;
+                    gss = __builtin_fma(dv, dv, gss);
+                }
             }
+        }
+        if (gnp) {      // channels of the group (xor butterfly), the tile pair of the wave, then the 8 waves in order
+            for (int d = 1; d < cg && d < 32; d <<= 1) {
+                gs = gs + __shfl_xor(gs, d, 64);
+                gss = gss + __shfl_xor(gss, d, 64);
+            }
+            const double a2 = gs + __shfl_xor(gs, 32, 64), b2 = gss + __shfl_xor(gss, 32, 64);
+            if (lane < 32 && (c31 & (cg - 1)) == 0) {
+                double *dst = red + ((size_t)(wave * 2 + z) * 16 + c31 / cg) * 2;
+                dst[0] = a2;
+                dst[1] = b2;
+            }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (pntl(q) == r) {
+                float *dst = Mx + pcomp(q) * 1024 + c31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32] = acc[q][e];
+            }
+        }
+        float ra1[16], ra2[16], rb1[16], rb2[16];          // residuals of the two items: in flight across the barrier / the first item
+        if (p.res1) fetch(p.res1, 0, r, ra1);
+        if (p.res2) fetch(p.res2, 0, r, ra2);
+        const float bv = p.bias[n0 + 32 * r + c31];
         __syncthreads();
         WTT(5)
-        const int j = 2 * rnd + jj;                    // 32-channel tile of the block handled by this wave now
-        if (j < TNW) {
-            float rn[16], r2[16];
-            const bool next = rnd + 1 < ROUNDS && j + 2 < TNW;
-            if (ra && next) fetch_res(ra, j + 2, rn);  // the next round's residual flies under this round's arithmetic
-            if (rb) fetch_res(rb, j, r2);
-            float v[16];
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const int wt = q * 8 + (t4 >> 1) * 4 + 2 * hh + (t4 & 1);
-                const float *src = Ms + ((size_t)(jj * 16) * 32 + wt) * ALD + c31;
-                float m[16], sm[2][4];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) m[k] = src[(size_t)k * 32 * ALD];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    sm[0][x] = (m[0 * 4 + x] + m[1 * 4 + x]) + m[2 * 4 + x];
-                    sm[1][x] = (m[1 * 4 + x] - m[2 * 4 + x]) - m[3 * 4 + x];
-                }
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const int r0 = dy * 8 + (t4 >> 1) * 4 + (t4 & 1) * 2;
-                    v[r0] = (sm[dy][0] + sm[dy][1]) + sm[dy][2];
-                    v[r0 + 1] = (sm[dy][1] - sm[dy][2]) - sm[dy][3];
-                }
-            }
-            // from here on: the direct halo kernel's epilogue for row tile q, column tile j (same pixel per element r)
-            const int col = n0 + j * 32 + c31;
-            const float bv = col < p.Cout ? p.bias[col] : 0.f;
-            double gs = 0.0, gss = 0.0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float y = v[r] + bv;
-                if (ra) y = y + rv[r];
-                if (rb) y = y + r2[r];
-                if (ok_l(j, r)) {
-                    stg_u32(p.out + uoff(j, r), 4u * loff, y);
-                    if (gnp) {
-                        const double d = (double)y;
-                        gs = gs + d;
-                        gss = __builtin_fma(d, d, gss);
-                    }
-                }
-            }
-            if (ra && next) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = rn[r];
-            }
-            if (gnp) {      // levels 1 and 2 of the moment tree (lane halves, channels of the group), as in conv3x3_halo_kernel
-                double a = gs + __shfl_xor(gs, 32, 64), b = gss + __shfl_xor(gss, 32, 64);
-                for (int d = 1; d < cg; d <<= 1) {
-                    a = a + __shfl_xor(a, d, 64);
-                    b = b + __shfl_xor(b, d, 64);
-                }
-                const int cl = j * 32 + c31;
-                if (lane < 32 && (cl & (cg - 1)) == 0) {
-                    double *dst = red + ((size_t)q * gpb + cl / cg) * 2;
-                    dst[0] = a;
-                    dst[1] = b;
-                }
-            }
-        }
+        if (p.res1) fetch(p.res1, 1, r, rb1);
+        if (p.res2) fetch(p.res2, 1, r, rb2);
+        item(0, r, bv, ra1, ra2);
+        item(1, r, bv, rb1, rb2);
         __syncthreads();
         WTT(6)
+        if (gnp && t < 2 * gpt) {
+            const int z = t / gpt, gl = t - z * gpt;
+            if (z ? sval[1] : sval[0]) {
+                double S = red[((size_t)(0 * 2 + z) * 16 + gl) * 2], SS = red[((size_t)(0 * 2 + z) * 16 + gl) * 2 + 1];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) {
+                    S = S + red[((size_t)(w * 2 + z) * 16 + gl) * 2];
+                    SS = SS + red[((size_t)(w * 2 + z) * 16 + gl) * 2 + 1];
+                }
+                const int g = (n0 + 32 * r) / cg + gl;
+                double *dst = p.gn_part + (((size_t)(z ? sn[1] : sn[0]) * p.sbY * p.sbX + (z ? sbi[1] : sbi[0])) * 32 + g) * 2;
+                dst[0] = S;
+                dst[1] = SS;
+            }
+        }
     }
     WTT_END
-    if (gnp && t < gpb) {
-        const int g = n0 / cg + t;
-        if (g < 32) {
-            double S = red[(0 * gpb + t) * 2], SS = red[(0 * gpb + t) * 2 + 1];
-#pragma unroll
-            for (int qq = 1; qq < 4; ++qq) {           // level 3: ((q0 + q1) + q2) + q3
-                S = S + red[((size_t)qq * gpb + t) * 2];
-                SS = SS + red[((size_t)qq * gpb + t) * 2 + 1];
-            }
-            double *dst = p.gn_part + (((size_t)n * p.tilesY * p.tilesX + (size_t)ty * p.tilesX + tx) * 32 + g) * 2;
-            dst[0] = S;
-            dst[1] = SS;
-        }
+}
+
+// G g G^T per (o, i), rows (over ky) then columns (over kx), each one fixed sequence of IEEE operations:
+//   u0 = g0 * 0.25     u1 = ((g0 + g1) + g2) * (-1/6)     u2 = ((g0 - g1) + g2) * (-1/6)
+//   u3 = fma(4, g2, fma(2, g1, g0)) * (1/24)     u4 = fma(4, g2, fma(-2, g1, g0)) * (1/24)     u5 = g2
+__device__ __forceinline__ float g6(int r, float g0, float g1, float g2)
+{
+    const float c6 = -1.0f / 6.0f, c24 = 1.0f / 24.0f;
+    switch (r) {
+    case 0: return g0 * 0.25f;
+    case 1: return ((g0 + g1) + g2) * c6;
+    case 2: return ((g0 - g1) + g2) * c6;
+    case 3: return __builtin_fmaf(4.0f, g2, __builtin_fmaf(2.0f, g1, g0)) * c24;
+    case 4: return __builtin_fmaf(4.0f, g2, __builtin_fmaf(-2.0f, g1, g0)) * c24;
+    default: return g2;
     }
 }
 
-// 3x3 OIHW -> U = G g G^T, K order of a 4x4-tap conv (k = ((ci/32)*16 + 4 i + j)*32 + ci%32), stored as
-// out[q = k/32][ntile][g][lane][t]: column o = 32 ntile + lane%32, k = 32 q + 2 (4 g + t) + lane/32   (same size as the
-// fragment-major layout of femasr_repack_oihw; a wave's 16-byte-per-lane load of one (q, ntile, g) is contiguous)
+// 3x3 OIHW -> out[step = ci/8][component 6 i + j][32-column tile][lane][e]: column o = 32 tile + lane%32,
+// ci = 8 step + 2 e + lane/32 (the B fragments of the four k-pairs of a step: one 16-byte load per lane, 1 KiB per wave)
 __global__ void repack_wino_kernel(const float *__restrict__ in, int O, int I, float *__restrict__ out, size_t total)
 {
-    const int K = I * 16, NT32 = (O + 31) / 32;
+    const int NT32 = (O + 31) / 32;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int tq = (int)(idx & 3), lane = (int)((idx >> 2) & 63), g = (int)((idx >> 8) & 3);
-        const size_t rest = idx >> 10;
-        const int ntile = (int)(rest % NT32), q = (int)(rest / NT32);
-        const int k = q * 32 + (4 * g + tq) * 2 + (lane >> 5), o = ntile * 32 + (lane & 31);
+        const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        size_t rest = idx >> 8;
+        const int ntile = (int)(rest % NT32);
+        rest /= NT32;
+        const int comp = (int)(rest % 36), step = (int)(rest / 36);
+        const int ci = 8 * step + 2 * e + (lane >> 5), o = ntile * 32 + (lane & 31);
         float v = 0.f;
-        if (k < K && o < O) {
-            const int cl = k % 32, r = k / 32, comp = r & 15, ci = (r >> 4) * 32 + cl;
-            const int i = comp >> 2, j = comp & 3;
+        if (ci < I && o < O) {
+            const int i = comp / 6, j = comp - 6 * i;
             const float *gw = in + ((size_t)o * I + ci) * 9;
-            float u[3];
+            float ur[3];
 #pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                const float g0 = gw[x], g1 = gw[3 + x], g2 = gw[6 + x];
-                u[x] = i == 0 ? g0 : (i == 1 ? ((g0 + g1) + g2) * 0.5f : (i == 2 ? ((g0 - g1) + g2) * 0.5f : g2));
-            }
-            v = j == 0 ? u[0] : (j == 1 ? ((u[0] + u[1]) + u[2]) * 0.5f : (j == 2 ? ((u[0] - u[1]) + u[2]) * 0.5f : u[2]));
+            for (int x = 0; x < 3; ++x) ur[x] = g6(i, gw[x], gw[3 + x], gw[6 + x]);
+            v = g6(j, ur[0], ur[1], ur[2]);
         }
         out[idx] = v;
     }
@@ -368,17 +463,14 @@ __global__ void repack_wino_kernel(const float *__restrict__ in, int O, int I, f
 
 struct WVariant {
     const char *name;
-    int bn;
-    void (*kern)(const ConvParams);
-    size_t lds;
+    void (*kern)(const WinoParams);
     unsigned long long attr_devs;
+    size_t attr_lds;
 };
-#define FEMASR_WINO(TNW, PRO) { "conv3x3_wino<8x16x" #TNW "*32," #PRO ",waves=8>", 32 * TNW, conv3x3_wino_kernel<TNW, PRO>, wino_lds_bytes<TNW>(), 0ull }
+#define FEMASR_WINO(PRO, RING) { "conv3x3_wino4<2x16x16px x64," #PRO ",ring" #RING ",waves=8>", conv3x3_wino4_kernel<PRO, RING>, 0ull, 0 }
 WVariant g_wv[] = {
-    FEMASR_WINO(4, FEMASR_PRO_NONE),
-    FEMASR_WINO(4, FEMASR_PRO_GN_SILU),
-    FEMASR_WINO(2, FEMASR_PRO_NONE),
-    FEMASR_WINO(2, FEMASR_PRO_GN_SILU),
+    FEMASR_WINO(FEMASR_PRO_NONE, 3),
+    FEMASR_WINO(FEMASR_PRO_GN_SILU, 3),
 };
 constexpr int kNumW = sizeof(g_wv) / sizeof(g_wv[0]);
 
@@ -386,41 +478,48 @@ constexpr int kNumW = sizeof(g_wv) / sizeof(g_wv[0]);
 
 bool femasr_conv_wino_shape_ok(const femasr_conv_args *a)
 {
-    return a->ksz == 3 && a->stride == 1 && a->pad == 1 && !a->up2 && a->act == FEMASR_ACT_NONE && (a->Cin % BK) == 0 &&
+    return a->ksz == 3 && a->stride == 1 && a->pad == 1 && !a->up2 && a->act == FEMASR_ACT_NONE && (a->Cin % BK) == 0 && a->Cin <= 1024 &&
            (a->Cout % 64) == 0 && (a->prologue == FEMASR_PRO_NONE || a->prologue == FEMASR_PRO_GN_SILU) &&
-           (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31) && (size_t)a->B * a->H * a->W * a->Cout < ((size_t)1 << 31);
+           (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31) && (size_t)a->B * a->H * a->W * a->Cout < ((size_t)1 << 31) &&
+           (size_t)a->H * a->W * a->Cin < ((size_t)1 << 27) &&          // two images within the 2 GiB range of the input descriptor
+           (size_t)36 * a->Cin * a->Cout < ((size_t)1 << 29);
 }
 int femasr_conv_wino_variant_count() { return kNumW; }
 const char *femasr_conv_wino_variant_name(int v) { return v >= 0 && v < kNumW ? g_wv[v].name : "?"; }
+int femasr_conv_wino_gn_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }
 
 int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out)
 {
     FEMASR_REQUIRE(a && a->in && a->w_wino && a->bias && a->out && femasr_conv_wino_shape_ok(a), "conv_wino: bad arguments / shape");
     FEMASR_REQUIRE(a->Ho == a->H && a->Wo == a->W, "conv_wino: Ho/Wo mismatch");
-    if (a->prologue == FEMASR_PRO_GN_SILU) FEMASR_REQUIRE(a->pro_a && a->pro_b, "conv_wino: GN prologue needs a,b");
+    const bool gn = a->prologue == FEMASR_PRO_GN_SILU;
+    if (gn) FEMASR_REQUIRE(a->pro_a && a->pro_b, "conv_wino: GN prologue needs a,b");
     FEMASR_REQUIRE(!a->gn_part || femasr_gn_fusable(a->Cout), "conv_wino: gn_part needs 32 | Cout and Cout/32 a power of two <= 32");
-    ConvParams p{};
-    p.in = a->in; p.w_wino = (const float *)a->w_wino; p.bias = a->bias; p.pro_a = a->pro_a; p.pro_b = a->pro_b;
-    p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
-    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.ksz = 3; p.stride = 1; p.pad = 1; p.Ho = a->H; p.Wo = a->W;
-    p.NT32 = (a->Cout + 31) / 32;
-    p.gn_part = a->gn_part;
-    const int vi = ((a->Cout % 128) == 0 ? 0 : 2) + (a->prologue == FEMASR_PRO_GN_SILU ? 1 : 0);
+    WinoParams p{};
+    p.in = a->in; p.u = (const float *)a->w_wino; p.bias = a->bias; p.pro_a = a->pro_a; p.pro_b = a->pro_b;
+    p.res1 = a->res1; p.res2 = a->res2; p.out = a->out; p.gn_part = a->gn_part;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
+    p.sbX = (a->W + 15) / 16;
+    p.sbY = (a->H + 15) / 16;
+    p.nsb = a->B * p.sbX * p.sbY;
+    p.MB = (p.nsb + 1) / 2;
+    p.NB = a->Cout / 64;
+    p.nsteps = a->Cin / 8;
+    p.NT32 = a->Cout / 32;
+    const int vi = gn ? 1 : 0;
     WVariant &v = g_wv[vi];
-    p.tilesX = (a->W + 15) / 16;
-    p.tilesY = (a->H + 7) / 8;
-    p.MB = a->B * p.tilesX * p.tilesY;
-    p.NB = a->Cout / v.bn;
+    const size_t lds = wino_lds_bytes(a->Cin, gn);
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull)) {
-        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+    if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull) || v.attr_lds < lds) {
+        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
+        if (v.attr_lds < lds) { v.attr_lds = lds; v.attr_devs = dev >= 0 && dev < 64 ? 1ull << dev : 0ull; }
     }
-    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(WI_NT), v.lds, s, p);
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(W4_NT), lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
-    // ALGORITHMIC flops (the definition's 9 taps per output pixel, like every other conv launcher); the kernel issues 16/36 of them
+    // ALGORITHMIC flops (the definition's 9 taps per output pixel, like every other conv launcher); the kernel issues 36/144 of them
     if (flops_out) *flops_out = 2.0 * (double)a->B * a->H * a->W * 9.0 * (double)a->Cin * (double)a->Cout;
     return FEMASR_OK;
 }
@@ -435,12 +534,12 @@ int femasr_debug_wino_time(unsigned long long *buf, int reset)
 }
 #endif
 
-size_t femasr_wino_weight_floats(int O, int I) { return (I % 32) == 0 ? femasr_packed_weight_floats(O, I, 4, 4) : 0; }
+size_t femasr_wino_weight_floats(int O, int I) { return (I % 32) == 0 ? (size_t)(I / 8) * 36 * ((O + 31) / 32) * 256 : 0; }
 
 int femasr_repack_oihw_wino(void *stream, const float *in, int O, int I, float *out)
 {
     FEMASR_REQUIRE(in && out && O > 0 && I > 0 && (I % 32) == 0, "repack_wino: needs a 3x3 OIHW weight with I %% 32 == 0");
-    const size_t total = femasr_packed_weight_floats(O, I, 4, 4);
+    const size_t total = femasr_wino_weight_floats(O, I);
     size_t blocks = (total + 255) / 256;
     if (blocks > 65535) blocks = 65535;
     hipLaunchKernelGGL(repack_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, O, I, out, total);

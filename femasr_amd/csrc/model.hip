@@ -369,14 +369,16 @@ struct Ctx {
             if (it != h->index.end()) split = h->specs[it->second].split;
         }
         const bool lowp_on = split != nullptr && cout > 4 && femasr_conv_bf16x3_shape_ok(&a);      // out_conv: exact VALU kernel in both modes
-        // exact-fp32 mode: convs behind the codebook lookup of a single-codebook network run in the Winograd F(2x2,3x3) form
+        // exact-fp32 mode: convs behind the codebook lookup of a single-codebook network run in the Winograd F(4x4,3x3) form
         // (they cannot move a VQ index; oracle: OracleNet.wino).  decoder_math 2 = 'fp32_direct' keeps the direct form.
         const bool wino_on = !lowp_on && o.lowp && h->decoder_math == 0 && h->cfg.n_codebooks == 1 && femasr_conv_wino_shape_ok(&a);
         const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
                                    : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
         if (o.want_gn && gn_ok) {
             // exact x2 convs (phase filters) emit one partial per half-resolution tile and phase
-            y.gn_tiles = (o.up2 && !lowp_on) ? 4 * ((x.H + 7) / 8) * ((x.W + 15) / 16) : ((Ho + 7) / 8) * ((Wo + 15) / 16);
+            // (a Winograd conv emits one partial per 16x16-pixel sub-block, orc_gn_coeffs mode 2)
+            y.gn_tiles = (o.up2 && !lowp_on) ? 4 * ((x.H + 7) / 8) * ((x.W + 15) / 16)
+                         : (wino_on ? femasr_conv_wino_gn_tiles(Ho, Wo) : ((Ho + 7) / 8) * ((Wo + 15) / 16));
             y.gn_part = (double *)arena->alloc((size_t)x.B * y.gn_tiles * 32 * 2 * sizeof(double));
             if (!y.gn_part && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
         }

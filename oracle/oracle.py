@@ -103,7 +103,7 @@ def repack_linear_weight(w_oi):
 
 
 def winograd_ok(cin, cout, ksz, stride, pad, up2, act=0):
-    """The shapes the kernels run in the Winograd F(2x2,3x3) form when the caller marks the conv as behind the codebook
+    """The shapes the kernels run in the Winograd F(4x4,3x3) form when the caller marks the conv as behind the codebook
     lookup (femasr_conv_args.w_wino): 3x3 stride-1 pad-1, no x2, Cin % 32 == 0, Cout % 64 == 0."""
     return ksz == 3 and stride == 1 and pad == 1 and not up2 and act == 0 and cin % 32 == 0 and cout % 64 == 0
 
@@ -151,14 +151,15 @@ def gn_fusable(c):
 
 
 def gn_coeffs(x, gamma, beta, eps=1e-6, groups=32, phases=False):
-    """phases: x is the output of a phase-filter x2 conv whose epilogue produced the partial moments (per half-resolution tile
-    and phase) -- only the ORDER of the fp64 partial sums differs."""
+    """phases: x is the output of a conv whose epilogue produced the partial moments in its own tile order -- only the ORDER of
+    the fp64 partial sums differs.  True / 1: a phase-filter x2 conv (per half-resolution tile and phase); 2: a Winograd conv
+    (per 16x16-pixel sub-block, orc_gn_wino_partial)."""
     x = _c(x)
     b, h, w, c = x.shape
     a = np.empty((b, c), np.float32)
     bb = np.empty((b, c), np.float32)
     gamma, beta = _c(gamma), _c(beta)
-    lib().orc_gn_coeffs(_p(x), b, h, w, c, groups, _p(gamma), _p(beta), eps, _p(a), _p(bb), int(bool(phases)))
+    lib().orc_gn_coeffs(_p(x), b, h, w, c, groups, _p(gamma), _p(beta), eps, _p(a), _p(bb), int(phases))
     return a, bb
 
 
@@ -243,7 +244,7 @@ class OracleNet:
                  scale_factor=4, use_quantize=True, use_residual=True, winograd=True):
         self.sd = {k: np.asarray(v) for k, v in sd.items()}
         # the kernels' default exact-fp32 mode: 3x3 convs behind the codebook lookup of a single-codebook network run in
-        # the Winograd F(2x2,3x3) form (model.hip Ctx::conv `wino`); winograd=False = decoder_math 'fp32_direct'
+        # the Winograd F(4x4,3x3) form (model.hip Ctx::conv `wino`); winograd=False = decoder_math 'fp32_direct'
         self.wino = bool(winograd) and len(codebook_params) == 1
         self.cb_scales = [int(c[0]) for c in codebook_params]
         self.LQ_stage = bool(LQ_stage)
@@ -278,13 +279,21 @@ class OracleNet:
         w, b = self._conv_w(prefix)
         return conv2d(x, w, b, ksz, stride, pad, up2, 0, res1, res2, wino=dec and self.wino)
 
-    def _resblock(self, x, prefix, res2=None, dec=False, from_up2=None):
+    def _wino_fused(self, c, dec):
+        """The conv that produced a c-channel tensor ran in the Winograd form AND emitted the GroupNorm partials (model.hip
+        Ctx::conv: wino_on && gn_ok): the next GroupNorm sums them in the sub-block order (orc_gn_coeffs mode 2)."""
+        return dec and self.wino and winograd_ok(c, c, 3, 1, 1, False) and gn_fusable(c)
+
+    def _resblock(self, x, prefix, res2=None, dec=False, from_up2=None, from_wino=False):
         # fema_utils.py:65-84: conv2(silu(gn2(conv1(silu(gn1(x)))))) + x   (+ optional fused skip add)
-        # from_up2 = Cin of the x2 conv that produced x: its phase-filter kernel emitted the moments (phase-tile order)
-        ph = from_up2 is not None and from_up2 % 32 == 0 and gn_fusable(x.shape[-1])
+        # from_up2 = Cin of the x2 conv that produced x: its phase-filter kernel emitted the moments (phase-tile order);
+        # from_wino: x is the output of the previous ResBlock's Winograd conv, which emitted the moments (sub-block order)
+        c = x.shape[-1]
+        ph = 1 if (from_up2 is not None and from_up2 % 32 == 0 and gn_fusable(c)) else (2 if (from_wino and self._wino_fused(c, dec)) else 0)
         t = gn_silu(x, self.sd[prefix + '.conv.0.norm.weight'], self.sd[prefix + '.conv.0.norm.bias'], phases=ph)
         t = self._conv(t, prefix + '.conv.2', 3, dec=dec)
-        t = gn_silu(t, self.sd[prefix + '.conv.3.norm.weight'], self.sd[prefix + '.conv.3.norm.bias'])
+        t = gn_silu(t, self.sd[prefix + '.conv.3.norm.weight'], self.sd[prefix + '.conv.3.norm.bias'],
+                    phases=2 if self._wino_fused(c, dec) else 0)
         return self._conv(t, prefix + '.conv.5', 3, res1=x, res2=res2, dec=dec)
 
     def _swin_block(self, x, b, h, w, prefix, shift):
@@ -336,7 +345,7 @@ class OracleNet:
                 cin = x.shape[-1]
                 x = self._conv(x, f'{p}.blocks.{bi}.1', 3, 1, 1, up2=True)
                 x = self._resblock(x, f'{p}.blocks.{bi}.2', dec=True, from_up2=cin)       # the LQ up-blocks only make the decoder's skip features
-                x = self._resblock(x, f'{p}.blocks.{bi}.3', dec=True)
+                x = self._resblock(x, f'{p}.blocks.{bi}.3', dec=True, from_wino=True)
                 self._probe(f'enc_block{bi}', x)
                 outs.append(x)
                 bi += 1
@@ -347,7 +356,7 @@ class OracleNet:
         cin = x.shape[-1]
         x = self._conv(x, p + '.1', 3, 1, 1, up2=True)
         x = self._resblock(x, p + '.2', dec=True, from_up2=cin)
-        return self._resblock(x, p + '.3', res2=res2, dec=True)
+        return self._resblock(x, p + '.3', res2=res2, dec=True, from_wino=True)
 
     def encode_and_decode(self, x_nhwc):
         """femasr_arch.py:311-374; returns (out NHWC, [indices (B,1,h,w) int64 per codebook])."""

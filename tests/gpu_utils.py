@@ -89,6 +89,8 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
         tiles = ((ho + 7) // 8) * ((wo + 15) // 16)
         if wup2 is not None:        # phase-filter x2 conv: one partial per half-resolution tile and phase
             tiles = 4 * ((h + 7) // 8) * ((w + 15) // 16)
+        if wwino is not None:       # Winograd conv: one partial per 16x16-pixel sub-block
+            tiles = ((ho + 15) // 16) * ((wo + 15) // 16)
         part = torch.full((b, tiles, 32, 2), float('nan'), dtype=torch.float64, device='cuda')
         a.gn_part = part.data_ptr()
     _lib.check(lib.femasr_conv2d(None, ctypes.byref(a)))

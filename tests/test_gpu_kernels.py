@@ -292,8 +292,8 @@ def test_conv_up2_phase_filters_bit_exact(cuda_device, cin, cout, shape, nres):
     (256, 128, (1, 9, 7), False, 1, False), (64, 64, (1, 24, 40), True, 1, True), (32, 192, (2, 5, 33), False, 0, False),
     (512, 256, (1, 8, 8), False, 0, False)])
 def test_conv_winograd_bit_exact(cuda_device, cin, cout, shape, gn, nres, part):
-    """3x3 convs in the Winograd F(2x2,3x3) form: bit-identical to the oracle's restatement of the same form (including the
-    fused GroupNorm partial moments of the output), and within fp32 rounding of the direct form."""
+    """3x3 convs in the Winograd F(4x4,3x3) form: bit-identical to the oracle's restatement of the same form (including the
+    fused GroupNorm partial moments of the output, summed in the sub-block order), and within fp32 rounding of the direct form."""
     import gpu_utils as G
     b, h, w = shape
     x = synth.uniform(21, 'wix', (b, h, w, cin), -2.0, 2.0)
@@ -312,11 +312,11 @@ def test_conv_winograd_bit_exact(cuda_device, cin, cout, shape, gn, nres, part):
     _same(y, y_ref, 'winograd conv')
     y_dir = orc.conv2d(xin, wt, bias, 3, 1, 1, res1=r1, res2=r2)
     err = np.abs(y - y_dir).max()
-    assert err <= 2e-5 * max(1.0, np.abs(y_dir).max()), err
+    assert err <= 1e-4 * max(1.0, np.abs(y_dir).max()), err
     if part:
         gamma = synth.uniform(21, 'wigg', (cout,), 0.5, 1.5)
         beta = synth.uniform(21, 'wigbe', (cout,), -0.5, 0.5)
-        a_ref, b_ref = orc.gn_coeffs(y_ref, gamma, beta)
+        a_ref, b_ref = orc.gn_coeffs(y_ref, gamma, beta, phases=2)
         a, bb = G.gn_coeffs_from_partials(got[1], h, w, cout, gamma, beta)
         _same(a, a_ref, 'fused gn a (winograd)')
         _same(bb, b_ref, 'fused gn b (winograd)')

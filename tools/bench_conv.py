@@ -20,7 +20,7 @@ def main():
     ap.add_argument('--gn', action='store_true')
     ap.add_argument('--res', action='store_true')
     ap.add_argument('--fp32', action='store_true')
-    ap.add_argument('--wino', action='store_true', help='Winograd F(2x2,3x3) form (fp32)')
+    ap.add_argument('--wino', action='store_true', help='Winograd F(4x4,3x3) form (fp32)')
     ap.add_argument('--gn-part', action='store_true')
     ap.add_argument('--k1', action='store_true', help='1x1 conv / nn.Linear (fp32 igemm path)')
     ap.add_argument('--gelu', action='store_true')
@@ -65,7 +65,7 @@ def main():
         _lib.check(lib.femasr_repack_oihw_bf16x3(None, _lib.ptr(w_oihw), cout, cin, 3, 3, _lib.ptr(ws)))
         args.w_bf16x3 = ws.data_ptr(); keep.append(ws)
     if a_.gn_part:
-        tiles = ((ho + 7) // 8) * ((wo + 15) // 16)
+        tiles = ((ho + 15) // 16) * ((wo + 15) // 16) if a_.wino else ((ho + 7) // 8) * ((wo + 15) // 16)
         part = torch.empty(b, tiles, 32, 2, dtype=torch.float64, device=dev)
         args.gn_part = part.data_ptr(); keep.append(part)
     for _ in range(2):
@@ -87,10 +87,11 @@ def main():
         buf = (ctypes.c_ulonglong * 8)()
         raw.femasr_debug_wino_time(buf, 0)
         tot = float(buf[7]) or 1.0
-        names = ['prologue', 'transform', 'barrier_T', 'mfma_phase', 'barrier_M', 'slab_exchange', 'output_stage']
+        names = ['prologue', 'M_phase', 'store_patch', 'transform', 'barrier', 'epi_exchange', 'epi_items']
         print('  per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(names)))
-        nwaves = b * ((ho + 7) // 8) * ((wo + 15) // 16) * (cout // (128 if cout % 128 == 0 else 64)) * 8
-        print('  cycles per wave: %.0f' % (tot / (a_.iters + 2) / nwaves))
+        nsb = b * ((ho + 15) // 16) * ((wo + 15) // 16)
+        nwaves = ((nsb + 1) // 2) * (cout // 64) * 8
+        print('  cycles per wave: %.0f' % (tot / a_.iters / nwaves))
     print('conv %s dbg=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_DBG', '0') + '/' + os.environ.get('FEMASR_DBG16', '0'),
                                                                     os.environ.get('FEMASR_BF16_CLS', '-'), ms, fl / ms / 1e9))
 
