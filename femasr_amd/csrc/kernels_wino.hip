@@ -99,6 +99,15 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
     y3 = __builtin_fmaf(8.0f, ss, qq) + m5;
 }
 
+#ifndef FEMASR_WINO_ABL      // ablation experiments (tools/build_debug.sh): bit 0 no patch loads, 1 no U loads, 2 no transform, 3 no MFMAs,
+#define FEMASR_WINO_ABL 0    // 4 no output items, 5 no activation, 6 no staging stores
+#endif
+#ifdef FEMASR_WINO_FASTACT      // experiment: hardware exp2 / rcp (1 ulp each) instead of the IEEE-exact polynomial + division
+__device__ __forceinline__ float act_silu(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.44269504088896341f)); }
+#else
+__device__ __forceinline__ float act_silu(float t) { return det_silu(t); }
+#endif
+
 template <int PRO, int RING>
 __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParams p)
 {
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         const int sc = s < p.nsteps ? s : p.nsteps - 1;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
+            if (FEMASR_WINO_ABL & 1) { rp[i] = make_float4(0.1f * sc, 0.2f, 0.3f, 0.4f); continue; }
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[i], sc * 32, 0);
             rp[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
@@ -172,20 +182,20 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (i == 2 && lane >= 34) continue;
+            if (FEMASR_WINO_ABL & 64) { asm volatile("" :: "v"(rp[i].x), "v"(rp[i].y), "v"(rp[i].z), "v"(rp[i].w)); continue; }
             float4 v = rp[i];
-            if (PRO == FEMASR_PRO_GN_SILU) {
+            if (PRO == FEMASR_PRO_GN_SILU && !(FEMASR_WINO_ABL & 32)) {
                 const int z = unit_z(i);
                 const float4 ga = ld4(ABs + z * 2 * p.Cin + s * 8 + 4 * quad), gb = ld4(ABs + z * 2 * p.Cin + p.Cin + s * 8 + 4 * quad);
-                v.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
-                v.y = det_silu(__builtin_fmaf(v.y, ga.y, gb.y));
-                v.z = det_silu(__builtin_fmaf(v.z, ga.z, gb.z));
-                v.w = det_silu(__builtin_fmaf(v.w, ga.w, gb.w));
+                v.x = act_silu(__builtin_fmaf(v.x, ga.x, gb.x));
+                v.y = act_silu(__builtin_fmaf(v.y, ga.y, gb.y));
+                v.z = act_silu(__builtin_fmaf(v.z, ga.z, gb.z));
+                v.w = act_silu(__builtin_fmaf(v.w, ga.w, gb.w));
             }
             if (!(pmask & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding AFTER the activation
             float *dst = Pb + unit_loff(i);
             *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
             *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
-            __builtin_amdgcn_sched_barrier(0);          // one unit at a time: the four SiLU chains of a unit already fill the VALU
         }
     };
 
@@ -195,6 +205,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     const int tsrc = (tm >> 4) * W4_PPIX * W4_PS + ((4 * ((tm & 15) >> 2) + thalf) * W4_PW + 4 * (tm & 3)) * W4_PS + tch;
     const int tdst = thalf * 18 * 256 + tm * 8 + (tch & 1) * 4 + (tch >> 1);
     auto transform = [&](int pbuf, int vbuf) {
+        if (FEMASR_WINO_ABL & 4) return;
         const float *src = Ps + pbuf * W4_PSZ + tsrc;
         float *dst = Vs + vbuf * W4_VSZ + tdst;
         float d[5][6];
@@ -237,6 +248,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     auto pntl = [&](int q) -> int { return q < 8 ? (q & 1) : (wave & 1); };
     auto ldU = [&](int s, int q) -> f32x4_t {       // unconditional, like load_patch
         const int sc = s < p.nsteps ? s : p.nsteps - 1;
+        if (FEMASR_WINO_ABL & 2) { f32x4_t c = {0.5f + sc, 0.25f, 0.125f, 1.0f}; return c; }
         const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, lw, (((sc * 36 + pcomp(q)) * p.NT32 + 2 * nb + pntl(q)) << 10), 0);
         return __builtin_bit_cast(f32x4_t, v);
     };
@@ -261,7 +273,10 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
             if ((q & 1) && q + 1 < 9) an = *reinterpret_cast<const f32x4_t *>(Vb + pcomp(q + 1) * 256);      // one A fragment per component
             const f32x4_t b = q < 3 ? ring[q] : (q < 6 ? early[q - 3] : late[q - 6]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                if (FEMASR_WINO_ABL & 8) { asm volatile("" :: "v"(a[e]), "v"(b[e])); continue; }
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
+            }
             if (q < 3) ring[q] = ldU(s + 1, q);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -295,10 +310,15 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     for (int hs = 0; hs < 2 * p.nsteps; ++hs) {
         const int s = hs >> 1;
         if (((hs & 1) ^ tfirst) == 0) {
+            // the MFMA stream of one wave can keep the SIMD busy by itself, and (measured) an older wave issuing back-to-back
+            // MFMAs starves its partner's VALU work: the M phase runs at low priority, the T phase (short VALU / LDS bursts
+            // between latencies) at high priority, so the MFMAs fill whatever the partner's T phase leaves free
+            __builtin_amdgcn_s_setprio(0);
             load_patch(s + 2 + tfirst);
             mphase(s);
             WTT(1)
         } else {
+            __builtin_amdgcn_s_setprio(3);
             if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);          // first: frees the staging registers ahead of the transform
             WTT(2)
             __builtin_amdgcn_sched_barrier(0);
@@ -397,8 +417,10 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         WTT(5)
         if (p.res1) fetch(p.res1, 1, r, rb1);
         if (p.res2) fetch(p.res2, 1, r, rb2);
-        item(0, r, bv, ra1, ra2);
-        item(1, r, bv, rb1, rb2);
+        if (!(FEMASR_WINO_ABL & 16)) {
+            item(0, r, bv, ra1, ra2);
+            item(1, r, bv, rb1, rb2);
+        }
         __syncthreads();
         WTT(6)
         if (gnp && t < 2 * gpt) {

@@ -1,9 +1,14 @@
 #!/bin/bash
-# Debug build of the Winograd conv kernel with per-phase cycle stamps (-DFEMASR_WINO_TT) -> tools/dbg/libfemasr_hip_tt.so
-# (python tools/bench_conv.py ... --wino with FEMASR_SO=tools/dbg/libfemasr_hip_tt.so prints the per-wave cycle shares)
+# Experiment builds of the Winograd conv kernel -> tools/dbg/libfemasr_hip_<tag>.so  (FEMASR_SO=... python tools/bench_conv.py ... --wino)
+#   tt       per-phase cycle stamps (-DFEMASR_WINO_TT): bench_conv prints the per-wave cycle shares
+#   fastact  hardware exp2 / rcp SiLU in the staging (-DFEMASR_WINO_FASTACT): what the exact SiLU costs
+#   ablN     -DFEMASR_WINO_ABL=N: parts of the kernel removed (bit list in kernels_wino.hip); results are garbage, timings only
 set -e
 cd "$(dirname "$0")/.."; mkdir -p tools/dbg
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result"
-/opt/rocm/bin/hipcc $F -DFEMASR_WINO_TT=1 -c femasr_amd/csrc/kernels_wino.hip -o tools/dbg/kernels_wino_tt.o
 O=femasr_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/dbg/libfemasr_hip_tt.so $O/kernels_conv.o $O/kernels_gemm.o $O/kernels_vq.o tools/dbg/kernels_wino_tt.o $O/kernels_conv_bf16.o $O/kernels_misc.o $O/model.o
+for tag in ${@:-tt fastact}; do
+  case $tag in tt) D="-DFEMASR_WINO_TT=1";; fastact) D="-DFEMASR_WINO_FASTACT=1";; abl*) D="-DFEMASR_WINO_ABL=${tag#abl}";; ttfast) D="-DFEMASR_WINO_TT=1 -DFEMASR_WINO_FASTACT=1";; *) D="$EXTRA_DEFS";; esac
+  /opt/rocm/bin/hipcc $F $D -c $O/kernels_wino.hip -o tools/dbg/kernels_wino_$tag.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/dbg/libfemasr_hip_$tag.so $O/kernels_conv.o $O/kernels_gemm.o $O/kernels_vq.o tools/dbg/kernels_wino_$tag.o $O/kernels_conv_bf16.o $O/kernels_misc.o $O/model.o
+done
