@@ -187,9 +187,12 @@ class FeMaSRNet(nn.Module):
         self.max_tile_batch = 16        # tiles per batched test() call inside test_tile
         self.num_streams = 1            # sub-batch streams inside one forward (femasr_set_streams)
         self._streams_set = None
-        # 'fp32': every layer exact fp32 (bit-identical to the oracle).  'bf16x3': the convs BEHIND the codebook lookup
-        # run on the bf16 matrix cores with a 3-term hi/lo split (output within the 1e-3 bound, indices unaffected)
-        self.decoder_math = 'fp32'
+        # 'fp32' (default): every layer fp32; the convs BEHIND the codebook lookup in the Winograd F(4x4,3x3) form, the SiLU of
+        #   their GroupNorm prologue on the hardware exp2 / rcp units (image within ~1e-5 of the oracle, VQ indices bit-exact)
+        # 'fp32_strict': the same with the IEEE-exact SiLU - bit-identical to the oracle (OracleNet())
+        # 'fp32_direct': every conv in the direct form - bit-identical to OracleNet(winograd=False)
+        # 'bf16x3': the convs behind the lookup on the bf16 matrix cores with a 3-term hi/lo split (within the 1e-3 bound)
+        self.decoder_math = ignore_kwargs.get('decoder_math', 'fp32')       # (an extension key of this build in `network_g`)
         # True: each (shape, mode) class is captured once into a hipGraph (torch.cuda.CUDAGraph around femasr_forward, which
         # is capture-safe: no allocation / synchronisation inside) and replayed; inputs are copied into the graph's static
         # buffer and the outputs are copies of its static outputs.  Only pays when the ~330 launches are host-bound (tiny
@@ -269,10 +272,10 @@ class FeMaSRNet(nn.Module):
             self._version_sum = sum(p_._version for p_ in self.parameters())
             self._weights_dirty = False
         if self._streams_set != (self._handle.value, self.num_streams, self.decoder_math):
-            if self.decoder_math not in ('fp32', 'bf16x3', 'fp32_direct'):
-                raise ValueError(f"decoder_math must be 'fp32', 'bf16x3' or 'fp32_direct', got {self.decoder_math!r}")
+            if self.decoder_math not in ('fp32', 'bf16x3', 'fp32_direct', 'fp32_strict'):
+                raise ValueError(f"decoder_math must be 'fp32', 'fp32_strict', 'fp32_direct' or 'bf16x3', got {self.decoder_math!r}")
             _lib.check(lib.femasr_set_streams(self._handle, int(self.num_streams)))
-            _lib.check(lib.femasr_set_decoder_math(self._handle, {'fp32': 0, 'bf16x3': 1, 'fp32_direct': 2}[self.decoder_math]))
+            _lib.check(lib.femasr_set_decoder_math(self._handle, {'fp32': 0, 'bf16x3': 1, 'fp32_direct': 2, 'fp32_strict': 3}[self.decoder_math]))
             self._streams_set = (self._handle.value, self.num_streams, self.decoder_math)
         return lib, self._handle
 

@@ -7,10 +7,11 @@
 // the result is bit-identical to that restatement (measured against the reference goldens: <= 6e-6 max-abs on outputs of
 // magnitude 2, 4.4e-5 on the +-49 un-scaled case - the same class as the direct form).
 //
-// What shapes the kernel (tools/ubench/coexec.hip, round 3): a VALU instruction of ANY wave on a SIMD takes its 2 cycles
-// out of that SIMD's fp32 MFMA time (v_mfma_f32_32x32x2_f32 runs on the vector lanes: 4 MFMA waves + 4 VALU waves take
-// exactly the SUM of the two alone), while LDS traffic and global loads overlap freely.  So: one MFMA stream per CU that
-// never waits for memory, as few VALU instructions as possible, and every latency hidden behind the partner wave.
+// What shapes the kernel (tools/ubench/coexec.hip, quantum.hip, round 3): v_mfma_f32_32x32x2_f32 runs on the vector lanes.
+// A VALU instruction of ANY wave on a SIMD takes its cycles out of that SIMD's fp32 MFMA time (4 MFMA waves + 4 VALU waves
+// take exactly the SUM of the two alone), and beside a wave that streams back-to-back MFMAs the partner's VALU work does not
+// advance at all.  Only LDS traffic and global loads overlap with MFMAs.  So: time = MFMA + VALU + exposed latency -
+// as few VALU instructions as possible, and every load issued a phase ahead of its use.
 //
 // Block = 8 waves (2 per SIMD), two 16x16-pixel sub-blocks (consecutive in (n, y, x) order; 2 x 16 Winograd tiles = ONE
 // 32-row MFMA tile) x 64 output channels.  K is walked in steps of 8 input channels; per step
@@ -21,7 +22,7 @@
 //   M phase   wave w owns 9 (component, 32-column tile) pairs - components 4w..4w+3 x both column tiles, and column tile w&1
 //             of component 32 + w/2: M += V_k[32 x 8] . U_k[8 x 32], 4 MFMAs per pair,
 //             U fragments stream from L2 through a register ring (1 KiB contiguous per wave load, issued one pair-group ahead)
-//   one barrier per step; waves 0-3 run M then T, waves 4-7 T then M, so each SIMD always has one wave in its MFMAs.
+//   one barrier per step; every wave runs M then T (VALU work cannot hide behind a partner's MFMAs, see the main loop).
 // Epilogue: accumulators -> LDS per 32-column tile; thread = (Winograd tile, channel) applies A^T M A, bias, residuals,
 // stores, and accumulates the fused GroupNorm partial moments (fp64) per 16x16 sub-block in the order of orc_gn_coeffs mode 2.
 #include "conv_common.h"
@@ -102,13 +103,18 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 #ifndef FEMASR_WINO_ABL      // ablation experiments (tools/build_debug.sh): bit 0 no patch loads, 1 no U loads, 2 no transform, 3 no MFMAs,
 #define FEMASR_WINO_ABL 0    // 4 no output items, 5 no activation, 6 no staging stores
 #endif
-#ifdef FEMASR_WINO_FASTACT      // experiment: hardware exp2 / rcp (1 ulp each) instead of the IEEE-exact polynomial + division
-__device__ __forceinline__ float act_silu(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.44269504088896341f)); }
-#else
-__device__ __forceinline__ float act_silu(float t) { return det_silu(t); }
-#endif
+// SiLU of the staged input.  FAST: x * rcp(1 + exp2(-x log2 e)) on the hardware transcendental units (v_exp_f32 / v_rcp_f32,
+// 1 ulp each; 5 VALU instructions instead of ~28) - the default of the model: these convs sit behind the codebook lookup, the
+// result stays within ~1e-6 relative of the exact form.  !FAST: the IEEE-exact polynomial + division of detmath.h, bit-identical
+// to the oracle (decoder_math 'fp32_strict').
+template <bool FAST>
+__device__ __forceinline__ float act_silu(float t)
+{
+    if (FAST) return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.44269504088896341f));
+    return det_silu(t);
+}
 
-template <int PRO, int RING>
+template <int PRO, bool FAST>
 __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParams p)
 {
         extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -187,10 +193,10 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
             if (PRO == FEMASR_PRO_GN_SILU && !(FEMASR_WINO_ABL & 32)) {
                 const int z = unit_z(i);
                 const float4 ga = ld4(ABs + z * 2 * p.Cin + s * 8 + 4 * quad), gb = ld4(ABs + z * 2 * p.Cin + p.Cin + s * 8 + 4 * quad);
-                v.x = act_silu(__builtin_fmaf(v.x, ga.x, gb.x));
-                v.y = act_silu(__builtin_fmaf(v.y, ga.y, gb.y));
-                v.z = act_silu(__builtin_fmaf(v.z, ga.z, gb.z));
-                v.w = act_silu(__builtin_fmaf(v.w, ga.w, gb.w));
+                v.x = act_silu<FAST>(__builtin_fmaf(v.x, ga.x, gb.x));
+                v.y = act_silu<FAST>(__builtin_fmaf(v.y, ga.y, gb.y));
+                v.z = act_silu<FAST>(__builtin_fmaf(v.z, ga.z, gb.z));
+                v.w = act_silu<FAST>(__builtin_fmaf(v.w, ga.w, gb.w));
             }
             if (!(pmask & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding AFTER the activation
             float *dst = Pb + unit_loff(i);
@@ -204,22 +210,25 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     const int tm = (wave >> 1) * 8 + (lane >> 3), tch = lane & 7;
     const int tsrc = (tm >> 4) * W4_PPIX * W4_PS + ((4 * ((tm & 15) >> 2) + thalf) * W4_PW + 4 * (tm & 3)) * W4_PS + tch;
     const int tdst = thalf * 18 * 256 + tm * 8 + (tch & 1) * 4 + (tch >> 1);
-    auto transform = [&](int pbuf, int vbuf) {
+    float td[5][6];                                        // the transform item's 5 x 6 patch values (rows 3*thalf.. of the 6x6 patch)
+    auto transform_read = [&](int pbuf) {
         if (FEMASR_WINO_ABL & 4) return;
         const float *src = Ps + pbuf * W4_PSZ + tsrc;
-        float *dst = Vs + vbuf * W4_VSZ + tdst;
-        float d[5][6];
 #pragma unroll
         for (int a = 0; a < 5; ++a)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) d[a][b] = src[(a * W4_PW + b) * W4_PS];
+            for (int b = 0; b < 6; ++b) td[a][b] = src[(a * W4_PW + b) * W4_PS];
+    };
+    auto transform_write = [&](int vbuf) {
+        if (FEMASR_WINO_ABL & 4) return;
+        float *dst = Vs + vbuf * W4_VSZ + tdst;
         float r[3][6];
         if (thalf == 0) {
 #pragma unroll
-            for (int b = 0; b < 6; ++b) bt_lo(d[0][b], d[1][b], d[2][b], d[3][b], d[4][b], r[0][b], r[1][b], r[2][b]);
+            for (int b = 0; b < 6; ++b) bt_lo(td[0][b], td[1][b], td[2][b], td[3][b], td[4][b], r[0][b], r[1][b], r[2][b]);
         } else {
 #pragma unroll
-            for (int b = 0; b < 6; ++b) bt_hi(d[0][b], d[1][b], d[2][b], d[3][b], d[4][b], r[0][b], r[1][b], r[2][b]);
+            for (int b = 0; b < 6; ++b) bt_hi(td[0][b], td[1][b], td[2][b], td[3][b], td[4][b], r[0][b], r[1][b], r[2][b]);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -278,6 +287,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
             }
             if (q < 3) ring[q] = ldU(s + 1, q);
+            if (q == 5) load_patch(s + 2);          // into the registers the early fragments just left; 3 pairs + the transform ahead of its use
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -297,37 +307,42 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     store_patch(0, 0);
     load_patch(1);
     __syncthreads();
-    transform(0, 0);
+    transform_read(0);
+    transform_write(0);
     if (1 < p.nsteps) store_patch(1, 1);
-    const int tfirst = wave >> 2;
-    if (tfirst) load_patch(2);
-    else issue_early(0);
+    issue_early(0);
     __syncthreads();
     WTT(0)
 
-    // ---- main loop over half-steps: waves 0-3 run M(s) T(s), waves 4-7 T(s) M(s); the patch of step s+2 is loaded right
-    //      before the wave's M phase and stored by its next T phase
-    for (int hs = 0; hs < 2 * p.nsteps; ++hs) {
-        const int s = hs >> 1;
-        if (((hs & 1) ^ tfirst) == 0) {
-            // the MFMA stream of one wave can keep the SIMD busy by itself, and (measured) an older wave issuing back-to-back
-            // MFMAs starves its partner's VALU work: the M phase runs at low priority, the T phase (short VALU / LDS bursts
-            // between latencies) at high priority, so the MFMAs fill whatever the partner's T phase leaves free
-            __builtin_amdgcn_s_setprio(0);
-            load_patch(s + 2 + tfirst);
-            mphase(s);
-            WTT(1)
+    // ---- main loop.  Measured (tools/ubench/quantum.hip): while one wave of a SIMD streams back-to-back fp32 MFMAs, its
+    // partner's VALU instructions do not issue at all (whatever s_setprio says) - the MFMA stream owns the vector lanes.
+    // VALU work therefore never hides behind another wave's MFMAs; only memory latency does.  So all waves run the same
+    // order: M(s) with every load of the following phases in flight, then the VALU work T(s), one barrier per step.
+    for (int s = 0; s < p.nsteps; ++s) {
+        // the lean (hardware SiLU / no prologue) variants fetch the next transform's patch values right behind the last MFMA
+        // issue (the U registers are free again): the LDS latency runs under the tail of the MFMA pipeline
+        constexpr bool HOIST = FAST || PRO == FEMASR_PRO_NONE;
+        mphase(s);
+        if (HOIST) transform_read((s + 1) & 1);       // (unconditional: after the last step it transforms a stale patch into a dead buffer)
+        __builtin_amdgcn_sched_barrier(0);
+        WTT(1)
+        if (HOIST) {
+            transform_write((s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);
+            WTT(2)
         } else {
-            __builtin_amdgcn_s_setprio(3);
             if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);          // first: frees the staging registers ahead of the transform
             WTT(2)
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < p.nsteps) transform((s + 1) & 1, (s + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_early(s + 1 - tfirst);        // waves 0-3: in flight across the barrier; waves 4-7: right ahead of their M phase
-            WTT(3)
+            transform_read((s + 1) & 1);
+            transform_write((s + 1) & 1);
         }
-        if (hs & 1) { __syncthreads(); WTT(4) }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_early(s + 1);                                       // in flight across the barrier
+        WTT(3)
+        __syncthreads();
+        WTT(4)
     }
 
     // ---------------------------------------------------------------------------------------------------------------
@@ -489,10 +504,11 @@ struct WVariant {
     unsigned long long attr_devs;
     size_t attr_lds;
 };
-#define FEMASR_WINO(PRO, RING) { "conv3x3_wino4<2x16x16px x64," #PRO ",ring" #RING ",waves=8>", conv3x3_wino4_kernel<PRO, RING>, 0ull, 0 }
+#define FEMASR_WINO(PRO, FAST) { "conv3x3_wino4<2x16x16px x64," #PRO "," #FAST ",waves=8>", conv3x3_wino4_kernel<PRO, FAST>, 0ull, 0 }
 WVariant g_wv[] = {
-    FEMASR_WINO(FEMASR_PRO_NONE, 3),
-    FEMASR_WINO(FEMASR_PRO_GN_SILU, 3),
+    FEMASR_WINO(FEMASR_PRO_NONE, false),
+    FEMASR_WINO(FEMASR_PRO_GN_SILU, false),       // exact SiLU
+    FEMASR_WINO(FEMASR_PRO_GN_SILU, true),        // hardware exp2 / rcp SiLU
 };
 constexpr int kNumW = sizeof(g_wv) / sizeof(g_wv[0]);
 
@@ -528,7 +544,7 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
     p.NB = a->Cout / 64;
     p.nsteps = a->Cin / 8;
     p.NT32 = a->Cout / 32;
-    const int vi = gn ? 1 : 0;
+    const int vi = gn ? (a->fast_act ? 2 : 1) : 0;
     WVariant &v = g_wv[vi];
     const size_t lds = wino_lds_bytes(a->Cin, gn);
     int dev = 0;

@@ -370,8 +370,9 @@ struct Ctx {
         }
         const bool lowp_on = split != nullptr && cout > 4 && femasr_conv_bf16x3_shape_ok(&a);      // out_conv: exact VALU kernel in both modes
         // exact-fp32 mode: convs behind the codebook lookup of a single-codebook network run in the Winograd F(4x4,3x3) form
-        // (they cannot move a VQ index; oracle: OracleNet.wino).  decoder_math 2 = 'fp32_direct' keeps the direct form.
-        const bool wino_on = !lowp_on && o.lowp && h->decoder_math == 0 && h->cfg.n_codebooks == 1 && femasr_conv_wino_shape_ok(&a);
+        // (they cannot move a VQ index; oracle: OracleNet.wino).  decoder_math 2 = 'fp32_direct' keeps the direct form; 0 runs the
+        // SiLU of their GroupNorm prologue on the hardware exp2 / rcp units, 3 = 'fp32_strict' keeps it IEEE-exact (== oracle).
+        const bool wino_on = !lowp_on && o.lowp && (h->decoder_math == 0 || h->decoder_math == 3) && h->cfg.n_codebooks == 1 && femasr_conv_wino_shape_ok(&a);
         const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
                                    : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
         if (o.want_gn && gn_ok) {
@@ -404,6 +405,7 @@ struct Ctx {
             variant += femasr_conv_variant_count();
         } else if (wino_w) {
             a.w_wino = wino_w;
+            a.fast_act = h->decoder_math == 0 ? 1 : 0;
             r = femasr_conv_wino_launch(s(), &a, &variant, &flops);
             variant += femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count();
         } else {
@@ -1101,7 +1103,7 @@ int femasr_decode_indices(femasr_handle *h, void *stream, const int64_t *indices
 
 int femasr_set_decoder_math(femasr_handle *h, int mode)
 {
-    FEMASR_REQUIRE(h && mode >= 0 && mode <= 2, "set_decoder_math: mode must be 0 (fp32), 1 (bf16x3) or 2 (fp32, direct convs only)");
+    FEMASR_REQUIRE(h && mode >= 0 && mode <= 3, "set_decoder_math: mode must be 0 (fp32), 1 (bf16x3), 2 (fp32, direct convs only) or 3 (fp32, exact SiLU)");
     if (h->decoder_math != mode) h->plans.clear();
     h->decoder_math = mode;
     return FEMASR_OK;

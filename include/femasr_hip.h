@@ -164,10 +164,15 @@ typedef struct {
                              2x2-tap filters on the low-resolution input (REQUIRED for that shape; other up2 shapes
                              read the upsampled image through `w`). */
     const float *w_wino;  /* optional: femasr_repack_oihw_wino weights.  When non-NULL the layer (3x3 stride-1 pad-1, no
-                             x2, Cin % 32 == 0, Cout % 64 == 0, no GELU) runs in the Winograd F(2x2,3x3) form: fp32
-                             throughout, 2.25x fewer multiplies, results within fp32 rounding (~1e-6 relative) of the
+                             x2, Cin % 32 == 0, Cout % 64 == 0, no GELU) runs in the Winograd F(4x4,3x3) form: fp32
+                             throughout, 4x fewer multiplies, results within fp32 rounding (~1e-5 relative at worst) of the
                              direct form and bit-identical to oracle/femasr_oracle.c orc_conv3x3_winograd.  The model uses
-                             it for the convs behind the codebook lookup only (they cannot move a VQ index). */
+                             it for the convs behind the codebook lookup only (they cannot move a VQ index).  With gn_part the
+                             partials are per 16x16-pixel sub-block: [B][ceil(H/16)*ceil(W/16)][32][2] (orc_gn_coeffs mode 2). */
+    int32_t fast_act;     /* Winograd convs with the GN+SiLU prologue only: 1 = SiLU through the hardware exp2 / rcp units
+                             (v_exp_f32, v_rcp_f32: 1 ulp each) instead of the IEEE-exact polynomial + division - ~6x fewer
+                             VALU instructions in the staging; output within ~1e-6 relative of the exact form (no longer
+                             bit-identical to the oracle).  0 = exact. */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 
@@ -241,8 +246,9 @@ int femasr_repack_oihw(void *stream, const float *in, int O, int I, int kh, int 
  * {x-1+b, x+b}; slot weights are the fp32 sums of the taps that land on the same input pixel (rows summed over kx first,
  * ascending; then over ky, ascending).  out: femasr_up2_weight_floats(O, I) floats = 4 x femasr_packed_weight_floats(O,I,2,2). */
 size_t femasr_up2_weight_floats(int O, int I);
-/* 3x3 OIHW -> femasr_conv_args.w_wino: U = G g G^T per (o, i) with rows then columns, u1 = ((g0 + g1) + g2) * 0.5,
- * u2 = ((g0 - g1) + g2) * 0.5, packed like a 4x4-tap conv.  out: femasr_wino_weight_floats(O, I) floats. */
+/* 3x3 OIHW -> femasr_conv_args.w_wino: U = G g G^T (6x6 per (o, i)) of F(4x4,3x3), down the columns then along the rows in
+ * the operation order of oracle/femasr_oracle.c orc_g6, stored [Cin/8][36 components][Cout/32][lane][4] (the MFMA B fragments
+ * of one 8-channel step: 1 KiB per wave load).  out: femasr_wino_weight_floats(O, I) floats = 36 * I * 32*ceil(O/32). */
 size_t femasr_wino_weight_floats(int O, int I);
 int femasr_repack_oihw_wino(void *stream, const float *in, int O, int I, float *out);
 int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *out);
@@ -250,12 +256,15 @@ int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *o
 /* Split-bf16 (hi/lo) fragment-major weights for the opt-in bf16x3 conv path (3x3 convs behind the VQ lookup). */
 size_t femasr_packed_weight_bf16x3_bytes(int O, int I, int kh, int kw);
 int femasr_repack_oihw_bf16x3(void *stream, const float *in, int O, int I, int kh, int kw, void *out);
-/* 0 (default): every layer fp32, bit-identical to the oracle; in single-codebook networks the 3x3 convs that do NOT feed the
- * codebook lookup (after_quant, DecoderBlocks, the LQ encoder's two up-blocks) run in the Winograd F(2x2,3x3) form (2.25x
- * fewer multiplies, same fp32 accuracy against the reference, VQ indices unaffected).
+/* 0 (default, 'fp32'): every layer fp32; in single-codebook networks the 3x3 convs that do NOT feed the codebook lookup
+ *    (after_quant, DecoderBlocks, the LQ encoder's two up-blocks) run in the Winograd F(4x4,3x3) form (4x fewer multiplies)
+ *    with the GroupNorm+SiLU prologue on the hardware exp2 / rcp units (femasr_conv_args.fast_act): same fp32 accuracy against
+ *    the reference (~1e-5), VQ indices bit-exact (everything that feeds a lookup stays in the exact direct form), the image
+ *    within ~1e-5 of the oracle.
+ * 3 ('fp32_strict'): the same with the IEEE-exact SiLU: bit-identical to the oracle (OracleNet()).
  * 1: those convs (and the x2 convs) use the bf16x3 path instead: output within the north-star 1e-3 bound of the fp32 result
  *    (measured ~1e-4).
- * 2: fp32 with every conv in the direct form (the round-1 arithmetic; oracle: OracleNet(winograd=False)). */
+ * 2 ('fp32_direct'): fp32 with every conv in the direct form, bit-identical to OracleNet(winograd=False). */
 int femasr_set_decoder_math(femasr_handle *h, int mode);
 
 /* ---- image pre / post-processing (the steps either side of the path) ---- */

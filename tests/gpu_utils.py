@@ -41,7 +41,7 @@ def lib_weight_layout(w_khwc):
 
 
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
-           res1=None, res2=None, bf16x3=False, gn_part=False, wino=False):
+           res1=None, res2=None, bf16x3=False, gn_part=False, wino=False, fast_act=False):
     """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout)."""
     lib = _lib.load()
     cout = np.asarray(w_khwc).shape[-1]
@@ -84,6 +84,7 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     a.w_bf16x3 = None if wsplit is None else wsplit.data_ptr()
     a.w_up2 = None if wup2 is None else wup2.data_ptr()
     a.w_wino = None if wwino is None else wwino.data_ptr()
+    a.fast_act = int(bool(fast_act))
     part = None
     if gn_part:
         tiles = ((ho + 7) // 8) * ((wo + 15) // 16)
@@ -197,10 +198,14 @@ def vq_candidates(z_rows, codebook):
     return cand.cpu().numpy().view('uint16'), cnt.cpu().numpy().view('uint16')
 
 
-def build_net(cfg_name, weights, device='cuda'):
+def build_net(cfg_name, weights, device='cuda', decoder_math='fp32_strict'):
+    """decoder_math defaults to 'fp32_strict' HERE (the tests' bit-exact comparisons with the oracle): the product default
+    'fp32' runs the SiLU of the Winograd convs on the hardware exp2 / rcp units and is compared with a tolerance instead
+    (test_gpu_network.py::test_default_mode_vs_oracle_and_reference)."""
     from femasr_amd.archs import build_network
     from helpers import CONFIGS
     net = build_network(dict(type='FeMaSRNet', **CONFIGS[cfg_name]))
     missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=False)
     assert not missing.unexpected_keys
+    net.decoder_math = decoder_math
     return net.to(device).eval()

@@ -187,15 +187,15 @@ def _net_cases(seed, n):
         else:                                        # test(): any size the mirror pad accepts
             h, w = int(rng.randint(16, 57)), int(rng.randint(16, 57))
         out.append(dict(id=i, cfg=cfg, b=int(rng.randint(1, 4)), h=h, w=w, streams=int(rng.choice([1, 2, 3])),
-                        math=str(rng.choice(['fp32', 'bf16x3']))))
+                        math=str(rng.choice(['fp32_strict', 'fp32', 'bf16x3']))))
     return out
 
 
 @pytest.mark.parametrize('c', _net_cases(4242, 8 * _MULT), ids=lambda c: 'n%(id)d_%(cfg)s_%(b)dx%(h)dx%(w)d_s%(streams)d_%(math)s' % c)
 def test_fuzz_network_vs_oracle(cuda_device, c):
-    """Whole network at random small sizes / batch / stream count / math mode: fp32 mode bit-exact against the oracle
-    (output and VQ indices), bf16x3 mode identical indices and <= 1e-3 (workspace planner, stream fork/join, ragged
-    tiles in every layer)."""
+    """Whole network at random small sizes / batch / stream count / math mode: fp32_strict bit-exact against the oracle
+    (output and VQ indices); the default fp32 mode (hardware exp2 / rcp SiLU in the Winograd convs) identical indices and
+    <= 1e-4; bf16x3 identical indices and <= 1e-3 (workspace planner, stream fork/join, ragged tiles in every layer)."""
     import gpu_utils as G
     import torch
     from helpers import oracle_net, synth_weights
@@ -214,10 +214,10 @@ def test_fuzz_network_vs_oracle(cuda_device, c):
         y, idx = y.cpu().numpy(), idx.cpu().numpy()
         yo, io = onet.test(x, return_indices=True)
     assert np.array_equal(idx.reshape(-1), np.asarray(io).reshape(-1)), 'VQ indices differ from the oracle'
-    if c['math'] == 'fp32':
+    if c['math'] == 'fp32_strict':
         assert np.array_equal(y, yo), f'not bit-identical: max-abs {np.abs(y - yo).max():.3e}'
     else:
-        assert float(np.abs(y - yo).max()) < 1e-3
+        assert float(np.abs(y - yo).max()) < (1e-4 if c['math'] == 'fp32' else 1e-3)
 
 
 @pytest.mark.parametrize('seed', range(8 * _MULT))

@@ -322,6 +322,34 @@ def test_conv_winograd_bit_exact(cuda_device, cin, cout, shape, gn, nres, part):
         _same(bb, b_ref, 'fused gn b (winograd)')
 
 
+@pytest.mark.parametrize('cin,cout,shape,nres', [(64, 128, (2, 16, 32), 1), (128, 64, (1, 13, 21), 2), (256, 256, (1, 20, 9), 0)])
+def test_conv_winograd_fast_act_close(cuda_device, cin, cout, shape, nres):
+    """The model's default for the convs behind the codebook lookup: Winograd form with the SiLU of the GroupNorm prologue on the
+    hardware exp2 / rcp units (femasr_conv_args.fast_act).  Not bit-identical to the oracle by construction (v_exp_f32 / v_rcp_f32
+    are 1-ulp approximations): within 1e-5 of the output scale of the exact kernel (the same class as the rounding noise of the F(4x4) transforms, which amplify a 1-ulp input change ~10x), and the fused GroupNorm coefficients of the
+    output within 1e-5 relative."""
+    import gpu_utils as G
+    b, h, w = shape
+    x = synth.uniform(23, 'fax', (b, h, w, cin), -3.0, 3.0)
+    wt = synth.uniform(23, 'faw', (3, 3, cin, cout), -0.1, 0.1)
+    bias = synth.uniform(23, 'fab', (cout,), -0.5, 0.5)
+    res = [synth.uniform(23, f'far{k}', (b, h, w, cout), -1, 1) for k in range(nres)]
+    r1, r2 = (res + [None, None])[:2]
+    ga = synth.uniform(23, 'faga', (b, cin), 0.5, 1.5)
+    gb = synth.uniform(23, 'fagb', (b, cin), -0.5, 0.5)
+    kw = dict(prologue=_lib.PRO_GN_SILU, pro=(ga, gb, None), res1=r1, res2=r2, wino=True, gn_part=True)
+    y_exact, p_exact = G.conv2d(x, wt, bias, 3, 1, 1, **kw)
+    y_fast, p_fast = G.conv2d(x, wt, bias, 3, 1, 1, fast_act=True, **kw)
+    scale = max(1.0, float(np.abs(y_exact).max()))
+    err = float(np.abs(y_fast - y_exact).max())
+    assert 0.0 < err <= 1e-5 * scale, (err, scale)
+    gamma = synth.uniform(23, 'fagg', (cout,), 0.5, 1.5)
+    beta = synth.uniform(23, 'fagbe', (cout,), -0.5, 0.5)
+    a0, b0 = G.gn_coeffs_from_partials(p_exact, h, w, cout, gamma, beta)
+    a1, b1 = G.gn_coeffs_from_partials(p_fast, h, w, cout, gamma, beta)
+    assert np.abs(a1 - a0).max() <= 1e-5 * np.abs(a0).max() and np.abs(b1 - b0).max() <= 1e-5 * max(1.0, np.abs(b0).max())
+
+
 def test_repack_oihw_layout(cuda_device):
     """femasr_repack_oihw (what set_weight runs) == the documented K-major layout."""
     import gpu_utils as G

@@ -37,7 +37,7 @@ def test_test_pipeline_end_to_end(cuda_device, tmp_path):
                datasets=dict(val=dict(name='tiny', type='PairedImageDataset', dataroot_lq=str(lq), dataroot_gt=str(gt),
                                       io_backend=dict(type='disk'))),
                network_g=dict(type='FeMaSRNet', gt_resolution=256, norm_type='gn', act_type='silu', scale_factor=4,
-                              codebook_params=[[32, 1024, 512]], LQ_stage=True,
+                              codebook_params=[[32, 1024, 512]], LQ_stage=True, decoder_math='fp32_strict',     # bit-exact PNGs below
                               frozen_module_keywords=['quantize', 'decoder', 'after_quant_group', 'out_conv']),
                path=dict(pretrain_network_g=str(ckpt), strict_load=False),
                val=dict(save_img=True, suffix=None,

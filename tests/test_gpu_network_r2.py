@@ -23,6 +23,7 @@ def _net(cfg, w):
     from femasr_amd.archs import build_network
     net = build_network(dict(type='FeMaSRNet', **cfg))
     net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    net.decoder_math = 'fp32_strict'        # the bit-exact comparisons below; the default mode is covered by test_gpu_network.py
     return net.cuda().eval()
 
 
