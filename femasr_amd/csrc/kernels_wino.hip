@@ -287,7 +287,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
             }
             if (q < 3) ring[q] = ldU(s + 1, q);
-            if (q == 5) load_patch(s + 2);          // into the registers the early fragments just left; 3 pairs + the transform ahead of its use
+            if (q == 5) load_patch(s + 2);           // into the registers the early fragments just left; 3 pairs + the transform ahead of its use
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -315,13 +315,12 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     WTT(0)
 
     // ---- main loop.  Measured (tools/ubench/quantum.hip): while one wave of a SIMD streams back-to-back fp32 MFMAs, its
-    // partner's VALU instructions do not issue at all (whatever s_setprio says) - the MFMA stream owns the vector lanes.
-    // VALU work therefore never hides behind another wave's MFMAs; only memory latency does.  So all waves run the same
-    // order: M(s) with every load of the following phases in flight, then the VALU work T(s), one barrier per step.
-    for (int s = 0; s < p.nsteps; ++s) {
-        // the lean (hardware SiLU / no prologue) variants fetch the next transform's patch values right behind the last MFMA
-        // issue (the U registers are free again): the LDS latency runs under the tail of the MFMA pipeline
-        constexpr bool HOIST = FAST || PRO == FEMASR_PRO_NONE;
+    // partner's VALU instructions do not issue at all (neither wave age nor s_setprio changes that) - the MFMA stream owns
+    // the vector lanes.  VALU work therefore never hides behind another wave's MFMAs; time = MFMA + VALU + exposed latency.
+    // A staggered order (waves 0-3 M then T, waves 4-7 T then M, with an s_sleep after every MFMA group so that the partner's
+    // VALU advances in the gap) was built and measured 3-5 % SLOWER than this plain order: every wave M(s), then T(s).
+    constexpr bool HOIST = FAST || PRO == FEMASR_PRO_NONE;       // the lean variants have the registers to read the next transform's
+    for (int s = 0; s < p.nsteps; ++s) {                         // patch values right behind the last MFMA issue
         mphase(s);
         if (HOIST) transform_read((s + 1) & 1);       // (unconditional: after the last step it transforms a stale patch into a dead buffer)
         __builtin_amdgcn_sched_barrier(0);
