@@ -11,7 +11,7 @@ A step = one pass of the hot path over one batch of synthetic input already resi
       256 tiles sharded over the ranks, all-gather + paste into the 8192x8192 canvas INSIDE the timed region.
       STRONG scaling (total work fixed).
 
-The arithmetic of record is exact fp32 (`decoder_math='fp32'`: every layer on v_mfma_f32_32x32x2_f32, bit-identical
+The arithmetic of record is fp32 (`decoder_math='fp32'`: every layer on v_mfma_f32_32x32x2_f32; `fp32_strict` is bit-identical
 to the CPU oracle, `dtype: "f32"`).  The split-bf16 mode (3-pass hi/lo products for the convs that do not feed the
 VQ argmin; within the 1e-3 bound but narrower products than fp32) is timed in the same run and reported under the
 secondary key `bf16x3_mode` — never as `value`.
@@ -56,9 +56,9 @@ def rocprof_kernel_name(bench_name):
     m = re.match(r'conv_igemm<(\d+)x(\d+),(\w+),cinvec=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
         return f'conv_igemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(5)}, {m.group(6)}, {pro[m.group(3)]}, {m.group(4)}>'
-    m = re.match(r'conv3x3_wino<8x16x(\d)\*32,(\w+),waves=8>', bench_name)
+    m = re.match(r'conv3x3_wino4<2x16x16px x64,(\w+),(\w+),waves=8>', bench_name)
     if m:
-        return f'conv3x3_wino_kernel<{m.group(1)}, {pro[m.group(2)]}>'
+        return f'conv3x3_wino4_kernel<{pro[m.group(1)]}, {m.group(2)}>'
     m = re.match(r'gemm_dma<128x128x(\d)\*8,stages=(\d),act=(\d),nres=(\d),vq=(\w+)>', bench_name)
     if m:
         return f'gemm_dma_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>'
@@ -122,17 +122,18 @@ def physical_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', choices=['tiles16', 'tile2048'], default='tiles16')
     ap.add_argument('--batch', type=int, default=16, help='128x128 LR tiles per GPU per step (tiles16) / per batched test() call (tile2048)')
     ap.add_argument('--image', type=int, default=2048, help='tile2048: LR image side')
     ap.add_argument('--streams', type=int, default=2, help='sub-batch streams inside one forward (femasr_set_streams)')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra serialized steps (streams=1) for the roofline object')
-    ap.add_argument('--decoder-math', choices=['fp32', 'bf16x3', 'fp32_direct'], default='fp32',
-                    help="'fp32' (bench of record): every layer fp32, bit-identical to the oracle; the 3x3 convs behind the VQ lookup in the "
-                         "Winograd F(2x2,3x3) form.  'fp32_direct': the same with every conv in the direct form.  'bf16x3': convs behind the VQ lookup on the bf16 "
-                         'matrix cores (3-term split, within 1e-3) - a secondary mode, reported as such')
+    ap.add_argument('--decoder-math', choices=['fp32', 'fp32_strict', 'bf16x3', 'fp32_direct'], default='fp32',
+                    help="'fp32' (bench of record, the product default): every layer fp32; the 3x3 convs behind the VQ lookup in the Winograd "
+                         "F(4x4,3x3) form with the SiLU of their GroupNorm prologue on the hardware exp2 / rcp units.  'fp32_strict': the same with "
+                         "the IEEE-exact SiLU (bit-identical to the oracle).  'fp32_direct': every conv in the direct form.  'bf16x3': convs behind "
+                         'the VQ lookup on the bf16 matrix cores (3-term split, within 1e-3) - a secondary mode, reported as such')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default=None)
     ap.add_argument('--dry-net', action='store_true', help='CPU stand-in network (launch-path test; no GPU work, not a measurement)')
     ap.add_argument('--no-gather', action='store_true', help='tiles16, N>1: skip the all-gather of upscaled tiles')
@@ -213,6 +214,7 @@ def main():
         do_gather = world > 1
         img = torch.from_numpy(synth.synth_input(2000, (1, 3, S, S))).to(dev)    # replicated LR image (48 MB at 2048^2)
         net.max_tile_batch = B
+        net.time_split = not dry
 
         def step():
             return fd.test_tile_parallel(net, img, 128, 0)       # partition -> batched test() -> ONE all-gather -> paste
@@ -230,38 +232,82 @@ def main():
             dist.barrier()
         sync()
 
+    def clock_probe():
+        """Clock the chip sustains under back-to-back fp32 MFMAs right now (femasr_clock_probe: ticks of s_memtime / wall time)."""
+        if dry:
+            return None
+        from femasr_amd import _lib
+        lib = _lib.load()
+        nb = 256 * 4
+        ticks = torch.zeros(nb, dtype=torch.int64, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream(dev)
+        _lib.check(lib.femasr_clock_probe(st.cuda_stream, 4000, _lib.ptr(ticks)))        # warm
+        e0.record(st)
+        _lib.check(lib.femasr_clock_probe(st.cuda_stream, 40000, _lib.ptr(ticks)))       # ~1.1 ms of MFMAs per wave
+        e1.record(st)
+        sync()
+        return round(float(ticks.double().mean().item()) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 3)
+
     for _ in range(args.warmup):
         step()
     fence()
+    clk_before = clock_probe()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if not dry else None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if step_ev:
+        step_ev[0].record(torch.cuda.current_stream(dev))
+    for i in range(args.steps):
         y = step()
+        if step_ev:
+            step_ev[i + 1].record(torch.cuda.current_stream(dev))
     fence()
     dt = time.perf_counter() - t0
+    dt_rank = dt
+    clk_after = clock_probe()
+    per_rank_ms = [round(dt / args.steps * 1e3, 3)]
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tall = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([dt], dtype=torch.float64, device=dev))
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in tall]
+        dt = max(float(t.item()) for t in tall)                 # the MAX over ranks is the job's time
     assert torch.isfinite(y).all()
+    step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)] if step_ev else []
 
     value = out_mpix * args.steps / dt
     res = {
         'metric': 'SR output megapixels/sec at x4 (128->512)', 'value': round(value, 4), 'unit': 'MPix/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
-        'dtype': 'f32' if args.decoder_math in ('fp32', 'fp32_direct') else 'f32 + bf16x3 split (secondary mode, not the bench of record)',
+        'dtype': 'f32' if args.decoder_math in ('fp32', 'fp32_strict', 'fp32_direct') else 'f32 + bf16x3 split (secondary mode, not the bench of record)',
         'data': 'synthetic' if not dry else 'dry-net stand-in on CPU (launch-path check, NOT a measurement)',
         'config': {'workload': workload, 'workload_name': args.workload,
                    'global_batch': units_per_step, 'tile': '128x128->512x512', 'parallelism': f'tile-parallel x{world}',
                    'backend': ('RCCL (torch.distributed nccl)' if backend == 'nccl' else backend) if use_pg else 'none (single process)',
                    'gather': bool(do_gather), 'streams': args.streams, 'decoder_math': args.decoder_math,
                    'algorithmic_gflop_per_tile': TILE_GFLOP,
-                   'end_to_end_tflops': None if dry else round(TILE_GFLOP * units_per_step * args.steps / dt / 1e3, 2),
-                   'fp32_mfma_ceiling_mpix_s_per_gpu': round(0.262144 / (TILE_GFLOP / (PEAK_FP32_MFMA_TFLOPS * 1e3)), 2),
-                   'ceiling_note': ('ceiling = the layer DEFINITIONS\' flops (964.47 GFLOP per tile, direct form) at the fp32 MFMA peak; the '
-                                    'default fp32 mode issues ~577 of them (Winograd F(2x2,3x3) behind the VQ lookup, phase-filter x2 '
-                                    'convs), so end_to_end_tflops counts algorithmic, not issued, flops')},
+                   'end_to_end_algorithmic_tflops': None if dry else round(TILE_GFLOP * units_per_step * args.steps / dt / 1e3, 2),
+                   'flops_note': ('algorithmic = the layer DEFINITIONS (964.47 GFLOP per tile, direct form); the default fp32 mode ISSUES far '
+                                  'fewer (Winograd F(4x4,3x3) behind the VQ lookup: 1/4; phase-filter x2 convs: 4/9) - the issued figure and '
+                                  'the physical MFMA fraction are in `roofline`')},
+        'timed_region': {'per_rank_ms_per_step': per_rank_ms, 'world_size': world,
+                         'rccl_version': ('.'.join(map(str, torch.cuda.nccl.version())) if (use_pg and backend == 'nccl') else None),
+                         'step_ms_first_median_last': ([round(step_ms[0], 2), round(sorted(step_ms)[len(step_ms) // 2], 2), round(step_ms[-1], 2)]
+                                                       if step_ms else None),
+                         'step_ms_min_max': [round(min(step_ms), 2), round(max(step_ms), 2)] if step_ms else None,
+                         'mfma_clock_ghz_before_after': [clk_before, clk_after],
+                         'clock_note': ('clock the chip sustains under back-to-back fp32 MFMAs (femasr_clock_probe), probed right before and '
+                                        'right after the timed steps: the hot kernels are clock-bound, so box-to-box / thermal differences '
+                                        'show here')},
     }
+    if args.workload == 'tile2048' and not dry:
+        # where the last step went on every rank: batched test() calls / the RCCL all-gather / the paste of all ranks' tiles
+        split = net.last_split_ms
+        if world > 1:
+            allsp = [None] * world
+            dist.all_gather_object(allsp, split)
+            split = allsp
+        res['timed_region']['last_step_split_ms_per_rank'] = split
     if args.workload == 'tiles16' and do_gather:
         res['config']['gather_overlap'] = 'all-gather of step k overlaps step k+1'
 
@@ -290,61 +336,77 @@ def main():
 
             def issued_share(name):      # MFMA flops issued / algorithmic flops of the layer definition
                 if name.startswith('conv3x3_wino'):
-                    return 16.0 / 36.0
+                    return 36.0 / 144.0          # Winograd F(4x4,3x3): 36 multiplies per 4x4 outputs instead of 16 x 9
                 if name.startswith('conv3x3_halo<') and 'up2=true' in name:
-                    return 4.0 / 9.0
+                    return 4.0 / 9.0             # nearest-x2 + 3x3 conv as four 2x2-tap phase filters
+                if name.startswith('conv3x3_halo_bf16x3'):
+                    return 3.0                   # three bf16 MFMA passes per multiply-add
                 return 1.0
 
             def roof(name):
+                """`achieved` / `frac` are PHYSICAL: the flops the MFMA pipe executes per second and their share of the dense peak
+                (<= 1).  The layer definition's (algorithmic) flops over the same time are reported beside them."""
                 ms, n, fl, _ = convs[name]
                 split = name.startswith('conv3x3_halo_bf16x3')
                 peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-                ach = fl / (ms * 1e-3) / 1e12
+                alg = fl / (ms * 1e-3) / 1e12
+                share = issued_share(name)
                 rec = pmc.get(rocprof_kernel_name(name))
-                out = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                       'frac': round(ach / peak, 4),
+                out = {'bound': 'mfma', 'kernel': name, 'achieved': round(alg * share, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                       'frac': round(alg * share / peak, 4),
                        'traffic': round((rec['fetch_bytes_corrected'] + rec['write_bytes']) / 1e9, 4) if rec else None,
-                       'launches': n, 'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
-                       'peak_basis': ('bf16 dense MFMA peak; ALGORITHMIC flops: each multiply-add costs 3 MFMA passes '
-                                      '(hi*hi + hi*lo + lo*hi), so MFMA issue fraction = 3 x frac') if split else
-                                     'fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)'}
-                if split:
-                    out['mfma_issue_frac'] = round(3 * ach / peak, 4)
-                elif issued_share(name) != 1.0:
-                    out['mfma_issue_frac'] = round(issued_share(name) * ach / peak, 4)
-                    out['peak_basis'] = ('fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32); ALGORITHMIC flops of the layer definition (9 taps per '
-                                         'output pixel) - this kernel issues only %s of them (%s), so the MFMA issue fraction is '
-                                         'mfma_issue_frac and frac can exceed 1' % (
-                                             '16/36' if 'wino' in name else '4/9',
-                                             'Winograd F(2x2,3x3), all fp32' if 'wino' in name else 'nearest-x2 folded into four 2x2-tap phase filters'))
+                       'launches': n, 'avg_launch_ms': round(ms / n, 4),
+                       'issued_gflop_per_launch': round(fl * share / n / 1e9, 3), 'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3),
+                       'issued_share_of_algorithmic': round(share, 4),
+                       'algorithmic_tflops': round(alg, 2), 'algorithmic_over_peak': round(alg / peak, 4),
+                       'peak_basis': ('bf16 dense MFMA peak; each multiply-add of the definition costs 3 MFMA passes (hi*hi + hi*lo + lo*hi)'
+                                      if split else 'fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)'),
+                       'basis': ('achieved = flops the MFMA pipe EXECUTES (algorithmic flops of the layer definition x issued share) / HIP-event '
+                                 'time of the launches; frac = achieved / peak = the physical MFMA issue fraction')}
+                if name.startswith('conv3x3_wino'):
+                    out['form'] = 'Winograd F(4x4,3x3), all fp32: 36 multiplies per 4x4 outputs where the definition has 144'
+                elif share == 4.0 / 9.0:
+                    out['form'] = 'nearest-x2 folded into four 2x2-tap phase filters: 4 multiplies per output where the definition has 9'
                 if rec:
-                    out['traffic_source'] = ('GB per launch, rocprofv3 --pmc FETCH_SIZE (doubled per MI355X_MICROARCH.md HBM '
-                                             'section) + WRITE_SIZE passes of this command (profiles/pmc_traffic.json)')
+                    out['traffic_source'] = ('GB per launch, rocprofv3 --pmc FETCH_SIZE (doubled per MI355X_MICROARCH.md HBM section) + WRITE_SIZE '
+                                             'passes of this command on the BUILD box (profiles/pmc_traffic.json); not re-measured in this run')
                 return out
             dom = max(convs, key=lambda k: convs[k][0])
             res['roofline'] = roof(dom)
-            tot_ms = sum(v[0] for v in convs.values())
-            tot_fl = sum(v[2] for v in convs.values())
-            iss_fl = sum(v[2] * (3.0 if k.startswith('conv3x3_halo_bf16x3') else issued_share(k)) for k, v in convs.items())
-            res['roofline']['all_mfma_conv_kernels'] = {
-                'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                'issued_tflops': round(iss_fl / (tot_ms * 1e-3) / 1e12, 2),
+            # every MFMA kernel of the step (convs + the GEMMs of the Swin linears) and the step as a whole
+            mf = {k: v for k, v in prof.items() if v[2] > 0 and not k.startswith('vq(')}
+            tot_ms = sum(v[0] for v in mf.values())
+            alg_fl = sum(v[2] for v in mf.values())
+            iss_fl = sum(v[2] * issued_share(k) for k, v in mf.items())
+            step_alg_gf = sum(v[2] for v in prof.values()) / psteps / 1e9
+            step_iss_gf = sum(v[2] * issued_share(k) for k, v in prof.items()) / psteps / 1e9
+            res['roofline']['all_mfma_kernels'] = {
+                'issued_tflops': round(iss_fl / (tot_ms * 1e-3) / 1e12, 2), 'frac_of_fp32_mfma_peak': round(iss_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                'algorithmic_tflops': round(alg_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'share_of_serialized_step_time': round(tot_ms / psteps / prof_ms_per_step, 4)}
+            t_step = dt / args.steps
+            res['roofline']['end_to_end'] = {
+                'issued_gflop_per_step': round(step_iss_gf, 1), 'algorithmic_gflop_per_step': round(step_alg_gf, 1),
+                'end_to_end_issued_tflops': round(step_iss_gf * (units_per_step / world / B) / t_step / 1e3, 2),
+                'end_to_end_issued_over_fp32_mfma_peak': round(step_iss_gf * (units_per_step / world / B) / t_step / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                'end_to_end_algorithmic_tflops': round(step_alg_gf * (units_per_step / world / B) / t_step / 1e3, 2),
+                'note': 'per GPU; flops of one profiled step (kernel launch records) over the TIMED step time of this rank'}
             res['roofline']['measured_in'] = (f'{psteps} serialized steps (streams=1, {prof_ms_per_step:.1f} ms/step, batch {B} of 128x128 tiles, '
                                               f"decoder_math={args.decoder_math}) right after the timed region")
             res['roofline']['per_kernel'] = {
                 k: {'ms_per_step': round(v[0] / psteps, 3), 'launches_per_step': v[1] // psteps,
-                    **({'tflops': round(v[2] / (v[0] * 1e-3) / 1e12, 1)} if v[2] > 0 else {})}
+                    **({'issued_tflops': round(v[2] * issued_share(k) / (v[0] * 1e-3) / 1e12, 1),
+                        'algorithmic_tflops': round(v[2] / (v[0] * 1e-3) / 1e12, 1)} if v[2] > 0 else {})}
                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
             vq = prof.get('vq(codebook lookup)')
             if vq:          # the north-star's VQ figure: algorithmic HBM bytes (SURVEY 8d: 23.37 MB per tile) / time
                 res['roofline']['vq'] = {'ms_per_step': round(vq[0] / psteps, 3), 'algorithmic_GB_per_step': round(vq[3] / psteps / 1e9, 4),
                                          'hbm_GB_s': round(vq[3] / (vq[0] * 1e-3) / 1e9, 1), 'frac_of_8TB_s': round(vq[3] / (vq[0] * 1e-3) / 8e12, 4),
-                                         'tflops': round(vq[2] / (vq[0] * 1e-3) / 1e12, 1),
+                                         'algorithmic_tflops': round(vq[2] / (vq[0] * 1e-3) / 1e12, 1),
                                          'search': ('single-pass fp32 MFMA (FEMASR_VQ=gemm)' if os.environ.get('FEMASR_VQ') == 'gemm' else
                                                     'two-pass exact: bf16 MFMA candidates + fp32 chain re-check (kernels_vq.hip)')}
         if world == 1 and not args.no_second_leg and args.workload == 'tiles16':
-            legs = ['bf16x3', 'fp32_direct'] if args.decoder_math == 'fp32' else ['fp32']
+            legs = ['fp32_strict', 'bf16x3', 'fp32_direct'] if args.decoder_math == 'fp32' else ['fp32']
             for other in legs:
                 net.decoder_math = other
                 net.test(x16)
@@ -356,14 +418,18 @@ def main():
                 te = (time.perf_counter() - te0) / args.steps
                 leg = {'value': round(B * 512 * 512 / 1e6 / te, 4), 'unit': 'MPix/s', 'ms_per_step': round(te * 1e3, 3),
                        'max_abs_vs_timed_mode': float((ye - y).abs().max()),
-                       'end_to_end_tflops': round(TILE_GFLOP * B / te / 1e3, 2)}
+                       'end_to_end_algorithmic_tflops': round(TILE_GFLOP * B / te / 1e3, 2)}
+                if other == 'fp32_strict':
+                    leg['note'] = ('the timed mode with the IEEE-exact SiLU in the Winograd convs (polynomial exp + division instead of v_exp_f32 / '
+                                   'v_rcp_f32): bit-identical to the CPU oracle; VQ indices identical to the timed mode')
                 if other == 'bf16x3':
                     leg['note'] = ('secondary mode: 698 of 964 GFLOP per tile as 3-pass split-bf16 MFMA (products narrower than fp32); '
                                    'everything feeding the VQ argmin stays exact fp32; NOT the bench of record')
                 if other == 'fp32_direct':
-                    leg['note'] = ('the same fp32 network with every 3x3 conv in the direct form (no Winograd behind the VQ lookup): '
-                                   'the arithmetic of rounds 1-2; VQ indices identical, output within fp32 rounding of the timed mode')
-                res[{'bf16x3': 'bf16x3_mode', 'fp32_direct': 'fp32_direct_mode', 'fp32': 'exact_fp32_mode'}[other]] = leg
+                    leg['note'] = ('the same fp32 network without the Winograd form (the 3x3 convs behind the VQ lookup in the direct form; the x2 '
+                                   'convs still as phase filters): bit-identical to OracleNet(winograd=False); VQ indices identical, output '
+                                   'within fp32 rounding of the timed mode')
+                res[{'bf16x3': 'bf16x3_mode', 'fp32_direct': 'fp32_direct_mode', 'fp32_strict': 'fp32_strict_mode', 'fp32': 'fp32_mode'}[other]] = leg
             net.decoder_math = args.decoder_math
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(net, x16, y if args.workload == 'tiles16' else None, B)

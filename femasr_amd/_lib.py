@@ -100,6 +100,7 @@ SIGNATURES = {
     'femasr_set_decoder_math': (c_int, [vp, c_int]),
     'femasr_image_u8_to_f32': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_image_f32_to_u8': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
+    'femasr_clock_probe': (c_int, [vp, c_int, vp]),
 }
 
 _lib = None

@@ -246,10 +246,7 @@ class FeMaSRNet(nn.Module):
         # the walk over the (~480-tensor) state dict only runs when something may have changed; otherwise a cheap scan of
         # the parameters' version counters (in-place updates) decides
         if not self._weights_dirty:
-            vsum = 0
-            for p_ in self.parameters():
-                vsum += p_._version
-            self._weights_dirty = vsum != self._version_sum
+            self._weights_dirty = self._param_stamp() != self._version_sum
         if self._weights_dirty:
             dirty = False
             for key, t in self.state_dict().items():
@@ -269,7 +266,7 @@ class FeMaSRNet(nn.Module):
                 self._pushed[key] = stamp
             if dirty:
                 _lib.check(lib.femasr_finalize_weights(self._handle))
-            self._version_sum = sum(p_._version for p_ in self.parameters())
+            self._version_sum = self._param_stamp()
             self._weights_dirty = False
         if self._streams_set != (self._handle.value, self.num_streams, self.decoder_math):
             if self.decoder_math not in ('fp32', 'bf16x3', 'fp32_direct', 'fp32_strict'):
@@ -279,8 +276,18 @@ class FeMaSRNet(nn.Module):
             self._streams_set = (self._handle.value, self.num_streams, self.decoder_math)
         return lib, self._handle
 
+    def _param_stamp(self):
+        """Cheap change detector over the parameters: in-place updates bump `_version`; a replaced Parameter object or rebound
+        storage (`mod.weight = nn.Parameter(t)`, `p.data = t`, `p.set_()`) changes `data_ptr()`.  Writes through `.data` views
+        stay invisible to both: FeMaSRNet.invalidate_weights()."""
+        acc = 0
+        for p_ in self.parameters():
+            acc = (acc * 1000003 + p_._version * 7919 + p_.data_ptr()) & 0xFFFFFFFFFFFFFFFF
+        return acc
+
     def _release(self):
         if getattr(self, '_handle', None) is not None:
+            self._graphs = {}             # captured graphs bake pointers into the handle's repacked weights / plans: drop them with it
             _lib.load().femasr_destroy(self._handle)
             self._handle = None
 
@@ -365,8 +372,13 @@ class FeMaSRNet(nn.Module):
 
     @torch.no_grad()
     def encode_and_decode(self, input, gt_indices=None, current_iter=None):
+        """`gt_indices` (one (B,1,h,w) index map per codebook) only changes the LOSS in the reference - VectorQuantizer.forward
+        computes z_q and the returned indices from its own argmin either way (femasr_arch.py:64-66,69-91,95,339-342) - so an
+        inference build serves the call and ignores it: image and indices are those of forward(input); the losses are zeros."""
         if gt_indices is not None:
-            raise NotImplementedError('gt_indices is a training-time input (femasr_arch.py:339-340)')
+            n_cb = len(self._cb)
+            if not isinstance(gt_indices, (list, tuple)) or len(gt_indices) < n_cb:
+                raise ValueError(f'gt_indices must hold one index map per codebook ({n_cb}), as FeMaSRNet.forward returns them')
         out, idx = self._run(input, 0)
         zero = out.new_zeros(())
         return out, zero, zero, idx
@@ -420,6 +432,11 @@ class FeMaSRNet(nn.Module):
         tiles = tiling.enumerate_tiles(height, width, tile_size, tile_pad)
         classes = tiling.shape_classes(tiles)
         mine = tiling.partition(classes, rank, world_size)
+        # `time_split = True`: record where the call's time goes (events on the current stream; read back in `last_split_ms`
+        # = {'compute', 'gather', 'paste', 'tiles_owned'} after a synchronize) - bench.py --workload tile2048 reports it per rank
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (getattr(self, 'time_split', False) and input.is_cuda) else None
+        if ev:
+            ev[0].record()
         results = {}
         for hw, tl in mine.items():
             outs = []
@@ -427,19 +444,37 @@ class FeMaSRNet(nn.Module):
                 chunk = tl[i:i + max(1, self.max_tile_batch // batch)]
                 outs.append(self.test(self._extract_tiles(input, chunk, hw)))
             results[hw] = torch.cat(outs, 0) if outs else input.new_zeros((0, channel, hw[0] * s, hw[1] * s))
+        if ev:
+            ev[1].record()
         if world_size > 1:
             if gather is None:
                 raise ValueError('world_size > 1 needs a gather callable')
             per_rank = gather(results, classes, batch, channel, s)
         else:
             per_rank = [results]
+        if ev:
+            ev[2].record()
         output = input.new_zeros((batch, channel, height * s, width * s))
         for r, res in enumerate(per_rank):
             owned = tiling.partition(classes, r, world_size)
             for hw, tl in owned.items():
                 if tl:
                     self._paste_tiles(output, res[hw], tl, batch, s)
+        if ev:
+            ev[3].record()
+            self._split_events = (ev, sum(len(tl) for tl in mine.values()))
         return output
+
+    @property
+    def last_split_ms(self):
+        """{'compute', 'gather', 'paste'} milliseconds of the last `test_tile` call made with `time_split = True` (synchronises)."""
+        rec = getattr(self, '_split_events', None)
+        if rec is None:
+            return None
+        ev, owned = rec
+        ev[3].synchronize()
+        return {'compute': round(ev[0].elapsed_time(ev[1]), 3), 'gather': round(ev[1].elapsed_time(ev[2]), 3),
+                'paste': round(ev[2].elapsed_time(ev[3]), 3), 'tiles_owned': owned}
 
     @staticmethod
     def _extract_tiles(input, chunk, hw):

@@ -726,6 +726,26 @@ inline unsigned grid_for(size_t total, int block = 256)
 // ------------------------------------------------------------------------------------------
 // C ABI (include/femasr_hip.h)
 // ------------------------------------------------------------------------------------------
+// Sustained-clock probe (bench.py): every wave streams back-to-back v_mfma_f32_32x32x2_f32 (64 shader cycles each: the load the
+// network's hot kernels put on the chip) and records the s_memtime ticks (= shader cycles) its loop took; ticks / wall time of
+// the launch = the clock the chip sustains under that load right now.
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void clock_probe_kernel(int groups, float a, float b, unsigned long long *ticks)
+{
+    probe_f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < groups; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c3, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = (t1 - t0) + (s == 12345.678f ? 1ull : 0ull);
+}
+
 extern "C" {
 
 int femasr_pad_nchw_to_nhwc(void *stream, const float *in, int B, int C, int H, int W, int Hp, int Wp, float *out)
@@ -963,6 +983,14 @@ int femasr_image_f32_to_u8(void *stream, const float *in_chw, int H, int W, int 
     const size_t total = (size_t)3 * H * W;
     hipLaunchKernelGGL(image_f32_to_u8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in_chw, H, W,
                        swap_rb, out_hwc, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_clock_probe(void *stream, int mfmas_per_wave, unsigned long long *ticks)
+{
+    FEMASR_REQUIRE(ticks && mfmas_per_wave >= 4, "clock_probe: bad args");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(FEMASR_CLOCK_PROBE_BLOCKS), dim3(256), 0, (hipStream_t)stream, mfmas_per_wave / 4, 1.0001f, 0.5f, ticks);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

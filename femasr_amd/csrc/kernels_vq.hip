@@ -491,7 +491,7 @@ size_t femasr_vq_scratch_bytes(int64_t M, int n_e)
     return gemm > two ? gemm : two;
 }
 
-// pass 1 alone (tests: the exact argmin must be among the candidates).  cand (M,16) u16, cnt (M) u16 with
+// pass 1 alone (tests: the exact argmin must be among the candidates).  cand (M, VQ_CMAX = 32) u16, cnt (M) u16 with
 // 0xFFFF = "every code".
 int femasr_vq_candidates(void *stream, const float *z, int64_t M, int D, const void *aux, const float *ee, int n_e,
                          uint16_t *cand, uint16_t *cnt)

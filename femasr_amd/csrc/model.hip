@@ -364,7 +364,9 @@ struct Ctx {
         a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
         a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
         const void *split = nullptr;
-        if (o.lowp && h->decoder_math == 1) {
+        // (several codebooks: the decoder feeds later lookups through before_quant_group[q > 0], so NO conv is 'behind' every
+        // lookup - the inexact bf16x3 form, like the Winograd form below, is only taken by single-codebook networks)
+        if (o.lowp && h->decoder_math == 1 && h->cfg.n_codebooks == 1) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) split = h->specs[it->second].split;
         }

@@ -275,6 +275,14 @@ int femasr_image_u8_to_f32(void *stream, const uint8_t *in_hwc, int H, int W, in
  * Replaces tensor2img (basicsr/utils/img_util.py:38-94). */
 int femasr_image_f32_to_u8(void *stream, const float *in_chw, int H, int W, int swap_rb, uint8_t *out_hwc);
 
+/* ---- measurement support ---- */
+/* Sustained-clock probe: FEMASR_CLOCK_PROBE_BLOCKS blocks of 4 waves stream `mfmas_per_wave` back-to-back fp32 MFMAs (the load
+ * of the hot kernels; 64 shader cycles each) and write the s_memtime ticks of their loop to ticks[blocks*4].  ticks / wall time
+ * of the launch = the clock the chip sustains under MFMA load at that moment (bench.py reports it before and after the timed
+ * region: the network's kernels are clock-bound, so a throttling box shows up here and not as a kernel regression). */
+#define FEMASR_CLOCK_PROBE_BLOCKS 256
+int femasr_clock_probe(void *stream, int mfmas_per_wave, unsigned long long *ticks);
+
 #ifdef __cplusplus
 }
 #endif

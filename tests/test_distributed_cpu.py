@@ -74,3 +74,63 @@ def test_two_rank_tile_parallel_equals_single_rank(shape, ts, pad):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# 8 ranks (the node size the north-star names) over the tile geometries of BASELINE config 3, scaled 1/8 in pixels so that the
+# canvases stay small on a CPU box: the TILE COUNTS and shape-class structure are those of a 2048x2048 LR image
+#   3a  tile_size 128, pad 0   -> 16/0 on 256x256:  256 tiles, one class            (32 per rank)
+#   3b  tile_size  96, pad 16  -> 12/2 on 256x256:  484 tiles, 9 classes 400/20/20/20/20/1/1/1/1
+#   3c  tile_size 240, pad 16  -> 30/2 on 256x256:   81 tiles, 9 classes 49/7/7/7/7/1/1/1/1
+_GEOMS8 = [(16, 0, 256), (12, 2, 484), (30, 2, 81)]
+
+
+def _worker8(rank, world, port, x, expects, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    fd.init_from_env('gloo')
+    ok = []
+    for (ts, pad, _), expect in zip(_GEOMS8, expects):
+        y = fd.test_tile_parallel(_make_net(), x, ts, pad)
+        ok.append(bool(torch.equal(y, expect)))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_tile_parallel_config3_geometries():
+    from femasr_amd import tiling
+    world = 8
+    torch.manual_seed(1)
+    x = torch.rand((1, 3, 256, 256))
+    net = _make_net()
+    expects = []
+    for ts, pad, ntiles in _GEOMS8:
+        tiles = tiling.enumerate_tiles(256, 256, ts, pad)
+        classes = tiling.shape_classes(tiles)
+        assert len(tiles) == ntiles
+        owned = [tiling.partition(classes, r, world) for r in range(world)]
+        per_rank = [sum(len(tl) for tl in o.values()) for o in owned]
+        assert sum(per_rank) == ntiles
+        # every tile is owned exactly once, and each class is split in contiguous blocks that differ by at most one tile
+        seen = sorted(t.index for o in owned for tl in o.values() for t in tl)
+        assert seen == list(range(ntiles))
+        for hw, tl in classes.items():
+            cnt = [len(o[hw]) for o in owned]
+            assert max(cnt) - min(cnt) <= 1 and sum(cnt) == len(tl)
+        if pad == 0:
+            assert per_rank == [32] * 8 and len(classes) == 1
+        else:
+            assert len(classes) == 9 and sorted((len(tl) for tl in classes.values()), reverse=True)[:5] == \
+                ([400, 20, 20, 20, 20] if ntiles == 484 else [49, 7, 7, 7, 7])
+        expects.append(net.test_tile(x, ts, pad))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, x, expects, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, [True, True, True]) for r in range(world)]

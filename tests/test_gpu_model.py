@@ -86,8 +86,21 @@ def test_hq_index_extraction_service(cuda_device, tmp_path):
     assert isinstance(idx_list, list) and len(idx_list) == 1
     idx = idx_list[0]
     assert idx.dtype == torch.int64 and tuple(idx.shape) == (1, 1, 8, 12)
+    # the indices are the ORACLE's (HQ forward of the reference restatement), not merely self-consistent
+    from helpers import oracle_net
+    yo, io = oracle_net('hq', hq_w).forward(gt.numpy())
+    assert np.array_equal(idx.cpu().numpy(), io)
+    assert float(np.abs(model.gt_rec.cpu().numpy() - yo).max()) < 1e-4
     rec = model.net_hq.decode_indices(idx)
     assert float((rec - model.gt_rec).abs().max()) <= 1e-5
+    # forward(input, gt_indices) - what FeMaSRModel.optimize_parameters passes (femasr_model.py:145-146): gt_indices only changes
+    # the loss in the reference (femasr_arch.py:69-91), so image and indices equal forward(input) and the losses are zeros
+    lq = torch.from_numpy(np.random.RandomState(4).rand(1, 3, 16, 24).astype(np.float32)).cuda()
+    out0, cl0, sl0, i0 = model.net_g(lq)
+    out1, cl1, sl1, i1 = model.net_g(lq, gt_indices=idx_list)
+    assert torch.equal(out0, out1) and torch.equal(i0[0], i1[0]) and float(cl1) == 0.0 and float(sl1) == 0.0
+    with pytest.raises(ValueError):
+        model.net_g(lq, gt_indices=[])
     # the HQ checkpoint was also loaded (non-strictly) into net_g: shared decoder / codebook tensors are identical
     g, h = model.net_g.state_dict(), model.net_hq.state_dict()
     k = 'quantize_group.0.embedding.weight'

@@ -95,7 +95,7 @@ def test_config3_full_size_tile_property(cuda_device):
     import gpu_utils as G
     net = G.build_net('x4', synth_weights('x4', 0, 'trained'), cuda_device)
     net.num_streams = 2
-    net.decoder_math = 'bf16x3'            # the property is math-mode independent; the faster mode keeps the test short
+    net.decoder_math = 'fp32'              # the mode of record (bench.py --workload tile2048 times exactly this call)
     x = torch.from_numpy(synth.synth_input(77, (1, 3, 2048, 2048))).cuda()
     y = net.test_tile(x, 128, 0)
     assert tuple(y.shape) == (1, 3, 8192, 8192)
