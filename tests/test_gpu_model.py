@@ -95,7 +95,7 @@ def test_hq_index_extraction_service(cuda_device, tmp_path):
     assert float((rec - model.gt_rec).abs().max()) <= 1e-5
     # forward(input, gt_indices) - what FeMaSRModel.optimize_parameters passes (femasr_model.py:145-146): gt_indices only changes
     # the loss in the reference (femasr_arch.py:69-91), so image and indices equal forward(input) and the losses are zeros
-    lq = torch.from_numpy(np.random.RandomState(4).rand(1, 3, 16, 24).astype(np.float32)).cuda()
+    lq = torch.from_numpy(np.random.RandomState(4).rand(1, 3, 32, 48).astype(np.float32)).cuda()      # forward(): no pad, Swin map 16x24
     out0, cl0, sl0, i0 = model.net_g(lq)
     out1, cl1, sl1, i1 = model.net_g(lq, gt_indices=idx_list)
     assert torch.equal(out0, out1) and torch.equal(i0[0], i1[0]) and float(cl1) == 0.0 and float(sl1) == 0.0
