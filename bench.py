@@ -59,9 +59,9 @@ def rocprof_kernel_name(bench_name):
     m = re.match(r'conv3x3_wino4<2x16x16px x64,(\w+),(\w+),waves=8>', bench_name)
     if m:
         return f'conv3x3_wino4_kernel<{pro[m.group(1)]}, {m.group(2)}>'
-    m = re.match(r'gemm_dma<128x128x(\d)\*8,stages=(\d),act=(\d),nres=(\d),vq=(\w+)>', bench_name)
+    m = re.match(r'gemm_dma<tile=64\*(\d),k=8\*(\d),stages=(\d),act=(\d),nres=(\d),vq=(\w+)>', bench_name)
     if m:
-        return f'gemm_dma_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>'
+        return f'gemm_dma_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}, {m.group(6)}>'
     return bench_name
 
 

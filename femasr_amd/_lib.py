@@ -101,6 +101,8 @@ SIGNATURES = {
     'femasr_image_u8_to_f32': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_image_f32_to_u8': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_clock_probe': (c_int, [vp, c_int, vp]),
+    'femasr_gemm_force_config': (c_int, [c_int]),
+    'femasr_conv_small_launch_blocks': (c_int, [c_int]),
 }
 
 _lib = None

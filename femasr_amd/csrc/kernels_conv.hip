@@ -31,6 +31,7 @@
 // Grid: 1-D, n-blocks fastest, bijective XCD remap (block b runs on XCD b % 8) so tiles sharing activations /
 //   halo rows share an L2.
 #include "conv_common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include "detmath.h"
 
@@ -784,18 +785,46 @@ Variant g_variants[] = {
 constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr int kFirstHalo = 9;
 
-int pick_variant(const femasr_conv_args *a)
+int g_small_blocks = -1;         // -1: not read yet (FEMASR_CONV_SMALL_BLOCKS or the default)
+constexpr int kSmallBlocksDefault = 384;
+int small_launch_blocks()
+{
+    if (g_small_blocks < 0) {
+        const char *e = getenv("FEMASR_CONV_SMALL_BLOCKS");
+        g_small_blocks = e ? atoi(e) : kSmallBlocksDefault;
+        if (g_small_blocks < 0) g_small_blocks = kSmallBlocksDefault;
+    }
+    return g_small_blocks;
+}
+
+int pick_variant(const femasr_conv_args *a, int Ho, int Wo)
 {
     const bool vec = (a->Cin % BK) == 0;
-    const int cls = a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2);     // BN = 128 / 64 / 32
+    int cls = a->Cout > 64 ? 0 : (a->Cout > 32 ? 1 : 2);           // BN = 128 / 64 / 32
+    const bool halo = femasr_conv_halo_eligible(a);
+    // Small launches (batch 1-2 of the 72x72 / 144x144 layers): with 128-column blocks a 256-channel layer of one tile is 90
+    // blocks on 256 CUs, each a serial chain over 9 taps x Cin.  64-column blocks double the block count and halve the chain
+    // (same fragment-major weights, same per-wave pixel tile: results and GroupNorm partial moments are unchanged).
+    if (cls == 0 && (halo || vec)) {
+        const long long mb = halo ? (long long)a->B * (((a->up2 ? a->W : Wo) + 15) / 16) * (((a->up2 ? a->H : Ho) + 7) / 8) * (a->up2 ? 4 : 1)
+                                  : ((long long)a->B * Ho * Wo + 127) / 128;
+        if (mb * ((a->Cout + 127) / 128) < small_launch_blocks()) cls = 1;
+    }
     // Cout > 32: 4-wave halo blocks (64 px x 64 / 32 ch per wave: half the LDS / weight-fragment reads per MFMA, 4 waves per
     // barrier instead of 8; measured +4..9 % over the 8-wave tiling, fused-x2 variant 141 TFLOP/s = 90 % of peak)
-    if (femasr_conv_halo_eligible(a)) return kFirstHalo + cls * 3 + (a->up2 ? 2 : a->prologue);
+    if (halo) return kFirstHalo + cls * 3 + (a->up2 ? 2 : a->prologue);
     if (!vec) return 6 + cls;
     return cls * 2 + a->prologue;
 }
 
 }  // namespace
+
+extern "C" int femasr_conv_small_launch_blocks(int blocks)
+{
+    const int prev = small_launch_blocks();
+    g_small_blocks = blocks >= 0 ? blocks : kSmallBlocksDefault;
+    return prev;
+}
 
 // 3x3 stride-1 pad-1 convs with Cin % 32 == 0 run on the halo kernels (shared with model.hip's planner)
 bool femasr_conv_halo_eligible(const femasr_conv_args *a)
@@ -863,7 +892,7 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
         if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K;
         return FEMASR_OK;
     }
-    const int vi = pick_variant(a);
+    const int vi = pick_variant(a, Ho, Wo);
     Variant &v = g_variants[vi];
     p.MB = (p.M + v.bm - 1) / v.bm;
     p.NB = (p.Cout + v.bn - 1) / v.bn;

@@ -44,12 +44,14 @@ struct GemmParams {
     int M, N, K, nchunks, MB, NB, NT32;
 };
 
-constexpr int G_BM = 128, G_BN = 128;
-// Pipeline configuration <KB, ST>: KB = 8-channel groups per K chunk (4: 32-deep chunks, 2: 16-deep), ST = LDS stages.
+// Configuration <WT, KB, ST>: WT = accumulator tiles (32 x 32) per wave and dimension - the block (4 waves, 2 x 2) computes
+//   64 WT x 64 WT outputs (WT = 2: 128 x 128, WT = 1: 64 x 64 for launches that would not fill the chip otherwise);
+//   KB = 8-channel groups per K chunk (4: 32-deep chunks, 2: 16-deep), ST = LDS stages.
 //   ST = 2: two barriers per chunk (data landed / stage free again);  ST = 3: one barrier per chunk.
-template <int KB, int ST>
+template <int WT, int KB, int ST>
 struct GCfg {
-    static constexpr int kTile = 1024 * KB;                 // floats of one operand tile per stage (128 rows x 8 KB floats)
+    static constexpr int kBM = 64 * WT;                     // block tile (rows = columns)
+    static constexpr int kTile = 512 * KB * WT;             // floats of one operand tile per stage (64 WT rows x 8 KB floats)
     static constexpr int kStage = 2 * kTile;                // A tile + W tile
     static constexpr int kLdsBytes = (ST * kStage * 4) > (4 * TSCRATCH * 4) ? (ST * kStage * 4) : (4 * TSCRATCH * 4);
     static constexpr int kBlocksPerCU = (160 * 1024) / kLdsBytes > 4 ? 4 : (160 * 1024) / kLdsBytes;
@@ -64,16 +66,20 @@ __device__ __forceinline__ void dma16(const float *gsrc, float *lds_dst_uniform)
     __builtin_amdgcn_global_load_lds((glb_cvptr)gsrc, (lds_vptr)lds_dst_uniform, 16, 0, 0);
 }
 
-template <int KB, int ST, int ACT, int NRES, bool VQ>
-__global__ __launch_bounds__(256, (GCfg<KB, ST>::kBlocksPerCU)) void gemm_dma_kernel(const GemmParams p)
+template <int WT, int KB, int ST, int ACT, int NRES, bool VQ>
+__global__ __launch_bounds__(256, (GCfg<WT, KB, ST>::kBlocksPerCU)) void gemm_dma_kernel(const GemmParams p)
 {
-    using C = GCfg<KB, ST>;
+    using C = GCfg<WT, KB, ST>;
+    constexpr int G_BM = C::kBM, G_BN = C::kBM;
     constexpr int GR = 2 * KB;                 // 16-byte granules per A row and chunk
     constexpr int RPP = 64 / GR;               // rows per 1 KiB DMA piece
     constexpr int SW = GR == 8 ? 1 : 2;        // swizzle: granule g of row r sits at r*GR + (g ^ ((r >> SW) & (GR-1)))
-    constexpr int PW = 2 * KB;                 // DMA pieces per wave and stage (KB of A + KB of W)
+    constexpr int PP = WT * KB / 2;            // DMA pieces per wave, stage and operand (the tile has 2 WT KB pieces of 1 KiB)
+    constexpr int PW = 2 * PP;                 // DMA pieces per wave and stage
     static_assert(KB == 2 || KB == 4, "chunk depth");
     static_assert(ST == 2 || ST == 3, "stages");
+    static_assert(WT == 2 || (WT == 1 && KB == 4), "block tile");
+    static_assert(!VQ || WT == 2, "the VQ epilogue reduces over 128-column blocks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -84,45 +90,47 @@ __global__ __launch_bounds__(256, (GCfg<KB, ST>::kBlocksPerCU)) void gemm_dma_ke
     const int m0 = mb * G_BM, n0 = nb * G_BN;
     const int h = lane >> 5, c31 = lane & 31;
 
-    // ---- DMA sources.  A piece i of this wave = rows RPP*(KB*wave+i) .. of the tile: lane -> (row, granule).
-    const float *srcA[KB];
+    // ---- DMA sources.  A piece i of this wave = rows RPP*(PP*wave+i) .. of the tile: lane -> (row, granule).
+    const float *srcA[PP];
 #pragma unroll
-    for (int i = 0; i < KB; ++i) {
-        const int row = RPP * (KB * wave + i) + lane / GR;
+    for (int i = 0; i < PP; ++i) {
+        const int row = RPP * (PP * wave + i) + lane / GR;
         const int g = (lane & (GR - 1)) ^ ((row >> SW) & (GR - 1));
         int grow = m0 + row;
         grow = grow < p.M ? grow : p.M - 1;                 // tail rows: clamp (computed, never stored)
         srcA[i] = p.A + (size_t)grow * p.K + 4 * g;
     }
-    // W pieces of column tile (n0/32 + wave): [chunk32][ntile][j = 0..3][lane][t]; a KB = 2 chunk takes j = 2*(c&1) + {0,1}
-    int ntile = (n0 >> 5) + wave;
+    // W pieces: the packed matrix is [chunk32][ntile][j = 0..3][lane][t] (a KB = 2 chunk takes j = 2*(c&1) + {0,1}); the stage
+    // holds [column tile of the block][j < KB] pieces; this wave copies pieces PP*wave .. PP*wave + PP-1 of them, which lie in
+    // ONE column tile (WT = 2: tile `wave`, all its j; WT = 1: tile wave/2, j = 2*(wave&1) + {0,1}).
+    int ntile = (n0 >> 5) + (PP * wave) / KB;
     ntile = ntile < p.NT32 ? ntile : p.NT32 - 1;            // tiles past the packed matrix: clamp (never stored)
-    const float *srcW = p.W + ((size_t)ntile * 256 + lane) * 4;
+    const float *srcW = p.W + ((size_t)ntile * 256 + lane) * 4 + ((PP * wave) % KB) * 256;
     const size_t wchunk = (size_t)p.NT32 * 1024;            // floats per 32-deep K chunk of the packed matrix
 
     auto issue = [&](int sb, int c) {
-        float *dA = smem + sb * C::kStage + wave * (256 * KB);          // this wave's KB A pieces
-        float *dW = smem + sb * C::kStage + C::kTile + wave * (256 * KB);
+        float *dA = smem + sb * C::kStage + wave * (256 * PP);          // this wave's PP A pieces
+        float *dW = smem + sb * C::kStage + C::kTile + wave * (256 * PP);
 #pragma unroll
-        for (int i = 0; i < KB; ++i) dma16(srcA[i] + c * (8 * KB), dA + i * 256);
+        for (int i = 0; i < PP; ++i) dma16(srcA[i] + c * (8 * KB), dA + i * 256);
         const float *w = KB == 4 ? srcW + (size_t)c * wchunk : srcW + (size_t)(c >> 1) * wchunk + (c & 1) * 512;
 #pragma unroll
-        for (int j = 0; j < KB; ++j) dma16(w + j * 256, dW + j * 256);
+        for (int j = 0; j < PP; ++j) dma16(w + j * 256, dW + j * 256);
     };
 
     // ---- fragment addresses (floats inside a stage)
     const int xq = h ^ ((c31 >> SW) & (GR - 1));
     int aoff[KB];
 #pragma unroll
-    for (int j = 0; j < KB; ++j) aoff[j] = ((wm * 64 + c31) * GR + ((2 * j) ^ xq)) * 4;
-    const int boff = C::kTile + (wn * 2 * KB) * 256 + lane * 4;
+    for (int j = 0; j < KB; ++j) aoff[j] = ((wm * 32 * WT + c31) * GR + ((2 * j) ^ xq)) * 4;
+    const int boff = C::kTile + (wn * WT * KB) * 256 + lane * 4;
     constexpr int AROW32 = 32 * GR * 4;        // floats between the two row tiles of a wave
 
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -133,27 +141,27 @@ __global__ __launch_bounds__(256, (GCfg<KB, ST>::kBlocksPerCU)) void gemm_dma_ke
     // Fragment double buffering is PINNED with sched_barrier(0): left alone, the scheduler funnels both fragment sets through
     // one register set (load -> wait -> 16 MFMAs -> load -> wait ...), exposing an LDS round trip per 8-channel group.
     auto compute = [&](const float *S) {
-        f32x4_t af[2][2], bf[2][2];
+        f32x4_t af[2][WT], bf[2][WT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const f32x4_t *>(S + aoff[0] + i * AROW32);
+        for (int i = 0; i < WT; ++i) af[0][i] = *reinterpret_cast<const f32x4_t *>(S + aoff[0] + i * AROW32);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[0][j] = *reinterpret_cast<const f32x4_t *>(S + boff + j * (256 * KB));
+        for (int j = 0; j < WT; ++j) bf[0][j] = *reinterpret_cast<const f32x4_t *>(S + boff + j * (256 * KB));
 #pragma unroll
         for (int g = 0; g < KB; ++g) {
             const int cur = g & 1, nxt = cur ^ 1;
             if (g + 1 < KB) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[nxt][i] = *reinterpret_cast<const f32x4_t *>(S + aoff[g + 1 < KB ? g + 1 : 0] + i * AROW32);
+                for (int i = 0; i < WT; ++i) af[nxt][i] = *reinterpret_cast<const f32x4_t *>(S + aoff[g + 1 < KB ? g + 1 : 0] + i * AROW32);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4_t *>(S + boff + j * (256 * KB) + (g + 1) * 256);
+                for (int j = 0; j < WT; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4_t *>(S + boff + j * (256 * KB) + (g + 1) * 256);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < WT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -198,9 +206,9 @@ __global__ __launch_bounds__(256, (GCfg<KB, ST>::kBlocksPerCU)) void gemm_dma_ke
         const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
         const bool vec = (p.N & 3) == 0;
 #pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-            const int i = tl >> 1, j = tl & 1;
-            const int rbase = m0 + (wm * 2 + i) * 32, cbase = n0 + (wn * 2 + j) * 32;
+        for (int tl = 0; tl < WT * WT; ++tl) {
+            const int i = tl / WT, j = tl % WT;
+            const int rbase = m0 + (wm * WT + i) * 32, cbase = n0 + (wn * WT + j) * 32;
             if (vec) {
                 const int col = cbase + 4 * tq;
                 const bool cok = col < p.N;
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256, (GCfg<KB, ST>::kBlocksPerCU)) void gemm_dma_ke
                 }
             }
         }
-    } else {
+    } else if constexpr (WT == 2) {
         // d = (|z|^2 + |e|^2) - 2 z.e ; first-min over this block's 128 columns, per row (femasr_arch.py:35-38,63-66).
         float *red = smem;   // [2 (wn)][128 rows][2]  (2 KB)
 #pragma unroll
@@ -304,12 +312,14 @@ struct GVariant {
     unsigned long long attr_devs;       // bit d: MaxDynamicSharedMemorySize set on device d
 };
 
-#define G_VARIANT(KB, ST, ACT, NRES, VQ) { "gemm_dma<128x128x" #KB "*8,stages=" #ST ",act=" #ACT ",nres=" #NRES ",vq=" #VQ ">", \
-                                            gemm_dma_kernel<KB, ST, ACT, NRES, VQ>, GCfg<KB, ST>::kLdsBytes, 0ull }
-#define G_CFG(KB, ST) G_VARIANT(KB, ST, 0, 0, false), G_VARIANT(KB, ST, 0, 1, false), G_VARIANT(KB, ST, 0, 2, false), \
-                      G_VARIANT(KB, ST, 1, 0, false), G_VARIANT(KB, ST, 1, 1, false), G_VARIANT(KB, ST, 1, 2, false), G_VARIANT(KB, ST, 0, 0, true)
-GVariant g_gv[] = { G_CFG(4, 2), G_CFG(2, 3) };
+#define G_VARIANT(WT, KB, ST, ACT, NRES, VQ) { "gemm_dma<tile=64*" #WT ",k=8*" #KB ",stages=" #ST ",act=" #ACT ",nres=" #NRES ",vq=" #VQ ">", \
+                                                gemm_dma_kernel<WT, KB, ST, ACT, NRES, VQ>, GCfg<WT, KB, ST>::kLdsBytes, 0ull }
+#define G_CFG(WT, KB, ST, VQ) G_VARIANT(WT, KB, ST, 0, 0, false), G_VARIANT(WT, KB, ST, 0, 1, false), G_VARIANT(WT, KB, ST, 0, 2, false), \
+                              G_VARIANT(WT, KB, ST, 1, 0, false), G_VARIANT(WT, KB, ST, 1, 1, false), G_VARIANT(WT, KB, ST, 1, 2, false), \
+                              G_VARIANT(WT, KB, ST, 0, 0, VQ)
+GVariant g_gv[] = { G_CFG(2, 4, 2, true), G_CFG(2, 2, 3, true), G_CFG(1, 4, 2, false) };     // (the 64 x 64 configuration has no VQ form: slot unused)
 constexpr int kPerCfg = 7;
+constexpr int kTileOf[] = { 128, 128, 64 };
 constexpr int kNumG = sizeof(g_gv) / sizeof(g_gv[0]);
 int g_cfg = -1;          // -1: not read yet, -2: automatic, 0 / 1: forced by FEMASR_GEMM_CFG (A/B runs)
 
@@ -334,6 +344,17 @@ bool femasr_gemm_eligible(const femasr_conv_args *a)
 }
 
 int femasr_gemm_variant_count() { return kNumG; }
+
+extern "C" int femasr_gemm_force_config(int cfg)
+{
+    if (g_cfg == -1) {
+        const char *e = getenv("FEMASR_GEMM_CFG");
+        g_cfg = e ? atoi(e) : -2;
+    }
+    const int prev = g_cfg;
+    g_cfg = (cfg >= 0 && cfg < kNumG / kPerCfg) ? cfg : -2;
+    return prev;
+}
 const char *femasr_gemm_variant_name(int v) { return (v >= 0 && v < kNumG) ? g_gv[v].name : "?"; }
 
 int femasr_repack_k1(hipStream_t s, const float *in, int O, int I, float *out)
@@ -358,10 +379,11 @@ int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_e
     GemmParams p{};
     p.A = a->in; p.W = a->w; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
     p.M = (int)M; p.N = a->Cout; p.K = a->Cin; p.nchunks = a->Cin / 32;
-    p.MB = (p.M + G_BM - 1) / G_BM; p.NB = (p.N + G_BN - 1) / G_BN; p.NT32 = (p.N + 31) / 32;
+    p.NT32 = (p.N + 31) / 32;
+    const int mb128 = (p.M + 127) / 128, nb128 = (p.N + 127) / 128;
     int vi;
     if (vq) {
-        FEMASR_REQUIRE(vq->zz && vq->ee && vq->part && vq->nblk == p.NB && (a->Cout % 32) == 0, "vq epilogue: bad args");
+        FEMASR_REQUIRE(vq->zz && vq->ee && vq->part && vq->nblk == nb128 && (a->Cout % 32) == 0, "vq epilogue: bad args");
         p.vq_zz = vq->zz; p.vq_ee = vq->ee; p.vq_part = vq->part; p.vq_nblk = vq->nblk;
         vi = 6;
     } else {
@@ -369,18 +391,25 @@ int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_e
         vi = (a->act == FEMASR_ACT_GELU ? 3 : 0) + nres;
     }
     if (g_cfg == -1) {
-        const char *e = getenv("FEMASR_GEMM_CFG");          // A/B runs: force one pipeline configuration
+        const char *e = getenv("FEMASR_GEMM_CFG");          // A/B runs: force one configuration
         g_cfg = e ? atoi(e) : -2;
         if (g_cfg >= kNumG / kPerCfg) g_cfg = -2;
     }
-    // Pipeline configuration by tile count: all tiles cost the same, so a launch takes ceil(tiles / resident slots) rounds.
-    // <4,2> (32-deep chunks, 2 blocks per CU) unless the 3-blocks-per-CU configuration <2,3> wastes less of its last round.
+    // Configuration by tile count.  All tiles of a launch cost the same, so it takes ceil(tiles / resident slots) rounds:
+    //   * fewer 128 x 128 tiles than FEMASR_GEMM_SMALL_TILES (small batches: B = 1 has 82 of them for proj / fc2 on 256 CUs,
+    //     each a serial chain of K/2 MFMAs per wave): 64 x 64 tiles - 4x the blocks, a quarter of the chain each;
+    //   * otherwise <4,2> (32-deep chunks, 2 blocks per CU) unless the 3-blocks-per-CU configuration <2,3> wastes less of its
+    //     last round.
     int cfg = g_cfg;
-    if (cfg < 0) {
-        const double tiles = (double)p.MB * p.NB;
+    if (cfg < 0 || (vq && cfg == 2)) {
+        const double tiles = (double)mb128 * nb128;
         auto eff = [&](double slots) { const double r = tiles / slots; return r / (double)(long long)(r + 0.999999); };
-        cfg = eff(768.0) > eff(512.0) + 0.02 ? 1 : 0;
+        static int small_tiles = -1;
+        if (small_tiles < 0) { const char *e = getenv("FEMASR_GEMM_SMALL_TILES"); small_tiles = e ? atoi(e) : 700; }
+        cfg = (!vq && tiles < (double)small_tiles) ? 2 : (eff(768.0) > eff(512.0) + 0.02 ? 1 : 0);
     }
+    const int bt = kTileOf[cfg];
+    p.MB = (p.M + bt - 1) / bt; p.NB = (p.N + bt - 1) / bt;
     vi += cfg * kPerCfg;
     GVariant &v = g_gv[vi];
     int dev = 0;

@@ -282,6 +282,16 @@ int femasr_image_f32_to_u8(void *stream, const float *in_chw, int H, int W, int 
  * region: the network's kernels are clock-bound, so a throttling box shows up here and not as a kernel regression). */
 #define FEMASR_CLOCK_PROBE_BLOCKS 256
 int femasr_clock_probe(void *stream, int mfmas_per_wave, unsigned long long *ticks);
+/* Tuning / test hook of the 1x1-conv and linear GEMM (kernels_gemm.hip): force one block configuration for every later launch -
+ * 0: 128x128 tiles, 32-deep chunks, 2 stages;  1: 128x128, 16-deep, 3 stages;  2: 64x64 tiles (what small launches get);
+ * any negative value: automatic choice by tile count (the default).  Results are bit-identical in every configuration (each
+ * output is the same fmaf chain); the parity tests run all of them.  Returns the previous setting (negative = automatic). */
+int femasr_gemm_force_config(int cfg);
+/* Same kind of hook for the 3x3 / strided convs with more than 64 output channels: a launch of fewer than `blocks` 128-column
+ * blocks runs with 64-column blocks instead (twice the blocks, half the serial chain each: batch-1 latency).  0 = never,
+ * negative = the default (384).  Bit-identical either way (same weights layout, same per-wave pixel tiles, same GroupNorm
+ * partial-moment order).  Returns the previous threshold. */
+int femasr_conv_small_launch_blocks(int blocks);
 
 #ifdef __cplusplus
 }

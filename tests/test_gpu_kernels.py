@@ -64,8 +64,22 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture
+def conv_small(request):
+    """Threshold of the small-launch rule of the convs (femasr_conv_small_launch_blocks): 0 = 128-column blocks as for the big
+    launches, -1 = the default (small launches take 64-column blocks)."""
+    lib = _lib.load()
+    prev = lib.femasr_conv_small_launch_blocks(request.param)
+    yield request.param
+    lib.femasr_conv_small_launch_blocks(prev)
+
+
+CONV_SMALL = pytest.mark.parametrize('conv_small', [0, -1], indirect=True, ids=['bn128', 'small_launch_bn64'])
+
+
+@CONV_SMALL
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_bit_exact(cuda_device, case):
+def test_conv_bit_exact(cuda_device, case, conv_small):
     import gpu_utils as G
     name, shp, cout, k, s, p, up = case
     x = synth.uniform(1, name + 'x', shp, -1.5, 1.5)
@@ -74,8 +88,9 @@ def test_conv_bit_exact(cuda_device, case):
     _same(G.conv2d(x, w, b, k, s, p, up), orc.conv2d(x, w, b, k, s, p, up), name)
 
 
+@CONV_SMALL
 @pytest.mark.parametrize('cin,cout', [(256, 256), (128, 128), (64, 64), (64, 3), (128, 64)])
-def test_conv_gn_silu_prologue_and_residuals(cuda_device, cin, cout):
+def test_conv_gn_silu_prologue_and_residuals(cuda_device, cin, cout, conv_small):
     """ResBlock conv: GroupNorm-apply + SiLU fused on load, bias + two residual adds fused on store."""
     import gpu_utils as G
     x = synth.uniform(2, 'gx', (2, 13, 10, cin), -3, 4)
@@ -106,8 +121,21 @@ def test_gn_moments_large_and_offset(cuda_device):
     _same(bb, b_ref, 'gn b (offset)')
 
 
+@pytest.fixture
+def gemm_cfg(request):
+    """Force one block configuration of the LDS-DMA GEMM (femasr_gemm_force_config); -1 = the automatic choice."""
+    lib = _lib.load()
+    prev = lib.femasr_gemm_force_config(request.param)
+    yield request.param
+    lib.femasr_gemm_force_config(prev)
+
+
+GEMM_CFGS = pytest.mark.parametrize('gemm_cfg', [-1, 0, 1, 2], indirect=True, ids=['auto', '128x128_k32', '128x128_k16', '64x64'])
+
+
+@GEMM_CFGS
 @pytest.mark.parametrize('cout,act', [(768, 0), (1024, 1), (256, 0)])
-def test_linear_ln_prologue_gelu(cuda_device, cout, act):
+def test_linear_ln_prologue_gelu(cuda_device, cout, act, gemm_cfg):
     """Swin linears: LayerNorm pass (norm1 / norm2) -> LDS-DMA GEMM (qkv / fc1), exact-erf GELU + residual on store."""
     import gpu_utils as G
     rows = 300
@@ -126,7 +154,8 @@ def test_linear_ln_prologue_gelu(cuda_device, cout, act):
     _same(got.reshape(rows, cout), ref, f'linear ln cout={cout} act={act}')
 
 
-def test_linear_k1024(cuda_device):
+@GEMM_CFGS
+def test_linear_k1024(cuda_device, gemm_cfg):
     import gpu_utils as G
     rows = 200
     x = synth.uniform(5, 'fx', (rows, 1024), -1, 1)
@@ -135,6 +164,22 @@ def test_linear_k1024(cuda_device):
     res = synth.uniform(5, 'fr', (rows, 256), -1, 1)
     got = G.conv2d(x.reshape(1, rows, 1, 1024), w.reshape(1, 1, 1024, 256), bias, 1, res1=res.reshape(1, rows, 1, 256))
     _same(got.reshape(rows, 256), orc.linear(x, w, bias, res=res), 'fc2')
+
+
+@GEMM_CFGS
+@pytest.mark.parametrize('n,k', [(96, 64), (160, 32)])
+def test_linear_ragged_columns_all_configs(cuda_device, n, k, gemm_cfg):
+    """N not a multiple of the block tile (64 / 128) nor of the packed 32-column tiles' pair; M with a ragged last row tile."""
+    import gpu_utils as G
+    rows = 77 + 64 * 3
+    x = synth.uniform(8, 'rx', (rows, k), -1, 1)
+    w = synth.uniform(8, 'rw', (k, n), -0.2, 0.2)
+    bias = synth.uniform(8, 'rb', (n,), -0.5, 0.5)
+    r1 = synth.uniform(8, 'rr1', (rows, n), -1, 1)
+    r2 = synth.uniform(8, 'rr2', (rows, n), -1, 1)
+    got = G.conv2d(x.reshape(1, rows, 1, k), w.reshape(1, 1, k, n), bias, 1, res1=r1.reshape(1, rows, 1, n), res2=r2.reshape(1, rows, 1, n))
+    ref = orc.linear(x, w, bias, res=r1) + r2
+    _same(got.reshape(rows, n), ref, f'ragged linear n={n} k={k}')
 
 
 @pytest.mark.parametrize('shift', [0, 4])
@@ -237,7 +282,8 @@ def test_conv_bf16x3_fused_gn_moments(cuda_device, cin, cout, shape, up):
 @pytest.mark.parametrize('cin,cout,shape,up,nres', [(64, 64, (2, 20, 33), False, 1), (128, 128, (1, 13, 10), False, 2),
                                                     (256, 256, (1, 9, 12), True, 0), (128, 64, (1, 7, 9), True, 0),
                                                     (64, 32, (1, 17, 40), False, 0), (32, 512, (1, 8, 16), False, 1)])
-def test_conv_fp32_fused_gn_moments_bit_exact(cuda_device, cin, cout, shape, up, nres):
+@CONV_SMALL
+def test_conv_fp32_fused_gn_moments_bit_exact(cuda_device, cin, cout, shape, up, nres, conv_small):
     """The exact-fp32 halo conv emits per-tile GroupNorm partial moments of its output in the specified summation order:
     finalising them gives bit-for-bit the oracle's (a, b) of that output, and so does the standalone moments kernel."""
     import gpu_utils as G
@@ -270,7 +316,8 @@ def test_conv_fp32_fused_gn_moments_bit_exact(cuda_device, cin, cout, shape, up,
 
 @pytest.mark.parametrize('cin,cout,shape,nres', [(32, 64, (1, 8, 16), 0), (64, 96, (2, 11, 19), 1), (128, 40, (1, 5, 33), 2),
                                                  (256, 128, (1, 16, 16), 0), (64, 3, (1, 9, 7), 0)])
-def test_conv_up2_phase_filters_bit_exact(cuda_device, cin, cout, shape, nres):
+@CONV_SMALL
+def test_conv_up2_phase_filters_bit_exact(cuda_device, cin, cout, shape, nres, conv_small):
     """nn.Upsample(x2, nearest) + 3x3 conv as four 2x2-tap phase filters with pre-summed fp32 weights: bit-identical to the
     oracle's restatement of the same form, and within fp32 rounding of the 9-tap definition on the upsampled image."""
     import gpu_utils as G
