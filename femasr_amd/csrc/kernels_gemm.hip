@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, (GCfg<WT, KB, ST>::kBlocksPerCU)) void gemm_dm
     constexpr int PP = WT * KB / 2;            // DMA pieces per wave, stage and operand (the tile has 2 WT KB pieces of 1 KiB)
     constexpr int PW = 2 * PP;                 // DMA pieces per wave and stage
     static_assert(KB == 2 || KB == 4, "chunk depth");
-    static_assert(ST == 2 || ST == 3, "stages");
+    static_assert(ST >= 2 && ST <= 4, "stages");
     static_assert(WT == 2 || (WT == 1 && KB == 4), "block tile");
     static_assert(!VQ || WT == 2, "the VQ epilogue reduces over 128-column blocks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256, (GCfg<WT, KB, ST>::kBlocksPerCU)) void gemm_dm
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nch = p.K / (8 * KB);
-    issue(0, 0);
-    issue(1, nch > 1 ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < (ST == 2 ? 2 : ST - 1); ++i) issue(i, i < nch ? i : nch - 1);
 
     // Fragment double buffering is PINNED with sched_barrier(0): left alone, the scheduler funnels both fragment sets through
     // one register set (load -> wait -> 16 MFMAs -> load -> wait ...), exposing an LDS round trip per 8-channel group.
@@ -180,17 +180,19 @@ __global__ __launch_bounds__(256, (GCfg<WT, KB, ST>::kBlocksPerCU)) void gemm_dm
             issue(c & 1, cn);                                     // surplus copies at the end land in a dead stage
         }
     } else {
-        int sc = 0, sn = 2;                                       // stage of chunk c / of chunk c+2
+        // ST >= 3: chunk c + ST-1 is issued at the START of chunk c (into the stage chunk c-1 just left): ST-2 chunks stay in
+        // flight under the MFMAs of chunk c, one barrier per chunk
+        int sc = 0, sn = ST - 1;                                  // stage of chunk c / of chunk c + ST-1
         for (int c = 0; c < nch; ++c) {
-            if constexpr (PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ST - 2) * PW) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the previous chunk's fragment reads have returned)
             __builtin_amdgcn_s_barrier();                         // chunk c landed everywhere; stage of chunk c-1 is free everywhere
             asm volatile("" ::: "memory");
-            const int cn = c + 2 < nch ? c + 2 : nch - 1;
-            issue(sn, cn);                                        // chunk c+2 -> the stage chunk c-1 used
+            const int cn = c + ST - 1 < nch ? c + ST - 1 : nch - 1;
+            issue(sn, cn);
             compute(smem + sc * C::kStage);
-            sc = sc == 2 ? 0 : sc + 1;
-            sn = sn == 2 ? 0 : sn + 1;
+            sc = sc == ST - 1 ? 0 : sc + 1;
+            sn = sn == ST - 1 ? 0 : sn + 1;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may still be writing LDS when the epilogue re-uses it
@@ -317,7 +319,10 @@ struct GVariant {
 #define G_CFG(WT, KB, ST, VQ) G_VARIANT(WT, KB, ST, 0, 0, false), G_VARIANT(WT, KB, ST, 0, 1, false), G_VARIANT(WT, KB, ST, 0, 2, false), \
                               G_VARIANT(WT, KB, ST, 1, 0, false), G_VARIANT(WT, KB, ST, 1, 1, false), G_VARIANT(WT, KB, ST, 1, 2, false), \
                               G_VARIANT(WT, KB, ST, 0, 0, VQ)
-GVariant g_gv[] = { G_CFG(2, 4, 2, true), G_CFG(2, 2, 3, true), G_CFG(1, 4, 2, false) };     // (the 64 x 64 configuration has no VQ form: slot unused)
+// (the 64 x 64 configuration has no VQ form: slot unused.  Measured and dropped again: 64 x 64 with 3 / 4 stages and 128 x 128 with
+// four 16-deep stages - G_CFG(1, 4, 3) / (1, 4, 4) / (2, 2, 4) - are within +-3 % of these at every batch size: prefetch depth is
+// not what bounds the kernel)
+GVariant g_gv[] = { G_CFG(2, 4, 2, true), G_CFG(2, 2, 3, true), G_CFG(1, 4, 2, false) };
 constexpr int kPerCfg = 7;
 constexpr int kTileOf[] = { 128, 128, 64 };
 constexpr int kNumG = sizeof(g_gv) / sizeof(g_gv[0]);
@@ -398,15 +403,22 @@ int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_e
     // Configuration by tile count.  All tiles of a launch cost the same, so it takes ceil(tiles / resident slots) rounds:
     //   * fewer 128 x 128 tiles than FEMASR_GEMM_SMALL_TILES (small batches: B = 1 has 82 of them for proj / fc2 on 256 CUs,
     //     each a serial chain of K/2 MFMAs per wave): 64 x 64 tiles - 4x the blocks, a quarter of the chain each;
+    //   * (FEMASR_GEMM_TAIL_PCT=90, off by default: 64 x 64 tiles also where 128 x 128 tiles would leave > 10 % of their last
+    //     round empty - proj / fc2 at B = 16, 2.53 rounds of 512.  Stand-alone that wins, proj 119 -> 103 us, fc2 399 -> 381 us;
+    //     in the network the second sub-batch stream already fills those tails and the step gets 0.4 ms SLOWER: 79.65 vs 79.27.)
     //   * otherwise <4,2> (32-deep chunks, 2 blocks per CU) unless the 3-blocks-per-CU configuration <2,3> wastes less of its
     //     last round.
     int cfg = g_cfg;
-    if (cfg < 0 || (vq && cfg == 2)) {
+    if (cfg < 0 || (vq && kTileOf[cfg] != 128)) {
         const double tiles = (double)mb128 * nb128;
         auto eff = [&](double slots) { const double r = tiles / slots; return r / (double)(long long)(r + 0.999999); };
         static int small_tiles = -1;
         if (small_tiles < 0) { const char *e = getenv("FEMASR_GEMM_SMALL_TILES"); small_tiles = e ? atoi(e) : 700; }
-        cfg = (!vq && tiles < (double)small_tiles) ? 2 : (eff(768.0) > eff(512.0) + 0.02 ? 1 : 0);
+        static int tail_pct = -1;             // 128 x 128 tiles whose last round would be emptier than this also go to 64 x 64 tiles
+        if (tail_pct < 0) { const char *e = getenv("FEMASR_GEMM_TAIL_PCT"); tail_pct = e ? atoi(e) : 0; }
+        const double e2 = eff(512.0), e3 = eff(768.0);
+        const bool small = tiles < (double)small_tiles || (e2 > e3 ? e2 : e3) * 100.0 < (double)tail_pct;
+        cfg = (!vq && small) ? 2 : (e3 > e2 + 0.02 ? 1 : 0);
     }
     const int bt = kTileOf[cfg];
     p.MB = (p.M + bt - 1) / bt; p.NB = (p.N + bt - 1) / bt;
