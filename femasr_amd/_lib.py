@@ -94,6 +94,8 @@ SIGNATURES = {
     'femasr_up2_weight_floats': (szt, [c_int, c_int]),
     'femasr_wino_weight_floats': (szt, [c_int, c_int]),
     'femasr_repack_oihw_wino': (c_int, [vp, vp, c_int, c_int, vp]),
+    'femasr_wino_up2_weight_floats': (szt, [c_int, c_int]),
+    'femasr_repack_oihw_wino_up2': (c_int, [vp, vp, c_int, c_int, vp]),
     'femasr_repack_oihw_up2': (c_int, [vp, vp, c_int, c_int, vp]),
     'femasr_packed_weight_bf16x3_bytes': (szt, [c_int, c_int, c_int, c_int]),
     'femasr_repack_oihw_bf16x3': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),

@@ -57,6 +57,10 @@ int femasr_conv_wino_gn_tiles(int H, int W);      // fused GroupNorm partials of
 int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out);
 int femasr_conv_wino_variant_count();
 const char *femasr_conv_wino_variant_name(int v);
+// nn.Upsample(x2) + 3x3 conv in the 25-product Winograd-type form (kernels_wino_up2.hip); GroupNorm partials per 16x16 OUTPUT sub-block
+bool femasr_conv_wino_up2_shape_ok(const femasr_conv_args *a);
+int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double *flops_out);
+const char *femasr_conv_wino_up2_variant_name();
 
 // bf16x3 3x3 halo convs (kernels_conv_bf16.hip)
 bool femasr_conv_bf16x3_eligible(const femasr_conv_args *a);

@@ -1001,6 +1001,10 @@ int femasr_conv2d(void *stream, const femasr_conv_args *a)
         FEMASR_REQUIRE(femasr_conv_bf16x3_eligible(a), "conv2d: w_bf16x3 given but the layer is not eligible for the bf16x3 path");
         return femasr_conv_bf16x3_launch((hipStream_t)stream, a, nullptr, nullptr);
     }
+    if (a && a->w_wino && a->up2) {
+        FEMASR_REQUIRE(femasr_conv_wino_up2_shape_ok(a), "conv2d: w_wino given with up2 but the layer is not a 3x3 stride-1 pad-1 conv with Cin %% 32 == 0, Cout %% 64 == 0, no prologue");
+        return femasr_conv_wino_up2_launch((hipStream_t)stream, a, nullptr);
+    }
     if (a && a->w_wino) {
         FEMASR_REQUIRE(femasr_conv_wino_shape_ok(a), "conv2d: w_wino given but the layer is not a 3x3 stride-1 pad-1 conv with Cin %% 32 == 0, Cout %% 64 == 0");
         return femasr_conv_wino_launch((hipStream_t)stream, a, nullptr, nullptr);

@@ -1,0 +1,430 @@
+// kernels_wino_up2.hip — nn.Upsample(x2, nearest) + 3x3 stride-1 pad-1 conv (femasr_arch.py:172-173,202-203) in a
+// Winograd-type minimal form on the fp32 matrix cores: 25 multiplies per 4x4 outputs.
+//
+// A 4x4 tile of the OUTPUT (upsampled grid) reads a 6x6 patch of the upsampled image, i.e. only a 4x4 patch of the
+// low-resolution input: per dimension d = (l0, l1, l1, l2, l2, l3).  Put through the F(4,3) input transform B^T that gives
+//     r0 = 4 l0 - 5 l1 + l2,   r1 = 2 (l2 - 4 l1),   r2 = 0,   r3 = 3 (l2 - l1),   r4 = -(l2 - l1),   r5 = 4 l1 - 5 l2 + l3
+// - one component vanishes and two are proportional, so per dimension FIVE products are enough for four outputs:
+//     v0 = fma(4, l0, fma(-5, l1, l2))   v1 = fma(-4, l1, l2)   v3 = l2 - l1   v5 = fma(4, l1, fma(-5, l2, l3))
+//     e0 = g0/4   e1 = -((g0 + g1) + g2)/3   eP = fma(4, g2, fma(4, g1, g0))/12   eQ = fma(4, g2, g0 + g1)/6   e5 = g2
+//     m0 = e0 v0,  m1 = e1 v1,  mP = eP v3,  mQ = eQ v3,  m5 = e5 v5          (each summed over the input channels)
+//     y0 = (m0 + m1) + mP    y1 = fma(2, mQ, m1)    y2 = fma(4, mP, m1)    y3 = fma(8, mQ, m1) + m5
+// (the constants 2, 3 and -1 of r1, r3, r4 are folded into the filters).  In 2-D: 25 products per 16 outputs and channel
+// pair where the phase-filter form of kernels_conv.hip needs 64 and the definition 144.  Like the F(4x4,3x3) kernel this is
+// only used behind the codebook lookup of single-codebook networks; all fp32, every value one fixed sequence of IEEE
+// operations restated by oracle/femasr_oracle.c orc_conv_up2_winograd.
+//
+// Structure = kernels_wino.hip (read its header first): block = 8 waves, two 16x16-pixel OUTPUT sub-blocks (= 2 x 16 tiles =
+// one 32-row MFMA tile) x 64 output channels, K in steps of 8 input channels, every wave M phase then T phase, one barrier
+// per step.  What differs:
+//   staging   the 10x10 low-resolution patch of a sub-block (8x8 + halo), plain copy (these convs have no GN prologue)
+//   T phase   thread = (tile, channel, half): 12 LDS reads -> 8 of the 16 DISTINCT transformed values V[4][4] (components P and
+//             Q share v3): V[16][32 tiles][8 channels]
+//   M phase   50 (component, 32-column tile) pairs: wave w owns column tile w&1 of components w/2 + 4q, q = 0..5 (waves 0, 1
+//             also q = 6): 13 / 13 / 12 / 12 pairs per SIMD
+//   epilogue  Mx[25][32][32] per column tile, thread = (tile, channel) applies the 5 -> 4 output transform twice
+#include "conv_common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct WinoUpParams {
+    const float *in, *u, *bias, *res1, *res2;
+    float *out;
+    double *gn_part;
+    int B, H, W, Cin, Cout, Ho, Wo;     // H, W: low-resolution input; Ho = 2H, Wo = 2W
+    int sbX, sbY, nsb;                  // 16x16-pixel output sub-blocks per row / per column / in the batch
+    int MB, NB, nsteps, NT32;
+};
+
+constexpr int WU_NT = 512;
+constexpr int WU_PS = 12;                         // floats per patch pixel: 8 channels + 4
+constexpr int WU_PW = 10;
+constexpr int WU_PPIX = WU_PW * WU_PW;            // 100
+constexpr int WU_PSZ = 2 * WU_PPIX * WU_PS;       // floats per patch buffer (two sub-blocks): 2400
+constexpr int WU_VSZ = 16 * 32 * 8;               // floats per V buffer: 4096
+constexpr int WU_MAIN = 2 * WU_PSZ + 2 * WU_VSZ;
+constexpr int WU_MX = 25 * 32 * 32;               // epilogue: one 32-column tile of all components
+constexpr int WU_RED = 8 * 2 * 16 * 2 * 2;        // floats: [8 waves][2 sub-blocks][<= 16 groups][2] doubles
+constexpr int WU_UNITS = 2 * WU_PPIX * 2;         // float4 staging units per step: 400
+
+inline size_t wino_up_lds_bytes() { return (size_t)((WU_MX + WU_RED) > WU_MAIN ? (WU_MX + WU_RED) : WU_MAIN) * sizeof(float); }
+
+// output rows of the 5 -> 4 transform (see the header)
+__device__ __forceinline__ void at5(float m0, float m1, float mP, float mQ, float m5, float &y0, float &y1, float &y2, float &y3)
+{
+    y0 = (m0 + m1) + mP;
+    y1 = __builtin_fmaf(2.0f, mQ, m1);
+    y2 = __builtin_fmaf(4.0f, mP, m1);
+    y3 = __builtin_fmaf(8.0f, mQ, m1) + m5;
+}
+
+__global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUpParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ps = smem;                        // [2][WU_PSZ]
+    float *Vs = smem + 2 * WU_PSZ;           // [2][WU_VSZ]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c31 = lane & 31, hh = lane >> 5;
+    const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
+    const int nb = L % p.NB, mb = L / p.NB;
+    const int n0 = nb * 64;
+
+    // ---- the two output sub-blocks (uniform)
+    int sn[2], sy0[2], sx0[2], sbi[2];
+    bool sval[2];
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+        const int sb = 2 * mb + z, per = p.sbY * p.sbX;
+        sval[z] = sb < p.nsb;
+        const int sbc = sval[z] ? sb : 0;
+        sn[z] = sbc / per;
+        sbi[z] = sbc - sn[z] * per;
+        const int by = sbi[z] / p.sbX, bx = sbi[z] - by * p.sbX;
+        sy0[z] = 16 * by;
+        sx0[z] = 16 * bx;
+    }
+
+    // ---- staging unit of this thread (threads 0..399): (sub-block z, pixel of its 10x10 low-resolution patch, channel quad)
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void *)(p.in + (size_t)sn[0] * p.H * p.W * p.Cin), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, 0x7fffffff, 0x00020000);
+    unsigned goff = 0xffffffffu;             // beyond num_records: the load returns zeros (padding, invalid sub-block, idle threads)
+    int sdst = 0;
+    {
+        const int z = t >= 2 * WU_PPIX ? 1 : 0, r = t - 2 * WU_PPIX * z;
+        const int pix = r >> 1, quad = r & 1;
+        const int py = pix / WU_PW, px = pix - py * WU_PW;
+        const int y = ((z ? sy0[1] : sy0[0]) >> 1) - 1 + py, x = ((z ? sx0[1] : sx0[0]) >> 1) - 1 + px;
+        const bool ok = t < WU_UNITS && (z ? sval[1] : sval[0]) && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        if (ok) goff = (unsigned)((((size_t)(z ? sn[1] - sn[0] : 0) * p.H + y) * p.W + x) * p.Cin + 4 * quad) * 4u;
+        sdst = (z * WU_PPIX + pix) * WU_PS + 4 * quad;
+    }
+    f32x4_t rp;
+    auto load_patch = [&](int s) {           // unconditional (steps past the end re-read the last one): the wait counters stay static
+        const int sc = s < p.nsteps ? s : p.nsteps - 1;
+        rp = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff, sc * 32, 0));
+    };
+    auto store_patch = [&](int buf) {
+        if (t < WU_UNITS) *reinterpret_cast<f32x4_t *>(Ps + buf * WU_PSZ + sdst) = rp;
+    };
+
+    // ---- input transform item: (tile tm, channel tch); waves 0-3 produce the rows v0, v1 of the column pass, waves 4-7 v3, v5
+    // (w and w+4 share a SIMD: each SIMD carries both halves)
+    const int thalf = wave >> 2;
+    const int titem = (wave & 3) * 64 + lane;
+    const int tm = titem >> 3, tch = titem & 7;
+    // patch rows 2 ety + thalf .. + 2, columns 2 etx .. 2 etx + 3 of sub-block tm >> 4
+    const int tsrc = (tm >> 4) * WU_PPIX * WU_PS + ((2 * ((tm & 15) >> 2) + thalf) * WU_PW + 2 * (tm & 3)) * WU_PS + tch;
+    const int tdst = thalf * 8 * 256 + tm * 8 + (tch & 1) * 4 + (tch >> 1);
+    float td[3][4];
+    auto transform_read = [&](int pbuf) {
+        const float *src = Ps + pbuf * WU_PSZ + tsrc;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) td[a][b] = src[(a * WU_PW + b) * WU_PS];
+    };
+    auto transform_write = [&](int vbuf) {
+        float *dst = Vs + vbuf * WU_VSZ + tdst;
+        float r[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (thalf == 0) {        // rows l0, l1, l2 -> v0, v1
+                r[0][b] = __builtin_fmaf(4.0f, td[0][b], __builtin_fmaf(-5.0f, td[1][b], td[2][b]));
+                r[1][b] = __builtin_fmaf(-4.0f, td[1][b], td[2][b]);
+            } else {                 // rows l1, l2, l3 -> v3, v5
+                r[0][b] = td[1][b] - td[0][b];
+                r[1][b] = __builtin_fmaf(4.0f, td[0][b], __builtin_fmaf(-5.0f, td[1][b], td[2][b]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float *o = dst + i * 4 * 256;
+            o[0 * 256] = __builtin_fmaf(4.0f, r[i][0], __builtin_fmaf(-5.0f, r[i][1], r[i][2]));
+            o[1 * 256] = __builtin_fmaf(-4.0f, r[i][1], r[i][2]);
+            o[2 * 256] = r[i][2] - r[i][1];
+            o[3 * 256] = __builtin_fmaf(4.0f, r[i][1], __builtin_fmaf(-5.0f, r[i][2], r[i][3]));
+        }
+    };
+
+    // ---- M phase: pair q of wave w = (component w/2 + 4 q, column tile w & 1); q = 6 only exists for waves 0 and 1
+    f32x16 acc[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const unsigned lw = (unsigned)lane * 16u;
+    const int aoff = c31 * 8 + hh * 4;
+    const int wcomp0 = wave >> 1, wnt = wave & 1;
+    const bool has6 = wave < 2;
+    auto pcomp = [&](int q) -> int { const int c = wcomp0 + 4 * q; return c < 25 ? c : 24; };             // (clamped: the surplus load of waves 2-7 is never used)
+    auto vcomp = [&](int q) -> int {           // component (i, j) of [0, 1, P, Q, 5]^2 -> distinct transformed value (P and Q share v3)
+        const int c = pcomp(q), i = c / 5, j = c - 5 * i;
+        return ((i > 2 ? i - 1 : i) << 2) + (j > 2 ? j - 1 : j);
+    };
+    auto ldU = [&](int s, int q) -> f32x4_t {  // unconditional, like load_patch
+        const int sc = s < p.nsteps ? s : p.nsteps - 1;
+        return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, lw, (((sc * 25 + pcomp(q)) * p.NT32 + 2 * nb + wnt) << 10), 0));
+    };
+    // U fragments: ring = pairs 0-2 of the NEXT step (loaded behind this step's pairs 0-2), early = pairs 3-5 (issued at the end of
+    // the T phase, in flight across the barrier), late = pair 6 (issued at the start of the M phase)
+    f32x4_t ring[3], early[3], late;
+    auto issue_early = [&](int s) {
+#pragma unroll
+        for (int q = 3; q < 6; ++q) early[q - 3] = ldU(s, q);
+    };
+    auto mphase = [&](int s) {
+        const float *Vb = Vs + (s & 1) * WU_VSZ + aoff;
+        late = ldU(s, 6);
+        f32x4_t an = *reinterpret_cast<const f32x4_t *>(Vb + vcomp(0) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const f32x4_t a = an;
+            if (q + 1 < 7) an = *reinterpret_cast<const f32x4_t *>(Vb + vcomp(q + 1) * 256);
+            const f32x4_t b = q < 3 ? ring[q] : (q < 6 ? early[q - 3] : late);
+            if (q < 6 || has6) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
+            }
+            if (q < 3) ring[q] = ldU(s + 1, q);
+            if (q == 4) load_patch(s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue
+    load_patch(0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ring[q] = ldU(0, q);
+    store_patch(0);
+    load_patch(1);
+    __syncthreads();
+    transform_read(0);
+    transform_write(0);
+    store_patch(1);
+    issue_early(0);
+    __syncthreads();
+
+    // ---- main loop: M(s), then transform step s+1 (its patch was staged during step s-1) and stage step s+2
+    for (int s = 0; s < p.nsteps; ++s) {
+        mphase(s);
+        transform_read((s + 1) & 1);          // (unconditional: after the last step it transforms a stale patch into a dead buffer)
+        __builtin_amdgcn_sched_barrier(0);
+        transform_write((s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_patch(s & 1);                   // step s+2 -> the buffer step s's transform read (all waves are past that: barrier of step s-1 ... see below)
+        issue_early(s + 1);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // epilogue: Mx[component][tile][32 channels] of one column tile at a time overlays the main-loop buffers
+    float *Mx = smem;
+    double *red = reinterpret_cast<double *>(smem + WU_MX);
+    const bool gnp = p.gn_part != nullptr;
+    const int cg = p.Cout >> 5;                      // channels per GroupNorm group (>= 2: Cout % 64 == 0)
+    const int gpt = 32 / (cg < 32 ? cg : 32);        // groups per 32-channel tile (<= 16)
+    const int tl = t >> 5;                           // tile inside the sub-block: 2 wave + hh
+    const int ety = tl >> 2, etx = tl & 3;
+    unsigned vmask[2];
+    size_t obase[2];
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+        const int oy = (z ? sy0[1] : sy0[0]) + 4 * ety, ox = (z ? sx0[1] : sx0[0]) + 4 * etx;
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m |= ((z ? sval[1] : sval[0]) && oy + (k >> 2) < p.Ho && ox + (k & 3) < p.Wo ? 1u : 0u) << k;
+        vmask[z] = m;
+        obase[z] = (m ? (((size_t)(z ? sn[1] : sn[0]) * p.Ho + oy) * p.Wo + ox) * p.Cout : (size_t)0) + n0 + c31;
+    }
+    auto eoff = [&](int k) -> unsigned { return (unsigned)((k >> 2) * p.Wo + (k & 3)) * (unsigned)p.Cout; };      // uniform
+    auto fetch = [&](const float *src, int z, int r, float (&dst)[16]) {       // branch-free batch of 16 loads
+        const float *bp = src + obase[z] + 32 * r;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dst[k] = bp[(vmask[z] >> k) & 1u ? eoff(k) : 0u];
+    };
+    auto item = [&](int z, int r, float bv, const float (&r1)[16], const float (&r2)[16]) {
+        const float *src = Mx + (z * 16 + tl) * 32 + c31;
+        float tt[4][5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            at5(src[(0 * 5 + j) * 1024], src[(1 * 5 + j) * 1024], src[(2 * 5 + j) * 1024], src[(3 * 5 + j) * 1024], src[(4 * 5 + j) * 1024],
+                tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
+        float *bo = p.out + obase[z] + 32 * r;
+        double gs = 0.0, gss = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float y[4];
+            at5(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], y[0], y[1], y[2], y[3]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int k = 4 * a + b;
+                const bool ok = (vmask[z] >> k) & 1u;
+                float v = y[b] + bv;
+                if (p.res1) v = v + r1[k];
+                if (p.res2) v = v + r2[k];
+                if (ok) bo[eoff(k)] = v;
+                if (gnp) {                                   // a masked pixel adds +0 (the oracle skips it: same sums)
+                    const double dv = ok ? (double)v : 0.0;
+                    gs = gs + dv;
+                    gss = __builtin_fma(dv, dv, gss);
+                }
+            }
+        }
+        if (gnp) {      // channels of the group (xor butterfly), the tile pair of the wave, then the 8 waves in order
+            for (int d = 1; d < cg && d < 32; d <<= 1) {
+                gs = gs + __shfl_xor(gs, d, 64);
+                gss = gss + __shfl_xor(gss, d, 64);
+            }
+            const double a2 = gs + __shfl_xor(gs, 32, 64), b2 = gss + __shfl_xor(gss, 32, 64);
+            if (lane < 32 && (c31 & (cg - 1)) == 0) {
+                double *dst = red + ((size_t)(wave * 2 + z) * 16 + c31 / cg) * 2;
+                dst[0] = a2;
+                dst[1] = b2;
+            }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (wnt == r) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                if (q < 6 || has6) {
+                    float *dst = Mx + (wcomp0 + 4 * q) * 1024 + c31;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32] = acc[q][e];
+                }
+            }
+        }
+        float ra1[16], ra2[16], rb1[16], rb2[16];          // residuals of the two items: in flight across the barrier / the first item
+        if (p.res1) fetch(p.res1, 0, r, ra1);
+        if (p.res2) fetch(p.res2, 0, r, ra2);
+        const float bv = p.bias[n0 + 32 * r + c31];
+        __syncthreads();
+        if (p.res1) fetch(p.res1, 1, r, rb1);
+        if (p.res2) fetch(p.res2, 1, r, rb2);
+        item(0, r, bv, ra1, ra2);
+        item(1, r, bv, rb1, rb2);
+        __syncthreads();
+        if (gnp && t < 2 * gpt) {
+            const int z = t / gpt, gl = t - z * gpt;
+            if (z ? sval[1] : sval[0]) {
+                double S = red[((size_t)(0 * 2 + z) * 16 + gl) * 2], SS = red[((size_t)(0 * 2 + z) * 16 + gl) * 2 + 1];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) {
+                    S = S + red[((size_t)(w * 2 + z) * 16 + gl) * 2];
+                    SS = SS + red[((size_t)(w * 2 + z) * 16 + gl) * 2 + 1];
+                }
+                const int g = (n0 + 32 * r) / cg + gl;
+                double *dst = p.gn_part + (((size_t)(z ? sn[1] : sn[0]) * p.sbY * p.sbX + (z ? sbi[1] : sbi[0])) * 32 + g) * 2;
+                dst[0] = S;
+                dst[1] = SS;
+            }
+        }
+    }
+}
+
+// the five 1-D filters of the form (header): rows (over ky) then columns (over kx)
+__device__ __forceinline__ float e5(int r, float g0, float g1, float g2)
+{
+    const float c3 = -1.0f / 3.0f, c12 = 1.0f / 12.0f, c6 = 1.0f / 6.0f;
+    switch (r) {
+    case 0: return g0 * 0.25f;
+    case 1: return ((g0 + g1) + g2) * c3;
+    case 2: return __builtin_fmaf(4.0f, g2, __builtin_fmaf(4.0f, g1, g0)) * c12;
+    case 3: return __builtin_fmaf(4.0f, g2, g0 + g1) * c6;
+    default: return g2;
+    }
+}
+
+// 3x3 OIHW -> out[step = ci/8][component 5 i + j][32-column tile][lane][e]: column o = 32 tile + lane%32,
+// ci = 8 step + 2 e + lane/32 (the B fragments of the four k-pairs of a step: one 16-byte load per lane, 1 KiB per wave)
+__global__ void repack_wino_up2_kernel(const float *__restrict__ in, int O, int I, float *__restrict__ out, size_t total)
+{
+    const int NT32 = (O + 31) / 32;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        size_t rest = idx >> 8;
+        const int ntile = (int)(rest % NT32);
+        rest /= NT32;
+        const int comp = (int)(rest % 25), step = (int)(rest / 25);
+        const int ci = 8 * step + 2 * e + (lane >> 5), o = ntile * 32 + (lane & 31);
+        float v = 0.f;
+        if (ci < I && o < O) {
+            const int i = comp / 5, j = comp - 5 * i;
+            const float *gw = in + ((size_t)o * I + ci) * 9;
+            float ur[3];
+#pragma unroll
+            for (int x = 0; x < 3; ++x) ur[x] = e5(i, gw[x], gw[3 + x], gw[6 + x]);
+            v = e5(j, ur[0], ur[1], ur[2]);
+        }
+        out[idx] = v;
+    }
+}
+
+unsigned long long g_attr_devs = 0;
+
+}  // namespace
+
+bool femasr_conv_wino_up2_shape_ok(const femasr_conv_args *a)
+{
+    return a->ksz == 3 && a->stride == 1 && a->pad == 1 && a->up2 && a->act == FEMASR_ACT_NONE && a->prologue == FEMASR_PRO_NONE &&
+           (a->Cin % BK) == 0 && a->Cin <= 1024 && (a->Cout % 64) == 0 &&
+           (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31) && (size_t)a->B * 4 * a->H * a->W * a->Cout < ((size_t)1 << 31) &&
+           (size_t)a->H * a->W * a->Cin < ((size_t)1 << 27) &&          // two images within the 2 GiB range of the input descriptor
+           (size_t)25 * a->Cin * a->Cout < ((size_t)1 << 29);
+}
+const char *femasr_conv_wino_up2_variant_name() { return "conv3x3_wino_up2<2x16x16px x64,waves=8>"; }
+
+int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double *flops_out)
+{
+    FEMASR_REQUIRE(a && a->in && a->w_wino && a->bias && a->out && femasr_conv_wino_up2_shape_ok(a), "conv_wino_up2: bad arguments / shape");
+    FEMASR_REQUIRE(a->Ho == 2 * a->H && a->Wo == 2 * a->W, "conv_wino_up2: Ho/Wo mismatch");
+    FEMASR_REQUIRE(!a->gn_part || femasr_gn_fusable(a->Cout), "conv_wino_up2: gn_part needs 32 | Cout and Cout/32 a power of two <= 32");
+    WinoUpParams p{};
+    p.in = a->in; p.u = (const float *)a->w_wino; p.bias = a->bias;
+    p.res1 = a->res1; p.res2 = a->res2; p.out = a->out; p.gn_part = a->gn_part;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.Ho = a->Ho; p.Wo = a->Wo;
+    p.sbX = (p.Wo + 15) / 16;
+    p.sbY = (p.Ho + 15) / 16;
+    p.nsb = a->B * p.sbX * p.sbY;
+    p.MB = (p.nsb + 1) / 2;
+    p.NB = a->Cout / 64;
+    p.nsteps = a->Cin / 8;
+    p.NT32 = a->Cout / 32;
+    const size_t lds = wino_up_lds_bytes();
+    int dev = 0;
+    FEMASR_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !((g_attr_devs >> dev) & 1ull)) {
+        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wino_up2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) g_attr_devs |= 1ull << dev;
+    }
+    hipLaunchKernelGGL(conv3x3_wino_up2_kernel, dim3((unsigned)(p.MB * p.NB)), dim3(WU_NT), lds, s, p);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    // ALGORITHMIC flops (the definition's 9 taps per output pixel, like every other conv launcher); the kernel issues 25/144 of them
+    if (flops_out) *flops_out = 2.0 * (double)a->B * a->Ho * a->Wo * 9.0 * (double)a->Cin * (double)a->Cout;
+    return FEMASR_OK;
+}
+
+extern "C" {
+
+size_t femasr_wino_up2_weight_floats(int O, int I) { return (I % 32) == 0 ? (size_t)(I / 8) * 25 * ((O + 31) / 32) * 256 : 0; }
+
+int femasr_repack_oihw_wino_up2(void *stream, const float *in, int O, int I, float *out)
+{
+    FEMASR_REQUIRE(in && out && O > 0 && I > 0 && (I % 32) == 0, "repack_wino_up2: needs a 3x3 OIHW weight with I %% 32 == 0");
+    const size_t total = femasr_wino_up2_weight_floats(O, I);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(repack_wino_up2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, O, I, out, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+}  // extern "C"

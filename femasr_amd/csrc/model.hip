@@ -374,14 +374,15 @@ struct Ctx {
         // exact-fp32 mode: convs behind the codebook lookup of a single-codebook network run in the Winograd F(4x4,3x3) form
         // (they cannot move a VQ index; oracle: OracleNet.wino).  decoder_math 2 = 'fp32_direct' keeps the direct form; 0 runs the
         // SiLU of their GroupNorm prologue on the hardware exp2 / rcp units, 3 = 'fp32_strict' keeps it IEEE-exact (== oracle).
-        const bool wino_on = !lowp_on && o.lowp && (h->decoder_math == 0 || h->decoder_math == 3) && h->cfg.n_codebooks == 1 && femasr_conv_wino_shape_ok(&a);
+        const bool wino_on = !lowp_on && o.lowp && (h->decoder_math == 0 || h->decoder_math == 3) && h->cfg.n_codebooks == 1 &&
+                             (o.up2 ? femasr_conv_wino_up2_shape_ok(&a) : femasr_conv_wino_shape_ok(&a));
         const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
                                    : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
         if (o.want_gn && gn_ok) {
             // exact x2 convs (phase filters) emit one partial per half-resolution tile and phase
             // (a Winograd conv emits one partial per 16x16-pixel sub-block, orc_gn_coeffs mode 2)
-            y.gn_tiles = (o.up2 && !lowp_on) ? 4 * ((x.H + 7) / 8) * ((x.W + 15) / 16)
-                         : (wino_on ? femasr_conv_wino_gn_tiles(Ho, Wo) : ((Ho + 7) / 8) * ((Wo + 15) / 16));
+            y.gn_tiles = wino_on ? femasr_conv_wino_gn_tiles(Ho, Wo)
+                         : ((o.up2 && !lowp_on) ? 4 * ((x.H + 7) / 8) * ((x.W + 15) / 16) : ((Ho + 7) / 8) * ((Wo + 15) / 16));
             y.gn_part = (double *)arena->alloc((size_t)x.B * y.gn_tiles * 32 * 2 * sizeof(double));
             if (!y.gn_part && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
         }
@@ -408,7 +409,12 @@ struct Ctx {
         } else if (wino_w) {
             a.w_wino = wino_w;
             a.fast_act = h->decoder_math == 0 ? 1 : 0;
-            r = femasr_conv_wino_launch(s(), &a, &variant, &flops);
+            if (o.up2) {
+                r = femasr_conv_wino_up2_launch(s(), &a, &flops);
+                variant = femasr_conv_wino_variant_count();          // the slot behind the F(4x4,3x3) variants
+            } else {
+                r = femasr_conv_wino_launch(s(), &a, &variant, &flops);
+            }
             variant += femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count();
         } else {
             r = femasr_conv2d_launch(s(), &a, nullptr, &variant, &flops);
@@ -799,12 +805,13 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
     if (!guard.ok) { delete h; return femasr_set_error(FEMASR_ERR_HIP, "hipSetDevice(%d) failed", cfg->device); }
     const int rc = build_specs(h);
     if (rc) { delete h; return rc; }
-    const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count() + femasr_conv_wino_variant_count();
+    const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count() + femasr_conv_wino_variant_count() + 1;
     h->acc_ms.assign(nslots, 0.0); h->acc_flops.assign(nslots, 0.0); h->acc_bytes.assign(nslots, 0.0); h->acc_n.assign(nslots, 0);
     for (int i = 0; i < SLOT_SMALL_COUNT; ++i) h->slot_names.push_back(kSmallNames[i]);
     for (int i = 0; i < femasr_conv_variant_count(); ++i) h->slot_names.push_back(femasr_conv_variant_name(i));
     for (int i = 0; i < femasr_conv_bf16x3_variant_count(); ++i) h->slot_names.push_back(femasr_conv_bf16x3_variant_name(i));
     for (int i = 0; i < femasr_conv_wino_variant_count(); ++i) h->slot_names.push_back(femasr_conv_wino_variant_name(i));
+    h->slot_names.push_back(femasr_conv_wino_up2_variant_name());
     *out = h;
     return FEMASR_OK;
 }
@@ -876,10 +883,13 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
         rc = femasr_repack_oihw_up2(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.up2w);
         if (rc) return rc;
     }
-    if (w.kind == W_CONV && dec_side && !w.up2 && h->cfg.n_codebooks == 1 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0 &&
+    if (w.kind == W_CONV && dec_side && h->cfg.n_codebooks == 1 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0 &&
         (w.shape[0] % 64) == 0) {
-        if (!w.wino) FEMASR_CHECK_HIP(hipMalloc((void **)&w.wino, femasr_wino_weight_floats((int)w.shape[0], (int)w.shape[1]) * sizeof(float)));
-        rc = femasr_repack_oihw_wino(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.wino);
+        // Winograd-domain weights: F(4x4,3x3) for the plain convs, the 25-component form for the convs behind nn.Upsample(x2)
+        const size_t nf = w.up2 ? femasr_wino_up2_weight_floats((int)w.shape[0], (int)w.shape[1]) : femasr_wino_weight_floats((int)w.shape[0], (int)w.shape[1]);
+        if (!w.wino) FEMASR_CHECK_HIP(hipMalloc((void **)&w.wino, nf * sizeof(float)));
+        rc = w.up2 ? femasr_repack_oihw_wino_up2(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.wino)
+                   : femasr_repack_oihw_wino(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.wino);
         if (rc) return rc;
     }
     if (w.kind == W_CONV && dec_side && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {

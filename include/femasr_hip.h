@@ -168,7 +168,9 @@ typedef struct {
                              throughout, 4x fewer multiplies, results within fp32 rounding (~1e-5 relative at worst) of the
                              direct form and bit-identical to oracle/femasr_oracle.c orc_conv3x3_winograd.  The model uses
                              it for the convs behind the codebook lookup only (they cannot move a VQ index).  With gn_part the
-                             partials are per 16x16-pixel sub-block: [B][ceil(H/16)*ceil(W/16)][32][2] (orc_gn_coeffs mode 2). */
+                             partials are per 16x16-pixel sub-block: [B][ceil(H/16)*ceil(W/16)][32][2] (orc_gn_coeffs mode 2).
+                             With up2 = 1: femasr_repack_oihw_wino_up2 weights, the 25-product form of nearest-x2 + conv
+                             (no prologue; partials per 16x16-pixel OUTPUT sub-block; orc_conv_up2_winograd). */
     int32_t fast_act;     /* Winograd convs with the GN+SiLU prologue only: 1 = SiLU through the hardware exp2 / rcp units
                              (v_exp_f32, v_rcp_f32: 1 ulp each) instead of the IEEE-exact polynomial + division - ~6x fewer
                              VALU instructions in the staging; output within ~1e-6 relative of the exact form (no longer
@@ -251,6 +253,12 @@ size_t femasr_up2_weight_floats(int O, int I);
  * of one 8-channel step: 1 KiB per wave load).  out: femasr_wino_weight_floats(O, I) floats = 36 * I * 32*ceil(O/32). */
 size_t femasr_wino_weight_floats(int O, int I);
 int femasr_repack_oihw_wino(void *stream, const float *in, int O, int I, float *out);
+/* The same for the conv behind nn.Upsample(x2, nearest) (femasr_arch.py:172-173,202-203): a 4x4 output tile reads a 4x4 patch of
+ * the low-resolution input, which leaves 5 products per dimension - 25 components per (o, i) instead of 36, layout
+ * [Cin/8][25][Cout/32][lane][4].  Pass the result as femasr_conv_args.w_wino together with up2 = 1 (no prologue; Cin % 32 == 0,
+ * Cout % 64 == 0).  GroupNorm partial moments (gn_part) come per 16x16-pixel OUTPUT sub-block, as for the F(4x4,3x3) form. */
+size_t femasr_wino_up2_weight_floats(int O, int I);
+int femasr_repack_oihw_wino_up2(void *stream, const float *w_oihw, int O, int I, float *out);
 int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *out);
 
 /* Split-bf16 (hi/lo) fragment-major weights for the opt-in bf16x3 conv path (3x3 convs behind the VQ lookup). */

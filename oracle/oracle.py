@@ -52,7 +52,8 @@ def lib():
         L.orc_vq.argtypes = [vp, i64, i, vp, i, vp, vp, vp, vp]
         L.orc_codebook_gather.argtypes = [vp, i64, i, vp, vp]
         L.orc_conv3x3_winograd.argtypes = [vp, i, i, i, i, vp, vp, i, vp, vp, vp]
-        for fn in ('orc_math_eval', 'orc_pad_nchw_to_nhwc', 'orc_crop_nhwc_to_nchw', 'orc_conv2d', 'orc_conv3x3_winograd',
+        L.orc_conv_up2_winograd.argtypes = [vp, i, i, i, i, vp, vp, i, vp, vp, vp]
+        for fn in ('orc_math_eval', 'orc_pad_nchw_to_nhwc', 'orc_crop_nhwc_to_nchw', 'orc_conv2d', 'orc_conv3x3_winograd', 'orc_conv_up2_winograd',
                    'orc_gn_coeffs', 'orc_scale_shift_silu', 'orc_layernorm', 'orc_window_attention',
                    'orc_vq', 'orc_codebook_gather'):
             getattr(L, fn).restype = None
@@ -108,10 +109,21 @@ def winograd_ok(cin, cout, ksz, stride, pad, up2, act=0):
     return ksz == 3 and stride == 1 and pad == 1 and not up2 and act == 0 and cin % 32 == 0 and cout % 64 == 0
 
 
+def winograd_up2_ok(cin, cout, ksz, stride, pad, up2, act=0):
+    """nn.Upsample(x2) + 3x3 conv in the 25-product Winograd-type form (orc_conv_up2_winograd; kernels_wino_up2.hip)."""
+    return ksz == 3 and stride == 1 and pad == 1 and bool(up2) and act == 0 and cin % 32 == 0 and cout % 64 == 0
+
+
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, act=0, res1=None, res2=None, wino=False):
     x = _c(x)
     b, h, w, cin = x.shape
     cout = w_khwc.shape[-1]
+    if wino and winograd_up2_ok(cin, cout, ksz, stride, pad, up2, act):
+        out = np.empty((b, 2 * h, 2 * w, cout), np.float32)
+        res1 = None if res1 is None else _c(res1)
+        res2 = None if res2 is None else _c(res2)
+        lib().orc_conv_up2_winograd(_p(x), b, h, w, cin, _p(_c(w_khwc)), _p(_c(bias)), cout, _p(res1), _p(res2), _p(out))
+        return out
     if wino and winograd_ok(cin, cout, ksz, stride, pad, up2, act):
         out = np.empty((b, h, w, cout), np.float32)
         res1 = None if res1 is None else _c(res1)

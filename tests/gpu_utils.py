@@ -60,8 +60,12 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     wwino = None
     if wino:        # Winograd-domain weights, transformed and packed on the GPU from OIHW
         w_oihw = dev(np.ascontiguousarray(np.asarray(w_khwc).transpose(3, 2, 0, 1)))
-        wwino = torch.empty(int(lib.femasr_wino_weight_floats(cout, cin)), dtype=torch.float32, device='cuda')
-        _lib.check(lib.femasr_repack_oihw_wino(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(wwino)))
+        if up2:     # the 25-component form of nearest-x2 + conv (kernels_wino_up2.hip)
+            wwino = torch.empty(int(lib.femasr_wino_up2_weight_floats(cout, cin)), dtype=torch.float32, device='cuda')
+            _lib.check(lib.femasr_repack_oihw_wino_up2(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(wwino)))
+        else:
+            wwino = torch.empty(int(lib.femasr_wino_weight_floats(cout, cin)), dtype=torch.float32, device='cuda')
+            _lib.check(lib.femasr_repack_oihw_wino(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(wwino)))
     w_khwc = lib_weight_layout(np.asarray(w_khwc))
     hv, wv = (2 * h, 2 * w) if up2 else (h, w)
     ho, wo = (hv + 2 * pad - ksz) // stride + 1, (wv + 2 * pad - ksz) // stride + 1

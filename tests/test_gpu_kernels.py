@@ -369,6 +369,34 @@ def test_conv_winograd_bit_exact(cuda_device, cin, cout, shape, gn, nres, part):
         _same(bb, b_ref, 'fused gn b (winograd)')
 
 
+@pytest.mark.parametrize('cin,cout,shape,nres,part', [(32, 64, (1, 8, 8), 0, False), (64, 128, (2, 9, 13), 1, True), (256, 128, (1, 12, 20), 0, True),
+                                                      (128, 64, (3, 5, 7), 2, True), (32, 192, (1, 1, 3), 0, False), (512, 256, (1, 4, 4), 0, True)])
+def test_conv_up2_winograd_bit_exact(cuda_device, cin, cout, shape, nres, part):
+    """nn.Upsample(x2) + 3x3 conv in the 25-product Winograd-type form (kernels_wino_up2.hip): bit-identical to the oracle's
+    restatement (orc_conv_up2_winograd), within fp32 rounding of the definition, fused GroupNorm moments per 16x16 output sub-block."""
+    import gpu_utils as G
+    b, h, w = shape
+    x = synth.uniform(23, 'wux', (b, h, w, cin), -2.0, 2.0)
+    wt = synth.uniform(23, 'wuw', (3, 3, cin, cout), -0.1, 0.1)
+    bias = synth.uniform(23, 'wub', (cout,), -0.5, 0.5)
+    res = [synth.uniform(23, f'wur{k}', (b, 2 * h, 2 * w, cout), -1, 1) for k in range(nres)]
+    r1, r2 = (res + [None, None])[:2]
+    ref = orc.conv2d(x, wt, bias, 3, 1, 1, True, res1=r1, res2=r2, wino=True)
+    got = G.conv2d(x, wt, bias, 3, 1, 1, True, res1=r1, res2=r2, wino=True, gn_part=part)
+    y = got[0] if part else got
+    _same(y, ref, 'up2 conv (Winograd-type form)')
+    xu = np.repeat(np.repeat(x, 2, axis=1), 2, axis=2)                 # the definition: upsample, then the ordinary conv
+    y_def = orc.conv2d(xu, wt, bias, 3, 1, 1, False, res1=r1, res2=r2)
+    assert np.abs(y - y_def).max() <= 1e-4 * max(1.0, np.abs(y_def).max()), np.abs(y - y_def).max()
+    if part:
+        gamma = synth.uniform(23, 'wug', (cout,), 0.5, 1.5)
+        beta = synth.uniform(23, 'wube', (cout,), -0.5, 0.5)
+        a_ref, b_ref = orc.gn_coeffs(ref, gamma, beta, phases=2)
+        a, bb = G.gn_coeffs_from_partials(got[1], 2 * h, 2 * w, cout, gamma, beta)
+        _same(a, a_ref, 'fused gn a (up2 winograd)')
+        _same(bb, b_ref, 'fused gn b (up2 winograd)')
+
+
 @pytest.mark.parametrize('cin,cout,shape,nres', [(64, 128, (2, 16, 32), 1), (128, 64, (1, 13, 21), 2), (256, 256, (1, 20, 9), 0)])
 def test_conv_winograd_fast_act_close(cuda_device, cin, cout, shape, nres):
     """The model's default for the convs behind the codebook lookup: Winograd form with the SiLU of the GroupNorm prologue on the

@@ -3,7 +3,8 @@
     product default mode and in 'fp32_strict';
   * one image of the reference's testset/ that takes the CLI's `test_tile(240, 16)` branch (inference_femasr.py:58-63:
     OST_120.png, 720x720 -> 2880x2880, 9 tiles in 4 shape classes), uint8 in -> uint8 out.
-Tolerance 1e-3 max-abs fp32 vs the reference; VQ indices exact (near-tie rule: zero mismatches today)."""
+Tolerance 1e-3 max-abs fp32 vs the reference; VQ indices exact up to the documented near-tie rule (zero mismatches on the
+single-tile cases; the 173 056-token image holds reference near ties, see the test)."""
 import hashlib
 import io
 
@@ -16,6 +17,10 @@ from helpers import cfg_name_of, check_indices_near_tie, load_golden, synth_weig
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+# A VQ index other than the reference's is accepted only where the REFERENCE's own fp32 distances of the two codes are this close
+# (d ~ 500 there: 8 ulp = 2.4e-4 absolute, 5e-7 relative - the size of the encoders' summation-order differences; SURVEY 7, hard
+# part 1).  The single-tile goldens need no allowance at all; the 173 056-token image has 193 tokens within 16 ulp of a tie.
+NEAR_TIE_ULP = 8.0
 
 
 @pytest.mark.parametrize('name', ['x2_tile256_trained', 'hq_full512_trained'])
@@ -58,13 +63,49 @@ def test_cli_tiled_branch_on_testset_png(cuda_device, math):
     x = imgproc.u8_to_input(u8)                            # (1,3,H,W) fp32 in [0,1], on the GPU
     y = net.test_tile(x, int(g['tile_size']), int(g['tile_pad']))
     assert tuple(y.shape) == tuple(g['out_shape'])
+    # The VQ index map of every tile, in the reference's loop order (femasr_arch.py:405-429), under the documented near-tie rule
+    # (helpers.check_indices_near_tie): 173 056 tokens with synthetic weights hold a few dozen whose two best codes are within
+    # 2 ulp of each other in the REFERENCE's own distances (sometimes more than two codes: large |z|^2 quantises d); such a token may
+    # resolve to any of the codes the reference itself has within 2 ulp of its best.  Anything else fails.
+    ts, pad = int(g['tile_size']), int(g['tile_pad'])
+    H, W = x.shape[2:]
+    near = {int(p): {int(c): float(gp) for c, gp in zip(cs, gs)} for p, cs, gs in zip(g['near_tie_pos'], g['near_tie_codes'], g['near_tie_gaps_ulp'])}
+    flip_gaps = []
+    mask = np.zeros((4 * H, 4 * W), bool)          # output pixels that may differ because an accepted near tie went the other way
+    R = 128                                          # decoder receptive radius in output pixels, generous
+    off = k = flips = 0
+    for ty in range(-(-H // ts)):
+        for tx in range(-(-W // ts)):
+            y0, y1, x0, x1 = ty * ts, min(ty * ts + ts, H), tx * ts, min(tx * ts + ts, W)
+            y0p, x0p = max(y0 - pad, 0), max(x0 - pad, 0)
+            crop = x[:, :, y0p:min(y1 + pad, H), x0p:min(x1 + pad, W)].contiguous()
+            _, idx = net.test_with_indices(crop)
+            hw = tuple(int(v) for v in g['tile_index_hw'][k])
+            assert tuple(idx.shape[-2:]) == hw
+            n = hw[0] * hw[1]
+            got = idx.cpu().numpy().reshape(-1)
+            ref = g['tile_indices'][off:off + n].astype(np.int64)
+            for r in np.nonzero(got != ref)[0]:
+                gp = near.get(off + int(r), {}).get(int(got[r]), 1e9)
+                assert gp <= NEAR_TIE_ULP, f'tile ({ty},{tx}) token {r}: index {got[r]} vs reference {ref[r]}: {gp} ulp apart in the reference, not a near tie'
+                flip_gaps.append(gp)
+                flips += 1
+                cy, cx = 4 * (y0p + 2 * (int(r) // hw[1])), 4 * (x0p + 2 * (int(r) % hw[1]))      # a token = 2x2 LR pixels = 8x8 output pixels
+                mask[max(cy - R, 0):cy + 8 + R, max(cx - R, 0):cx + 8 + R] = True
+            off += n
+            k += 1
+    assert off == g['tile_indices'].size
+    assert flips <= 40 and mask.mean() < 0.10, (flips, float(mask.mean()))
     yn = y.cpu().numpy()
-    err = float(np.abs(yn[:, :, ::8, ::8] - g['output_f32_stride8']).max())
-    assert err < TOL, err
-    assert abs(float(yn.astype(np.float64).mean()) - float(g['out_mean'])) < 1e-5
+    dz = np.abs(yn[:, :, ::8, ::8] - g['output_f32_stride8']).max(axis=(0, 1))
+    err = float(dz[~mask[::8, ::8]].max())
+    assert err < TOL, (err, flips)
+    if flips == 0:
+        assert abs(float(yn.astype(np.float64).mean()) - float(g['out_mean'])) < 1e-5
     out = imgproc.output_to_u8(y).cpu().numpy()
-    diff = np.abs(out[::4, ::4].astype(np.int16) - g['output_u8_stride4'].astype(np.int16))
+    diff = np.abs(out[::4, ::4].astype(np.int16) - g['output_u8_stride4'].astype(np.int16)).max(axis=2)[~mask[::4, ::4]]
     # a value within ~1e-5 of x.5/255 may round the other way
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (int(diff.max()), float((diff > 0).mean()))
     same = hashlib.sha256(out.tobytes()).hexdigest() == str(g['output_u8_sha256'])
-    print(f'OST_120 tiled [{math}]: max-abs vs reference {err:.3e}; uint8 image {"identical" if same else "differs in <= 1 LSB on %.2e of the strided pixels" % float((diff > 0).mean())}')
+    print(f'OST_120 tiled [{math}]: {flips} accepted near-tie flips, reference gaps {sorted(flip_gaps)} ulp ({100 * mask.mean():.2f} % of the output masked); max-abs vs reference outside {err:.3e}; '
+          f'uint8 image {"identical" if same else "differs in <= 1 LSB on %.2e of the unmasked strided pixels" % float((diff > 0).mean())}')

@@ -1,4 +1,4 @@
-"""Max-abs error table of the HIP path against every reference golden, both math modes (numbers quoted in DESIGN.md)."""
+"""Max-abs error table of the HIP path against every reference golden, every decoder math mode (numbers quoted in DESIGN.md)."""
 import os
 import sys
 
@@ -27,7 +27,7 @@ def run(name, r2):
     x = torch.from_numpy(synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))).cuda()
     st = int(g['out_stride']) if 'out_stride' in g else 1
     res = {}
-    for math in ('fp32', 'bf16x3'):
+    for math in ('fp32_direct', 'fp32_strict', 'fp32', 'bf16x3'):
         net.decoder_math = math
         if str(g['mode']) == 'test':
             y, idx = net.test_with_all_indices(x)
@@ -35,11 +35,14 @@ def run(name, r2):
             y, _, _, idx = net(x)
         y = y.cpu().numpy()[:, :, ::st, ::st]
         res[math] = (float(np.abs(y - g['output']).max()), int((idx[0].cpu().numpy().reshape(-1) != g['vq_indices'].reshape(-1)).sum()), y)
-    print(f'{name:22s} |out|max {float(np.abs(g["output"]).max()):8.3f}  fp32 vs reference {res["fp32"][0]:.2e} (idx mismatches {res["fp32"][1]})  '
-          f'bf16x3 vs reference {res["bf16x3"][0]:.2e}  bf16x3 vs fp32 {float(np.abs(res["bf16x3"][2] - res["fp32"][2]).max()):.2e}')
+    d = lambda a, b: float(np.abs(res[a][2] - res[b][2]).max())
+    print(f'{name:22s} |out|max {float(np.abs(g["output"]).max()):8.3f}  vs reference: direct {res["fp32_direct"][0]:.2e} strict(F4x4) {res["fp32_strict"][0]:.2e} '
+          f'fp32(default) {res["fp32"][0]:.2e} bf16x3 {res["bf16x3"][0]:.2e} (idx mismatches {res["fp32"][1]});  '
+          f'strict vs direct {d("fp32_strict", "fp32_direct"):.2e}  default vs strict {d("fp32", "fp32_strict"):.2e}  bf16x3 vs strict {d("bf16x3", "fp32_strict"):.2e}', flush=True)
 
 
-for n in ('x4_small_init', 'x4_small_trained', 'x2_small_trained', 'hq_small_trained', 'x4_tile128_init', 'x4_tile128_trained'):
+for n in ('x4_small_init', 'x4_small_trained', 'x2_small_trained', 'hq_small_trained', 'x4_tile128_init', 'x4_tile128_trained',
+          'x2_tile256_trained', 'hq_full512_trained'):
     run(n, False)
 for n in ('x4_small_torchinit', 'x4_small_unscaled', 'hq2_small_trained', 'x4mc_small_trained'):
     run(n, True)
