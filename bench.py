@@ -56,6 +56,8 @@ def rocprof_kernel_name(bench_name):
     m = re.match(r'conv_igemm<(\d+)x(\d+),(\w+),cinvec=(\w+),waves=(\d)x(\d)>', bench_name)
     if m:
         return f'conv_igemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(5)}, {m.group(6)}, {pro[m.group(3)]}, {m.group(4)}>'
+    if bench_name.startswith('conv3x3_wino_up2<'):
+        return 'conv3x3_wino_up2_kernel'
     m = re.match(r'conv3x3_wino4<2x16x16px x64,(\w+),(\w+),waves=8>', bench_name)
     if m:
         return f'conv3x3_wino4_kernel<{pro[m.group(1)]}, {m.group(2)}>'
@@ -335,6 +337,8 @@ def main():
             pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
 
             def issued_share(name):      # MFMA flops issued / algorithmic flops of the layer definition
+                if name.startswith('conv3x3_wino_up2'):
+                    return 25.0 / 144.0          # nearest-x2 + 3x3 conv, Winograd-type form: 25 multiplies per 4x4 outputs
                 if name.startswith('conv3x3_wino'):
                     return 36.0 / 144.0          # Winograd F(4x4,3x3): 36 multiplies per 4x4 outputs instead of 16 x 9
                 if name.startswith('conv3x3_halo<') and 'up2=true' in name:
@@ -363,7 +367,9 @@ def main():
                                       if split else 'fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)'),
                        'basis': ('achieved = flops the MFMA pipe EXECUTES (algorithmic flops of the layer definition x issued share) / HIP-event '
                                  'time of the launches; frac = achieved / peak = the physical MFMA issue fraction')}
-                if name.startswith('conv3x3_wino'):
+                if name.startswith('conv3x3_wino_up2'):
+                    out['form'] = 'nearest-x2 + 3x3 conv in a Winograd-type form on the low-resolution input, all fp32: 25 multiplies per 4x4 outputs where the definition has 144'
+                elif name.startswith('conv3x3_wino'):
                     out['form'] = 'Winograd F(4x4,3x3), all fp32: 36 multiplies per 4x4 outputs where the definition has 144'
                 elif share == 4.0 / 9.0:
                     out['form'] = 'nearest-x2 folded into four 2x2-tap phase filters: 4 multiplies per output where the definition has 9'

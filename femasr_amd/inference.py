@@ -44,6 +44,8 @@ def main(argv=None):
     ap.add_argument('--synthetic-seed', type=int, default=None, help='use deterministic synthetic weights (no checkpoint)')
     ap.add_argument('--tile_size', type=int, default=240)
     ap.add_argument('--tile_pad', type=int, default=16)
+    ap.add_argument('--decoder-math', choices=['fp32', 'fp32_strict', 'fp32_direct', 'bf16x3'], default='fp32',
+                    help="arithmetic of the convs behind the codebook lookup (FeMaSRNet.decoder_math); 'fp32_strict' is bit-identical to the CPU oracle")
     args = ap.parse_args(argv)
 
     if not torch.cuda.is_available():
@@ -60,6 +62,7 @@ def main(argv=None):
         model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
     else:
         raise SystemExit('no network here: pass -w <weights.pth> (FeMaSR_SRX4/SRX2_model_g.pth) or --synthetic-seed N')
+    model.decoder_math = args.decoder_math
     model = model.to(dev).eval()
 
     if rank == 0:

@@ -301,7 +301,14 @@ class OracleNet:
         # from_up2 = Cin of the x2 conv that produced x: its phase-filter kernel emitted the moments (phase-tile order);
         # from_wino: x is the output of the previous ResBlock's Winograd conv, which emitted the moments (sub-block order)
         c = x.shape[-1]
-        ph = 1 if (from_up2 is not None and from_up2 % 32 == 0 and gn_fusable(c)) else (2 if (from_wino and self._wino_fused(c, dec)) else 0)
+        ph = 0
+        if from_up2 is not None and gn_fusable(c):
+            if dec and self.wino and winograd_up2_ok(from_up2, c, 3, 1, 1, True):
+                ph = 2          # the x2 conv ran in the 25-product Winograd-type form: moments per 16x16 output sub-block
+            elif from_up2 % 32 == 0:
+                ph = 1          # phase-filter form: moments per half-resolution tile and phase
+        elif from_wino and self._wino_fused(c, dec):
+            ph = 2
         t = gn_silu(x, self.sd[prefix + '.conv.0.norm.weight'], self.sd[prefix + '.conv.0.norm.bias'], phases=ph)
         t = self._conv(t, prefix + '.conv.2', 3, dec=dec)
         t = gn_silu(t, self.sd[prefix + '.conv.3.norm.weight'], self.sd[prefix + '.conv.3.norm.bias'],
@@ -355,7 +362,7 @@ class OracleNet:
             bi += 1
             for _ in range(2):
                 cin = x.shape[-1]
-                x = self._conv(x, f'{p}.blocks.{bi}.1', 3, 1, 1, up2=True)
+                x = self._conv(x, f'{p}.blocks.{bi}.1', 3, 1, 1, up2=True, dec=True)
                 x = self._resblock(x, f'{p}.blocks.{bi}.2', dec=True, from_up2=cin)       # the LQ up-blocks only make the decoder's skip features
                 x = self._resblock(x, f'{p}.blocks.{bi}.3', dec=True, from_wino=True)
                 self._probe(f'enc_block{bi}', x)
@@ -366,7 +373,7 @@ class OracleNet:
     def _decoder_block(self, x, i, res2=None):
         p = f'decoder_group.{i}.block'
         cin = x.shape[-1]
-        x = self._conv(x, p + '.1', 3, 1, 1, up2=True)
+        x = self._conv(x, p + '.1', 3, 1, 1, up2=True, dec=True)
         x = self._resblock(x, p + '.2', dec=True, from_up2=cin)
         return self._resblock(x, p + '.3', res2=res2, dec=True, from_wino=True)
 

@@ -214,8 +214,10 @@ def test_cli_counterpart_end_to_end(cuda_device, tmp_path):
         u8 = (synth.synth_input(11, (1, 3, h, w), tag=name)[0].transpose(1, 2, 0) * 255).astype(np.uint8)
         Image.fromarray(u8, 'RGB').save(src / name)
         imgs[name] = u8
-    inference.main(['-i', str(src), '-o', str(dst), '-s', '4', '--synthetic-seed', '1', '--max_size', '40',
-                    '--tile_size', '24', '--tile_pad', '8'])
+    dst_d = tmp_path / 'out_default'
+    base = ['-i', str(src), '-s', '4', '--synthetic-seed', '1', '--max_size', '40', '--tile_size', '24', '--tile_pad', '8']
+    inference.main(base + ['-o', str(dst), '--decoder-math', 'fp32_strict'])
+    inference.main(base + ['-o', str(dst_d)])                  # the product default ('fp32': hardware-transcendental SiLU behind the lookup)
     w = synth_weights('x4', 1, 'trained')
     onet = oracle_net('x4', w)
     for name, u8 in imgs.items():
@@ -226,6 +228,9 @@ def test_cli_counterpart_end_to_end(cuda_device, tmp_path):
         got = np.asarray(Image.open(dst / name).convert('RGB'))
         assert got.shape == (h * 4, wd * 4, 3)
         assert np.array_equal(got, expect), name
+        got_d = np.asarray(Image.open(dst_d / name).convert('RGB'))
+        diff = np.abs(got_d.astype(np.int16) - expect.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (name, int(diff.max()), float((diff > 0).mean()))
 
 
 def test_other_configs_full_size_properties(cuda_device):
