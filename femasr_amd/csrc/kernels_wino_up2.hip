@@ -105,13 +105,15 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         sdst = (z * WU_PPIX + pix) * WU_PS + 4 * quad;
     }
     f32x4_t rp;
-    auto load_patch = [&](int s) {           // unconditional (steps past the end re-read the last one): the wait counters stay static
+    auto load_patch_to = [&](f32x4_t &rr, int s) {       // unconditional (steps past the end re-read the last one): the wait counters stay static
         const int sc = s < p.nsteps ? s : p.nsteps - 1;
-        rp = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff, sc * 32, 0));
+        rr = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff, sc * 32, 0));
     };
-    auto store_patch = [&](int buf) {
-        if (t < WU_UNITS) *reinterpret_cast<f32x4_t *>(Ps + buf * WU_PSZ + sdst) = rp;
+    auto load_patch = [&](int s) { load_patch_to(rp, s); };
+    auto store_patch_from = [&](const f32x4_t &rr, int buf) {
+        if (t < WU_UNITS) *reinterpret_cast<f32x4_t *>(Ps + buf * WU_PSZ + sdst) = rr;
     };
+    auto store_patch = [&](int buf) { store_patch_from(rp, buf); };
 
     // ---- input transform item: (tile tm, channel tch); waves 0-3 produce the rows v0, v1 of the column pass, waves 4-7 v3, v5
     // (w and w+4 share a SIMD: each SIMD carries both halves)
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         }
     };
 
-    // ---- prologue
+    // ---- prologue (requesting the patches of steps 0 and 1 together was measured on the F(4x4) kernel: 1-2 % slower)
     load_patch(0);
 #pragma unroll
     for (int q = 0; q < 3; ++q) ring[q] = ldU(0, q);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         __builtin_amdgcn_sched_barrier(0);
         transform_write((s + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-        store_patch(s & 1);                   // step s+2 -> the buffer step s's transform read (all waves are past that: barrier of step s-1 ... see below)
+        store_patch(s & 1);                   // step s+2 -> the buffer the transform of step s read during step s-1 (a barrier ago)
         issue_early(s + 1);
         __syncthreads();
     }

@@ -58,16 +58,26 @@ def main():
         r = torch.randn(b, ho, wo, cout, device=dev)
         args.res1 = r.data_ptr(); keep.append(r)
     if a_.wino:
-        ww = torch.empty(int(lib.femasr_wino_weight_floats(cout, cin)), device=dev)
-        _lib.check(lib.femasr_repack_oihw_wino(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(ww)))
+        if a_.up2:      # the 25-product form of nearest-x2 + conv
+            ww = torch.empty(int(lib.femasr_wino_up2_weight_floats(cout, cin)), device=dev)
+            _lib.check(lib.femasr_repack_oihw_wino_up2(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(ww)))
+        else:
+            ww = torch.empty(int(lib.femasr_wino_weight_floats(cout, cin)), device=dev)
+            _lib.check(lib.femasr_repack_oihw_wino(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(ww)))
         args.w_wino = ww.data_ptr(); keep.append(ww)
         args.fast_act = int(a_.fast_act)
     if not a_.fp32 and not a_.k1 and not a_.wino:
         ws = torch.empty(int(lib.femasr_packed_weight_bf16x3_bytes(cout, cin, 3, 3)), dtype=torch.uint8, device=dev)
         _lib.check(lib.femasr_repack_oihw_bf16x3(None, _lib.ptr(w_oihw), cout, cin, 3, 3, _lib.ptr(ws)))
         args.w_bf16x3 = ws.data_ptr(); keep.append(ws)
+    if a_.up2 and a_.fp32 and not a_.wino and cin % 32 == 0:      # phase-filter form of nearest-x2 + conv
+        wu = torch.empty(int(lib.femasr_up2_weight_floats(cout, cin)), device=dev)
+        _lib.check(lib.femasr_repack_oihw_up2(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(wu)))
+        args.w_up2 = wu.data_ptr(); keep.append(wu)
     if a_.gn_part:
         tiles = ((ho + 15) // 16) * ((wo + 15) // 16) if a_.wino else ((ho + 7) // 8) * ((wo + 15) // 16)
+        if a_.up2 and a_.fp32 and not a_.wino:
+            tiles = 4 * ((h + 7) // 8) * ((w + 15) // 16)
         part = torch.empty(b, tiles, 32, 2, dtype=torch.float64, device=dev)
         args.gn_part = part.data_ptr(); keep.append(part)
     for _ in range(2):
