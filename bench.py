@@ -290,7 +290,7 @@ def main():
                    'algorithmic_gflop_per_tile': TILE_GFLOP,
                    'end_to_end_algorithmic_tflops': None if dry else round(TILE_GFLOP * units_per_step * args.steps / dt / 1e3, 2),
                    'flops_note': ('algorithmic = the layer DEFINITIONS (964.47 GFLOP per tile, direct form); the default fp32 mode ISSUES far '
-                                  'fewer (Winograd F(4x4,3x3) behind the VQ lookup: 1/4; phase-filter x2 convs: 4/9) - the issued figure and '
+                                  'fewer (behind the VQ lookup: Winograd F(4x4,3x3) 36/144, nearest-x2 convs in the 25-product form 25/144; phase-filter x2 convs elsewhere: 4/9) - the issued figure and '
                                   'the physical MFMA fraction are in `roofline`')},
         'timed_region': {'per_rank_ms_per_step': per_rank_ms, 'world_size': world,
                          'rccl_version': ('.'.join(map(str, torch.cuda.nccl.version())) if (use_pg and backend == 'nccl') else None),
