@@ -134,12 +134,15 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     auto transform_write = [&](int vbuf) {
         float *dst = Vs + vbuf * WU_VSZ + tdst;
         float r[2][4];
+        if (thalf == 0) {            // rows l0, l1, l2 -> v0, v1
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (thalf == 0) {        // rows l0, l1, l2 -> v0, v1
+            for (int b = 0; b < 4; ++b) {
                 r[0][b] = __builtin_fmaf(4.0f, td[0][b], __builtin_fmaf(-5.0f, td[1][b], td[2][b]));
                 r[1][b] = __builtin_fmaf(-4.0f, td[1][b], td[2][b]);
-            } else {                 // rows l1, l2, l3 -> v3, v5
+            }
+        } else {                     // rows l1, l2, l3 -> v3, v5
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
                 r[0][b] = td[1][b] - td[0][b];
                 r[1][b] = __builtin_fmaf(4.0f, td[0][b], __builtin_fmaf(-5.0f, td[1][b], td[2][b]));
             }
@@ -183,12 +186,16 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     auto mphase = [&](int s) {
         const float *Vb = Vs + (s & 1) * WU_VSZ + aoff;
         late = ldU(s, 6);
-        f32x4_t an = *reinterpret_cast<const f32x4_t *>(Vb + vcomp(0) * 256);
+        // A fragments: the one of pair q+1 is REQUESTED before the MFMAs of pair q (two register sets, pinned with sched_barrier:
+        // left alone the scheduler reuses one set and sinks the read below the MFMAs - an LDS round trip exposed per pair)
+        f32x4_t af[2];
+        af[0] = *reinterpret_cast<const f32x4_t *>(Vb + vcomp(0) * 256);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            const f32x4_t a = an;
-            if (q + 1 < 7) an = *reinterpret_cast<const f32x4_t *>(Vb + vcomp(q + 1) * 256);
+            if (q + 1 < 7) af[(q + 1) & 1] = *reinterpret_cast<const f32x4_t *>(Vb + vcomp(q + 1) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4_t a = af[q & 1];
             const f32x4_t b = q < 3 ? ring[q] : (q < 6 ? early[q - 3] : late);
             if (q < 6 || has6) {
 #pragma unroll
