@@ -220,14 +220,17 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     issue_early(0);
     __syncthreads();
 
-    // ---- main loop: M(s), then transform step s+1 (its patch was staged during step s-1) and stage step s+2
+    // ---- main loop.  Per step: M(s); transform of step s+1 (its patch was staged during step s-1); stage step s+2.
+    // (Measured and dropped: the two waves of a SIMD taking the phases in opposite order - waves 0-3 M then T, waves 4-7 T then
+    // M - so that one wave's LDS round trips run under its partner's MFMAs: 2.10 vs 1.68 ms on 256 -> 128 channels; the merged
+    // control flow also costs a spilled accumulator tile per step.)
     for (int s = 0; s < p.nsteps; ++s) {
         mphase(s);
         transform_read((s + 1) & 1);          // (unconditional: after the last step it transforms a stale patch into a dead buffer)
         __builtin_amdgcn_sched_barrier(0);
         transform_write((s + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-        store_patch(s & 1);                   // step s+2 -> the buffer the transform of step s read during step s-1 (a barrier ago)
+        store_patch(s & 1);                   // step s+2 (loaded during the M phase) -> the buffer the transform of step s read a barrier ago
         issue_early(s + 1);
         __syncthreads();
     }
