@@ -221,7 +221,10 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     __syncthreads();
 
     // ---- main loop.  Per step: M(s); transform of step s+1 (its patch was staged during step s-1); stage step s+2.
-    // (Measured and dropped: the two waves of a SIMD taking the phases in opposite order - waves 0-3 M then T, waves 4-7 T then
+    // (Measured and dropped: 32-channel blocks with half the accumulators, <= 128 VGPRs and a 16-column epilogue exchange, so that
+    // TWO blocks are resident per CU and one's prologue / epilogue runs under the other's MFMAs - bit-exact, and exactly as fast
+    // as this form: 1.68 / 1.91 ms on both layer shapes.  The block's ends are instruction issue, not idle latency.
+    // Also measured and dropped: the two waves of a SIMD taking the phases in opposite order - waves 0-3 M then T, waves 4-7 T then
     // M - so that one wave's LDS round trips run under its partner's MFMAs: 2.10 vs 1.68 ms on 256 -> 128 channels; the merged
     // control flow also costs a spilled accumulator tile per step.)
     for (int s = 0; s < p.nsteps; ++s) {
