@@ -247,8 +247,10 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     const int gpt = 32 / (cg < 32 ? cg : 32);        // groups per 32-channel tile (<= 16)
     const int tl = t >> 5;                           // tile inside the sub-block: 2 wave + hh
     const int ety = tl >> 2, etx = tl & 3;
-    unsigned vmask[2];
-    size_t obase[2];
+    // Outputs and residuals go through BUFFER instructions: descriptor in SGPRs (base = the image of sub-block 0), ONE 32-bit byte
+    // offset per lane and sub-block, a uniform offset per pixel of the tile / round; a pixel outside the image gets an offset
+    // beyond num_records (stores are dropped, loads return 0).  No 64-bit address arithmetic, no exec masking per pixel.
+    unsigned vmask[2], ooff[2];
 #pragma unroll
     for (int z = 0; z < 2; ++z) {
         const int oy = (z ? sy0[1] : sy0[0]) + 4 * ety, ox = (z ? sx0[1] : sx0[0]) + 4 * etx;
@@ -256,13 +258,17 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
 #pragma unroll
         for (int k = 0; k < 16; ++k) m |= ((z ? sval[1] : sval[0]) && oy + (k >> 2) < p.Ho && ox + (k & 3) < p.Wo ? 1u : 0u) << k;
         vmask[z] = m;
-        obase[z] = (m ? (((size_t)(z ? sn[1] : sn[0]) * p.Ho + oy) * p.Wo + ox) * p.Cout : (size_t)0) + n0 + c31;
+        ooff[z] = (unsigned)(((((size_t)(z ? sn[1] - sn[0] : 0) * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + c31) * 4);
     }
-    auto eoff = [&](int k) -> unsigned { return (unsigned)((k >> 2) * p.Wo + (k & 3)) * (unsigned)p.Cout; };      // uniform
-    auto fetch = [&](const float *src, int z, int r, float (&dst)[16]) {       // branch-free batch of 16 loads
-        const float *bp = src + obase[z] + 32 * r;
+    const size_t img0 = (size_t)sn[0] * p.Ho * p.Wo * p.Cout;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(p.out + img0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc((void *)((p.res1 ? p.res1 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc((void *)((p.res2 ? p.res2 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
+    auto soff = [&](int k, int r) -> int { return (((k >> 2) * p.Wo + (k & 3)) * p.Cout + 32 * r) * 4; };      // uniform bytes
+    auto fetch = [&](const __amdgpu_buffer_rsrc_t rs, int z, int r, float (&dst)[16]) {       // 16 loads, no waits between
 #pragma unroll
-        for (int k = 0; k < 16; ++k) dst[k] = bp[(vmask[z] >> k) & 1u ? eoff(k) : 0u];
+        for (int k = 0; k < 16; ++k)
+            dst[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (vmask[z] >> k) & 1u ? ooff[z] : 0xffffffffu, soff(k, r), 0));
     };
     auto item = [&](int z, int r, float bv, const float (&r1)[16], const float (&r2)[16]) {
         const float *src = Mx + (z * 16 + tl) * 32 + c31;
@@ -271,7 +277,6 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         for (int j = 0; j < 5; ++j)
             at5(src[(0 * 5 + j) * 1024], src[(1 * 5 + j) * 1024], src[(2 * 5 + j) * 1024], src[(3 * 5 + j) * 1024], src[(4 * 5 + j) * 1024],
                 tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
-        float *bo = p.out + obase[z] + 32 * r;
         double gs = 0.0, gss = 0.0;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -284,9 +289,12 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
                 float v = y[b] + bv;
                 if (p.res1) v = v + r1[k];
                 if (p.res2) v = v + r2[k];
-                if (ok) bo[eoff(k)] = v;
+#ifdef FEMASR_WUP_NOSTORE          // experiment: everything but the output stores (tools/build_debug.sh)
+                if (p.nsteps < 0)
+#endif
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, ok ? ooff[z] : 0xffffffffu, soff(k, r), 0);
                 if (gnp) {                                   // a masked pixel adds +0 (the oracle skips it: same sums)
-                    const double dv = ok ? (double)v : 0.0;
+                    const double dv = (double)(ok ? v : 0.0f);
                     gs = gs + dv;
                     gss = __builtin_fma(dv, dv, gss);
                 }
@@ -317,15 +325,15 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
                 }
             }
         }
-        float ra1[16], ra2[16], rb1[16], rb2[16];          // residuals of the two items: in flight across the barrier / the first item
-        if (p.res1) fetch(p.res1, 0, r, ra1);
-        if (p.res2) fetch(p.res2, 0, r, ra2);
         const float bv = p.bias[n0 + 32 * r + c31];
         __syncthreads();
-        if (p.res1) fetch(p.res1, 1, r, rb1);
-        if (p.res2) fetch(p.res2, 1, r, rb2);
-        item(0, r, bv, ra1, ra2);
-        item(1, r, bv, rb1, rb2);
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            float r1[16], r2[16];                          // (the network's x2 convs have no residual operands: no prefetch across items)
+            if (p.res1) fetch(rs_r1, z, r, r1);
+            if (p.res2) fetch(rs_r2, z, r, r2);
+            item(z, r, bv, r1, r2);
+        }
         __syncthreads();
         if (gnp && t < 2 * gpt) {
             const int z = t / gpt, gl = t - z * gpt;
@@ -393,6 +401,7 @@ bool femasr_conv_wino_up2_shape_ok(const femasr_conv_args *a)
            (a->Cin % BK) == 0 && a->Cin <= 1024 && (a->Cout % 64) == 0 &&
            (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31) && (size_t)a->B * 4 * a->H * a->W * a->Cout < ((size_t)1 << 31) &&
            (size_t)a->H * a->W * a->Cin < ((size_t)1 << 27) &&          // two images within the 2 GiB range of the input descriptor
+           (size_t)4 * a->H * a->W * a->Cout < ((size_t)1 << 27) &&     // ... and of the output descriptor
            (size_t)25 * a->Cin * a->Cout < ((size_t)1 << 29);
 }
 const char *femasr_conv_wino_up2_variant_name() { return "conv3x3_wino_up2<2x16x16px x64,waves=8>"; }
