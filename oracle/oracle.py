@@ -109,6 +109,16 @@ def winograd_ok(cin, cout, ksz, stride, pad, up2, act=0):
     return ksz == 3 and stride == 1 and pad == 1 and not up2 and act == 0 and cin % 32 == 0 and cout % 64 == 0
 
 
+def wino_fits(b, h, w, cin, cout, up2=False):
+    """The kernels' size limits (32-bit buffer offsets: femasr_conv_wino_shape_ok / femasr_conv_wino_up2_shape_ok) are part of the
+    rule: a larger layer runs in the direct / phase-filter form on the GPU, so it does here.  (b, h, w) = the conv's INPUT."""
+    if not (b * h * w * cin < 2 ** 31 and h * w * cin < 2 ** 27 and cin <= 1024):
+        return False
+    if up2:
+        return b * 4 * h * w * cout < 2 ** 31 and 4 * h * w * cout < 2 ** 27 and 25 * cin * cout < 2 ** 29
+    return b * h * w * cout < 2 ** 31 and 36 * cin * cout < 2 ** 29
+
+
 def winograd_up2_ok(cin, cout, ksz, stride, pad, up2, act=0):
     """nn.Upsample(x2) + 3x3 conv in the 25-product Winograd-type form (orc_conv_up2_winograd; kernels_wino_up2.hip)."""
     return ksz == 3 and stride == 1 and pad == 1 and bool(up2) and act == 0 and cin % 32 == 0 and cout % 64 == 0
@@ -118,6 +128,7 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, act=0, res1=None, r
     x = _c(x)
     b, h, w, cin = x.shape
     cout = w_khwc.shape[-1]
+    wino = wino and wino_fits(b, h, w, cin, cout, up2)
     if wino and winograd_up2_ok(cin, cout, ksz, stride, pad, up2, act):
         out = np.empty((b, 2 * h, 2 * w, cout), np.float32)
         res1 = None if res1 is None else _c(res1)
@@ -291,10 +302,11 @@ class OracleNet:
         w, b = self._conv_w(prefix)
         return conv2d(x, w, b, ksz, stride, pad, up2, 0, res1, res2, wino=dec and self.wino)
 
-    def _wino_fused(self, c, dec):
+    def _wino_fused(self, c, dec, shape=None):
         """The conv that produced a c-channel tensor ran in the Winograd form AND emitted the GroupNorm partials (model.hip
         Ctx::conv: wino_on && gn_ok): the next GroupNorm sums them in the sub-block order (orc_gn_coeffs mode 2)."""
-        return dec and self.wino and winograd_ok(c, c, 3, 1, 1, False) and gn_fusable(c)
+        fits = shape is None or wino_fits(shape[0], shape[1], shape[2], c, c)
+        return dec and self.wino and fits and winograd_ok(c, c, 3, 1, 1, False) and gn_fusable(c)
 
     def _resblock(self, x, prefix, res2=None, dec=False, from_up2=None, from_wino=False):
         # fema_utils.py:65-84: conv2(silu(gn2(conv1(silu(gn1(x)))))) + x   (+ optional fused skip add)
@@ -303,16 +315,16 @@ class OracleNet:
         c = x.shape[-1]
         ph = 0
         if from_up2 is not None and gn_fusable(c):
-            if dec and self.wino and winograd_up2_ok(from_up2, c, 3, 1, 1, True):
+            if dec and self.wino and winograd_up2_ok(from_up2, c, 3, 1, 1, True) and wino_fits(x.shape[0], x.shape[1] // 2, x.shape[2] // 2, from_up2, c, True):
                 ph = 2          # the x2 conv ran in the 25-product Winograd-type form: moments per 16x16 output sub-block
             elif from_up2 % 32 == 0:
                 ph = 1          # phase-filter form: moments per half-resolution tile and phase
-        elif from_wino and self._wino_fused(c, dec):
+        elif from_wino and self._wino_fused(c, dec, x.shape):
             ph = 2
         t = gn_silu(x, self.sd[prefix + '.conv.0.norm.weight'], self.sd[prefix + '.conv.0.norm.bias'], phases=ph)
         t = self._conv(t, prefix + '.conv.2', 3, dec=dec)
         t = gn_silu(t, self.sd[prefix + '.conv.3.norm.weight'], self.sd[prefix + '.conv.3.norm.bias'],
-                    phases=2 if self._wino_fused(c, dec) else 0)
+                    phases=2 if self._wino_fused(c, dec, x.shape) else 0)
         return self._conv(t, prefix + '.conv.5', 3, res1=x, res2=res2, dec=dec)
 
     def _swin_block(self, x, b, h, w, prefix, shift):
