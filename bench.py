@@ -503,7 +503,68 @@ def cpu_baseline(net, x16, y_gpu, B):
         yg = y_gpu[:1].cpu().numpy()
         out['max_abs_torch_cpu_vs_gpu'] = float(np.abs(yt.numpy() - yg).max())
         out['c_oracle']['max_abs_vs_gpu'] = float(np.abs(yo - yg).max())
+    try:
+        out['host_throughput'] = cpu_host_throughput(sd, xs.numpy(), cores, best)
+    except Exception as e:                                  # a reported extra, never a reason to lose the bench line
+        out['host_throughput'] = {'error': f'{type(e).__name__}: {e}'[:200]}
     return out
+
+
+_HOST_WORKER = r'''
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+from oracle.torch_ref import TorchRefNet
+d, idx, nthreads, k = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+torch.set_num_threads(nthreads)
+z = np.load(os.path.join(d, 'state.npz'))
+net = TorchRefNet({n: z[n] for n in z.files if n != '__x__'}, LQ_stage=True, scale_factor=4)
+x = torch.from_numpy(z['__x__'])
+net.test(x)                                            # warm-up
+open(os.path.join(d, f'ready_{idx}'), 'w').close()
+while not os.path.exists(os.path.join(d, 'go')):
+    time.sleep(0.005)
+for _ in range(k):
+    net.test(x)
+open(os.path.join(d, f'done_{idx}'), 'w').close()
+'''
+
+
+def cpu_host_throughput(sd, x_np, cores, threads_each, tiles_each=2, timeout_s=180):
+    """What the HOST sustains when every core works: cores // threads_each concurrent processes, each running the stock-torch
+    restatement on its own copy of the tile with `threads_each` threads (the fastest single-tile setting), started together
+    behind a file barrier after their warm-ups; value = all tiles / wall time.  (VERDICT r2 item 9.)"""
+    import subprocess
+    import tempfile
+    import numpy as np
+    nproc = max(1, min(16, cores // max(1, threads_each)))
+    with tempfile.TemporaryDirectory() as d:
+        np.savez(os.path.join(d, 'state.npz'), __x__=x_np, **sd)
+        procs = [subprocess.Popen([sys.executable, '-c', _HOST_WORKER, ROOT, d, str(i), str(threads_each), str(tiles_each)],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(nproc)]
+        try:
+            t_end = time.time() + timeout_s
+            while not all(os.path.exists(os.path.join(d, f'ready_{i}')) for i in range(nproc)):
+                if time.time() > t_end or any(p.poll() not in (None, 0) for p in procs):
+                    raise RuntimeError('workers did not get ready')
+                time.sleep(0.01)
+            t0 = time.perf_counter()
+            open(os.path.join(d, 'go'), 'w').close()
+            while not all(os.path.exists(os.path.join(d, f'done_{i}')) for i in range(nproc)):
+                if time.time() > t_end:
+                    raise RuntimeError('workers did not finish')
+                time.sleep(0.005)
+            wall = time.perf_counter() - t0
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+                p.wait()
+    n = nproc * tiles_each
+    return {'value': round(n * 512 * 512 / 1e6 / wall, 5), 'unit': 'MPix/s', 'processes': nproc, 'threads_each': threads_each,
+            'tiles': n, 'seconds': round(wall, 2),
+            'sample': f'{nproc} concurrent processes x {tiles_each} tiles, {threads_each} torch threads each, started together after their warm-ups'}
 
 
 if __name__ == '__main__':
