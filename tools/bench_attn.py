@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 from femasr_amd import _lib  # noqa: E402
 
 b, h, w, shift = (int(a) for a in (sys.argv[1:5] + ['16', '72', '72', '4'][len(sys.argv) - 1:]))
+if os.environ.get('FEMASR_SO'):          # A/B against a debug build
+    _lib.SO_PATH = os.environ['FEMASR_SO']
 lib = _lib.load()
 qkv = torch.randn(b, h * w, 768, device='cuda')
 tab = torch.randn(225, 8, device='cuda') * 0.1
