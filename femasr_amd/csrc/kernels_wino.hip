@@ -210,31 +210,45 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     const int tm = (wave >> 1) * 8 + (lane >> 3), tch = lane & 7;
     const int tsrc = (tm >> 4) * W4_PPIX * W4_PS + ((4 * ((tm & 15) >> 2) + thalf) * W4_PW + 4 * (tm & 3)) * W4_PS + tch;
     const int tdst = thalf * 18 * 256 + tm * 8 + (tch & 1) * 4 + (tch >> 1);
-    float td[5][6];                                        // the transform item's 5 x 6 patch values (rows 3*thalf.. of the 6x6 patch)
+    // (first pass written on column PAIRS, explicitly two-wide: the patch reads come back as register pairs in exactly this order
+    // (ds_read2_b32) and v_pk_fma / v_pk_add take them as they are; left to the vectoriser the same arithmetic cost 44 v_mov per step)
+    typedef float tf2 __attribute__((ext_vector_type(2)));
+    tf2 td[5][3];                                          // the transform item's 5 x 6 patch values (rows 3*thalf.. of the 6x6 patch)
     auto transform_read = [&](int pbuf) {
         if (FEMASR_WINO_ABL & 4) return;
         const float *src = Ps + pbuf * W4_PSZ + tsrc;
 #pragma unroll
         for (int a = 0; a < 5; ++a)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) td[a][b] = src[(a * W4_PW + b) * W4_PS];
+            for (int b = 0; b < 3; ++b) td[a][b] = tf2{src[(a * W4_PW + 2 * b) * W4_PS], src[(a * W4_PW + 2 * b + 1) * W4_PS]};
     };
     auto transform_write = [&](int vbuf) {
         if (FEMASR_WINO_ABL & 4) return;
         float *dst = Vs + vbuf * W4_VSZ + tdst;
-        float r[3][6];
-        if (thalf == 0) {
+        auto fma2 = [](float c, tf2 x, tf2 y) -> tf2 { return __builtin_elementwise_fma(tf2{c, c}, x, y); };
+        tf2 r[3][3];
+        if (thalf == 0) {        // bt_lo on rows 0..4, two columns at a time (component-wise the same IEEE sequence)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) bt_lo(td[0][b], td[1][b], td[2][b], td[3][b], td[4][b], r[0][b], r[1][b], r[2][b]);
-        } else {
+            for (int b = 0; b < 3; ++b) {
+                r[0][b] = fma2(4.0f, td[0][b], fma2(-5.0f, td[2][b], td[4][b]));
+                const tf2 a2 = fma2(-4.0f, td[2][b], td[4][b]), b2 = fma2(-4.0f, td[1][b], td[3][b]);
+                r[1][b] = a2 + b2;
+                r[2][b] = a2 - b2;
+            }
+        } else {                 // bt_hi on rows 1..5 (held as td[0..4])
 #pragma unroll
-            for (int b = 0; b < 6; ++b) bt_hi(td[0][b], td[1][b], td[2][b], td[3][b], td[4][b], r[0][b], r[1][b], r[2][b]);
+            for (int b = 0; b < 3; ++b) {
+                const tf2 c2 = td[3][b] - td[1][b], e2 = td[2][b] - td[0][b];
+                r[0][b] = fma2(2.0f, e2, c2);
+                r[1][b] = fma2(-2.0f, e2, c2);
+                r[2][b] = fma2(4.0f, td[0][b], fma2(-5.0f, td[2][b], td[4][b]));
+            }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             float v0, v1, v2, v3, v4, v5;
-            bt_lo(r[i][0], r[i][1], r[i][2], r[i][3], r[i][4], v0, v1, v2);
-            bt_hi(r[i][1], r[i][2], r[i][3], r[i][4], r[i][5], v3, v4, v5);
+            bt_lo(r[i][0][0], r[i][0][1], r[i][1][0], r[i][1][1], r[i][2][0], v0, v1, v2);
+            bt_hi(r[i][0][1], r[i][1][0], r[i][1][1], r[i][2][0], r[i][2][1], v3, v4, v5);
             float *o = dst + i * 6 * 256;
             o[0 * 256] = v0;
             o[1 * 256] = v1;

@@ -7,6 +7,4 @@ for tag in ${TAGS:-default}; do
   for sh in "16 288 288 128 128" "16 576 576 64 64" "16 144 144 256 256"; do
     echo -n "$tag $sh fast: "; timeout 120 python tools/bench_conv.py $sh --gn --res --gn-part --iters 10 --wino --fast-act 2>&1 | tail -1 | sed 's/.*cls=-: //'
   done
-  echo -n "$tag up2 256->128 @144->288: "; timeout 120 python tools/bench_conv.py 16 144 144 256 128 --up2 --gn-part --iters 10 --wino 2>&1 | tail -1 | sed 's/.*cls=-: //'
-  echo -n "$tag up2 128->64 @288->576: "; timeout 120 python tools/bench_conv.py 16 288 288 128 64 --up2 --gn-part --iters 10 --wino 2>&1 | tail -1 | sed 's/.*cls=-: //'
 done; done
