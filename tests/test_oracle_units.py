@@ -53,8 +53,9 @@ def test_conv_variants_match_torch():
 
 
 def test_conv_winograd_and_phase_forms_match_torch():
-    """The two algebraic restatements the kernels use (Winograd F(2x2,3x3) behind the codebook lookup; nearest-x2 + conv as
-    four phase filters) against stock torch ops of the plain definition, and against the oracle's own direct form."""
+    """The algebraic restatements the kernels use (Winograd F(4x4,3x3) behind the codebook lookup; nearest-x2 + conv as four phase
+    filters, and behind the lookup in the 25-product Winograd-type form) against stock torch ops of the plain definition, and
+    against the oracle's own direct form."""
     cases = [(1, 8, 16, 32, 64, 0), (2, 13, 9, 64, 128, 1), (1, 7, 21, 128, 64, 2), (1, 16, 16, 256, 128, 1)]
     for i, (b, h, w, ci, co, nres) in enumerate(cases):
         x = synth.uniform(40 + i, 'wx', (b, h, w, ci), -2, 2)
@@ -85,6 +86,31 @@ def test_conv_winograd_and_phase_forms_match_torch():
         bias = synth.uniform(51, 'ub', (40,), -0.5, 0.5)
         y = orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, True)
         assert np.abs(y - _torch_conv(x, wt, bias, 1, 1, True)).max() < 2e-5
+    # x2 + conv behind the lookup: the 25-product form (orc_conv_up2_winograd) against torch's upsample + conv, the phase form, and
+    # odd sizes / image borders (a 4x4 output tile reads a 4x4 low-resolution patch with zero padding)
+    for i, (b, h, w, ci, co, nres) in enumerate([(1, 8, 8, 32, 64, 0), (2, 5, 7, 64, 128, 1), (1, 9, 3, 128, 64, 2), (1, 1, 1, 32, 64, 0)]):
+        x = synth.uniform(55 + i, 'vx', (b, h, w, ci), -2, 2)
+        wt = synth.uniform(55 + i, 'vw', (co, ci, 3, 3), -0.1, 0.1)
+        bias = synth.uniform(55 + i, 'vb', (co,), -0.5, 0.5)
+        res = [synth.uniform(55 + i, f'vr{k}', (b, 2 * h, 2 * w, co), -1, 1) for k in range(nres)]
+        r1, r2 = (res + [None, None])[:2]
+        assert orc.winograd_up2_ok(ci, co, 3, 1, 1, True)
+        y = orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, True, res1=r1, res2=r2, wino=True)
+        yp = orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, True, res1=r1, res2=r2)
+        ref = _torch_conv(x, wt, bias, 1, 1, True)
+        for r in res:
+            ref = ref + r
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() < 2e-5 * scale, (i, np.abs(y - ref).max())
+        assert np.abs(y - yp).max() < 2e-5 * scale and not np.array_equal(y, yp)
+    # layers beyond the kernels' 32-bit offset limits keep the phase form (orc.wino_fits), shapes outside the rule too
+    assert orc.wino_fits(16, 288, 288, 128, 128) and not orc.wino_fits(1, 4096, 4096, 64, 64) and not orc.wino_fits(1, 2048, 2048, 64, 64, True)
+    x = synth.uniform(59, 'vx', (1, 4, 4, 32), -1, 1)
+    wt = synth.uniform(59, 'vw', (48, 32, 3, 3), -0.1, 0.1)
+    bias = synth.uniform(59, 'vb', (48,), -0.5, 0.5)
+    assert np.array_equal(orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, True, wino=True),
+                          orc.conv2d(x, orc.repack_conv_weight(wt), bias, 3, 1, 1, True))
 
 
 def test_groupnorm_phase_tile_order():
