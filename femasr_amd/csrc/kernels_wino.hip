@@ -4,8 +4,9 @@
 // encoder's up-blocks that only make skip features; fema_utils.py:65-84, femasr_arch.py:196-207,298): they cannot move a VQ
 // index, and the form needs 36 multiplies per 4x4 outputs where the direct sweep needs 144 (4x fewer MFMAs; round 2 ran
 // F(2x2,3x3): 2.25x).  All fp32; the order of every addition is the one of oracle/femasr_oracle.c orc_conv3x3_winograd, so
-// the result is bit-identical to that restatement (measured against the reference goldens: <= 6e-6 max-abs on outputs of
-// magnitude 2, 4.4e-5 on the +-49 un-scaled case - the same class as the direct form).
+// the result is bit-identical to that restatement (measured against the reference goldens, whole network: <= 1.3e-5 max-abs on
+// outputs of magnitude <= 2.7 and 1.6e-4 on the +-49 un-scaled case, where the direct form has 1.2e-5 / 1.5e-4:
+// profiles/r03_parity_report.txt).
 //
 // What shapes the kernel (tools/ubench/coexec.hip, quantum.hip, round 3): v_mfma_f32_32x32x2_f32 runs on the vector lanes.
 // A VALU instruction of ANY wave on a SIMD takes its cycles out of that SIMD's fp32 MFMA time (4 MFMA waves + 4 VALU waves
