@@ -105,6 +105,7 @@ SIGNATURES = {
     'femasr_clock_probe': (c_int, [vp, c_int, vp]),
     'femasr_gemm_force_config': (c_int, [c_int]),
     'femasr_conv_small_launch_blocks': (c_int, [c_int]),
+    'femasr_debug_wino_limits': (c_int, [c_int, c_int]),
 }
 
 _lib = None

@@ -52,6 +52,8 @@ const char *femasr_gemm_variant_name(int v);
 int femasr_repack_k1(hipStream_t s, const float *in, int O, int I, float *out);
 
 // Winograd F(4x4,3x3) 3x3 convs (kernels_wino.hip)
+size_t femasr_wino_limit_total();       // element limits of the Winograd-form kernels (2^31 / 2^27 per image; femasr_debug_wino_limits)
+size_t femasr_wino_limit_image();
 bool femasr_conv_wino_shape_ok(const femasr_conv_args *a);
 int femasr_conv_wino_gn_tiles(int H, int W);      // fused GroupNorm partials of a Winograd conv: one per 16x16-pixel sub-block
 int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out);

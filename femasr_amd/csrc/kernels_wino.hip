@@ -29,15 +29,18 @@
 #include "conv_common.h"
 #include "detmath.h"
 #include <stdlib.h>
+#include <type_traits>
+#include <atomic>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float tf2 __attribute__((ext_vector_type(2)));
 
 #ifdef FEMASR_WINO_TT      // tools/build_debug.sh: per-wave cycle shares of the kernel's phases
-__device__ unsigned long long g_wi_tt[8];
+__device__ unsigned long long g_wi_tt[16];
 #define WTT(slot) { const unsigned long long now_ = __builtin_readcyclecounter(); tt_acc[slot] += now_ - tt_last; tt_last = now_; }
-#define WTT_INIT unsigned long long tt_acc[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long tt_last = __builtin_readcyclecounter(); const unsigned long long tt_first = tt_last;
-#define WTT_END { if (lane == 0) { for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&g_wi_tt[i_], tt_acc[i_]); atomicAdd(&g_wi_tt[7], __builtin_readcyclecounter() - tt_first); } }
+#define WTT_INIT unsigned long long tt_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tt_last = __builtin_readcyclecounter(); const unsigned long long tt_first = tt_last;
+#define WTT_END { if (lane == 0) { for (int i_ = 0; i_ < 15; ++i_) atomicAdd(&g_wi_tt[i_], tt_acc[i_]); atomicAdd(&g_wi_tt[15], __builtin_readcyclecounter() - tt_first); } }
 #else
 #define WTT(slot) {}
 #define WTT_INIT
@@ -92,32 +95,26 @@ __device__ __forceinline__ void bt_hi(float d1, float d2, float d3, float d4, fl
 }
 // output rows of A^T:  y0 = (m0 + (m1 + m2)) + (m3 + m4),  y1 = (m1 - m2) + 2 (m3 - m4),  y2 = (m1 + m2) + 4 (m3 + m4),
 //                      y3 = ((m1 - m2) + 8 (m3 - m4)) + m5
-__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1, float &y2, float &y3)
+// (on PAIRS: v_pk_add_f32 / v_pk_fma_f32 are IEEE per component)
+__device__ __forceinline__ void at6(tf2 m0, tf2 m1, tf2 m2, tf2 m3, tf2 m4, tf2 m5, tf2 &y0, tf2 &y1, tf2 &y2, tf2 &y3)
 {
-    const float pp = m1 + m2, qq = m1 - m2, rr = m3 + m4, ss = m3 - m4;
+    const tf2 pp = m1 + m2, qq = m1 - m2, rr = m3 + m4, ss = m3 - m4;
     y0 = (m0 + pp) + rr;
-    y1 = __builtin_fmaf(2.0f, ss, qq);
-    y2 = __builtin_fmaf(4.0f, rr, pp);
-    y3 = __builtin_fmaf(8.0f, ss, qq) + m5;
+    y1 = __builtin_elementwise_fma(tf2{2.0f, 2.0f}, ss, qq);
+    y2 = __builtin_elementwise_fma(tf2{4.0f, 4.0f}, rr, pp);
+    y3 = __builtin_elementwise_fma(tf2{8.0f, 8.0f}, ss, qq) + m5;
 }
 
 #ifndef FEMASR_WINO_ABL      // ablation experiments (tools/build_debug.sh): bit 0 no patch loads, 1 no U loads, 2 no transform, 3 no MFMAs,
 #define FEMASR_WINO_ABL 0    // 4 no output items, 5 no activation, 6 no staging stores
 #endif
 // SiLU of the staged input.  FAST: x * rcp(1 + exp2(-x log2 e)) on the hardware transcendental units (v_exp_f32 / v_rcp_f32,
-// 1 ulp each; 5 VALU instructions instead of ~28) - the default of the model: these convs sit behind the codebook lookup, the
-// result stays within ~1e-6 relative of the exact form.  !FAST: the IEEE-exact polynomial + division of detmath.h, bit-identical
-// to the oracle (decoder_math 'fp32_strict').
-template <bool FAST>
-__device__ __forceinline__ float act_silu(float t)
-{
-    if (FAST) return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.44269504088896341f));
-    return det_silu(t);
-}
-
-template <int PRO, bool FAST>
+// 1 ulp each) - the default of the model: these convs sit behind the codebook lookup, the result stays within ~1e-6 relative of
+// the exact form.  !FAST: the IEEE-exact polynomial + division of detmath.h, bit-identical to the oracle (decoder_math 'fp32_strict').
+template <int PRO, bool FAST, int NRES>
 __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParams p)
 {
+    constexpr bool HAS1 = NRES >= 1, HAS2 = NRES >= 2;      // residual operands of the epilogue (compile time: no selects per pixel)
         extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ps = smem;                        // [2][W4_PSZ]
     float *Vs = smem + 2 * W4_PSZ;           // [2][W4_VSZ]
@@ -146,10 +143,14 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         sx0[z] = 16 * bx;
     }
 
-    // ---- staging units: float4 = (pixel of the 18x18 patch, channel quad t&1); units t, t + 512, and 34 lanes per wave of a third round
+    // ---- staging units: float4 = (pixel of the 18x18 patch, channel quad t&1); unit u of the 2 x 648: u = t, t + 512, and 34 lanes
+    // per wave of a third round.  The LDS slot of unit u is (u >> 1) * PS + 4 (u & 1) floats whatever its sub-block - the second
+    // sub-block's patch lies right behind the first one's - so ONE per-lane offset serves the three rounds (+ a constant for the
+    // second, + a wave-uniform term for the third).  A unit outside the image (zero padding, invalid sub-block) never changes: its
+    // slot is zeroed once in both buffers and the main loop skips its store under the exec mask (no per-value selects).
     const int quad = t & 1;
     unsigned goff[3];
-    unsigned pmask = 0;
+    unsigned pmask = 0, rmask = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int u = i < 2 ? t + 512 * i : 1024 + wave * 34 + lane;
@@ -162,15 +163,13 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         // byte offset from the first sub-block's image (the second one lies in the same or the next image)
         goff[i] = ok ? (unsigned)((((size_t)(z ? sn[1] - sn[0] : 0) * p.H + y) * p.W + x) * p.Cin + 4 * quad) * 4u : 0u;
         pmask |= (ok ? 1u : 0u) << i;
+        rmask |= (real ? 1u : 0u) << i;
     }
-    // LDS offset / sub-block of unit i, recomputed per use (registers are the scarce resource here; ~3 VALU each)
-    auto unit_loff = [&](int i) -> int {
-        int tq = t;
-        asm volatile("" : "+v"(tq));         // opaque: keeps the compiler from hoisting the offsets out of the K loop into (spilled) registers
-        const int u = i < 2 ? tq + 512 * i : 1024 + wave * 34 + (tq & 63), z = u >= W4_UNITS_SB ? 1 : 0;
-        return z * W4_PPIX * W4_PS + ((u - W4_UNITS_SB * z) >> 1) * W4_PS + 4 * (tq & 1);
-    };
-    auto unit_z = [&](int i) -> int { return i == 0 ? 0 : (i == 1 ? (t >= W4_UNITS_SB - 512 ? 1 : 0) : 1); };
+    const int slot0 = (t >> 1) * W4_PS + 4 * quad;                       // unit 0; unit 1 = + 256 PS; unit 2 = + (512 - 15 wave) PS
+    const int slot2d = (512 - 15 * wave) * W4_PS;                        // (uniform)
+    auto unit_slot = [&](int i) -> int { return i == 0 ? slot0 : (i == 1 ? slot0 + 256 * W4_PS : slot0 + slot2d); };
+    constexpr int KINDS = 2;                                             // GN table rows per sub-block: a, b
+    const int zo1 = t >= W4_UNITS_SB - 512 ? KINDS * p.Cin : 0;          // table offset of unit 1's sub-block (unit 0: first, unit 2: second)
     // buffer loads: descriptor + uniform byte offset in SGPRs, ONE 32-bit per-lane offset register per load (no 64-bit VALU adds)
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void *)(p.in + (size_t)sn[0] * p.H * p.W * p.Cin), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, 0x7fffffff, 0x00020000);
@@ -188,21 +187,33 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         float *Pb = Ps + buf * W4_PSZ;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            if (i == 2 && lane >= 34) continue;
             if (FEMASR_WINO_ABL & 64) { asm volatile("" :: "v"(rp[i].x), "v"(rp[i].y), "v"(rp[i].z), "v"(rp[i].w)); continue; }
             float4 v = rp[i];
             if (PRO == FEMASR_PRO_GN_SILU && !(FEMASR_WINO_ABL & 32)) {
-                const int z = unit_z(i);
-                const float4 ga = ld4(ABs + z * 2 * p.Cin + s * 8 + 4 * quad), gb = ld4(ABs + z * 2 * p.Cin + p.Cin + s * 8 + 4 * quad);
-                v.x = act_silu<FAST>(__builtin_fmaf(v.x, ga.x, gb.x));
-                v.y = act_silu<FAST>(__builtin_fmaf(v.y, ga.y, gb.y));
-                v.z = act_silu<FAST>(__builtin_fmaf(v.z, ga.z, gb.z));
-                v.w = act_silu<FAST>(__builtin_fmaf(v.w, ga.w, gb.w));
+                const float *ab = ABs + (i == 0 ? 0 : (i == 1 ? zo1 : KINDS * p.Cin)) + s * 8 + 4 * quad;
+                const float4 ga = ld4(ab), gb = ld4(ab + p.Cin);
+                if (FAST) {      // x * rcp(1 + exp2(-x log2 e)), two-wide wherever the instruction set is (v_pk_fma / v_pk_mul / v_pk_add)
+                    const tf2 x01 = __builtin_elementwise_fma(tf2{v.x, v.y}, tf2{ga.x, ga.y}, tf2{gb.x, gb.y});
+                    const tf2 x23 = __builtin_elementwise_fma(tf2{v.z, v.w}, tf2{ga.z, ga.w}, tf2{gb.z, gb.w});
+                    const tf2 nl2e = {-1.44269504088896341f, -1.44269504088896341f}, one = {1.0f, 1.0f};
+                    const tf2 e01 = x01 * nl2e, e23 = x23 * nl2e;
+                    const tf2 d01 = tf2{__builtin_amdgcn_exp2f(e01[0]), __builtin_amdgcn_exp2f(e01[1])} + one;
+                    const tf2 d23 = tf2{__builtin_amdgcn_exp2f(e23[0]), __builtin_amdgcn_exp2f(e23[1])} + one;
+                    const tf2 y01 = x01 * tf2{__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1])};
+                    const tf2 y23 = x23 * tf2{__builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
+                    v = make_float4(y01[0], y01[1], y23[0], y23[1]);
+                } else {
+                    v.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
+                    v.y = det_silu(__builtin_fmaf(v.y, ga.y, gb.y));
+                    v.z = det_silu(__builtin_fmaf(v.z, ga.z, gb.z));
+                    v.w = det_silu(__builtin_fmaf(v.w, ga.w, gb.w));
+                }
             }
-            if (!(pmask & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding AFTER the activation
-            float *dst = Pb + unit_loff(i);
-            *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
-            *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
+            if (pmask & (1u << i)) {                      // zero padding AFTER the activation: those slots keep their zeros
+                float *dst = Pb + unit_slot(i);
+                *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
+            }
         }
     };
 
@@ -213,7 +224,6 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     const int tdst = thalf * 18 * 256 + tm * 8 + (tch & 1) * 4 + (tch >> 1);
     // (first pass written on column PAIRS, explicitly two-wide: the patch reads come back as register pairs in exactly this order
     // (ds_read2_b32) and v_pk_fma / v_pk_add take them as they are; left to the vectoriser the same arithmetic cost 44 v_mov per step)
-    typedef float tf2 __attribute__((ext_vector_type(2)));
     tf2 td[5][3];                                          // the transform item's 5 x 6 patch values (rows 3*thalf.. of the 6x6 patch)
     auto transform_read = [&](int pbuf) {
         if (FEMASR_WINO_ABL & 4) return;
@@ -308,11 +318,21 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     };
 
     // ---- prologue
-    if (PRO == FEMASR_PRO_GN_SILU) {
-        for (int i = t; i < 4 * p.Cin; i += W4_NT) {
-            const int z = i / (2 * p.Cin), r = i - z * 2 * p.Cin;
-            const float *src = r < p.Cin ? p.pro_a : p.pro_b;
-            ABs[i] = src[(size_t)(z ? sn[1] : sn[0]) * p.Cin + (r < p.Cin ? r : r - p.Cin)];
+    if (PRO == FEMASR_PRO_GN_SILU) {     // GN table [sub-block][a | b][Cin]
+        for (int i = t; i < 2 * KINDS * p.Cin; i += W4_NT) {
+            const int z = i / (KINDS * p.Cin), r = i - z * KINDS * p.Cin, kind = r / p.Cin, c = r - kind * p.Cin;
+            const float v = ((kind & 1) ? p.pro_b : p.pro_a)[(size_t)(z ? sn[1] : sn[0]) * p.Cin + c];
+            ABs[i] = v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {        // the slots the main loop never writes hold the zero padding in both buffers
+        if (((rmask & ~pmask) >> i) & 1u) {
+            float *dst = Ps + unit_slot(i);
+            *reinterpret_cast<float2 *>(dst) = make_float2(0.f, 0.f);
+            *reinterpret_cast<float2 *>(dst + 2) = make_float2(0.f, 0.f);
+            *reinterpret_cast<float2 *>(dst + W4_PSZ) = make_float2(0.f, 0.f);
+            *reinterpret_cast<float2 *>(dst + W4_PSZ + 2) = make_float2(0.f, 0.f);
         }
     }
     load_patch(0);
@@ -360,106 +380,152 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     }
 
     // ---------------------------------------------------------------------------------------------------------------
-    // epilogue: Mx[component][tile][32 channels] of one column tile at a time overlays the main-loop buffers
+    // epilogue, one 32-column tile (round) at a time: accumulators -> Mx[component][tile pair][channel][2] (overlays the main-loop
+    // buffers; rows e, e + 1 of an accumulator tile are two horizontally adjacent Winograd tiles and sit in an aligned register
+    // pair: one ds_write_b64).  A thread = (tile pair pi = (sub-block, tile row, left / right half), channel c31) handles BOTH tiles
+    // at once: one ds_read_b64 per component, and every operation of the output transform, the bias / residual adds and the moment
+    // sums is a packed fp32 instruction over the pair (component-wise IEEE: the same values as two scalar sequences).  Outputs and
+    // residuals go through buffer instructions: descriptors in SGPRs (base = the image of sub-block 0), ONE 32-bit byte offset per
+    // lane, a uniform offset per pixel and tile of the pair; in a block whose 32 tiles lie wholly inside the image (FULL, the common
+    // case) nothing is masked; otherwise a pixel outside gets an offset beyond num_records (stores dropped, loads return 0).
+    // GroupNorm partial moments of what was stored (orc_gn_wino_partial): per (tile, channel) an fp32 sum and an fp32 fma chain of
+    // squares over the 16 pixels (row-major, a pixel outside adds +0), then fp64: the two tiles of the pair, the channels of the
+    // group (xor butterfly), the two pairs of the tile row, then the four tile rows (= waves) of the sub-block in order.
     float *Mx = smem;
     double *red = reinterpret_cast<double *>(smem + W4_MX);
     const bool gnp = p.gn_part != nullptr;
     const int cg = p.Cout >> 5;                      // channels per GroupNorm group (>= 2: Cout % 64 == 0)
     const int gpt = 32 / (cg < 32 ? cg : 32);        // groups per 32-channel tile (<= 16)
-    const int tl = t >> 5;                           // Winograd tile inside the sub-block: 2 wave + hh
-    const int ety = tl >> 2, etx = tl & 3;
-    // the thread's two output items (sub-block z, tile tl, channel c31 of the round's column tile): validity of the 16 pixels
-    // (bit 4a + b) and the element offset of pixel (0, 0); masked pixels read / address the first valid element instead
-    unsigned vmask[2];
-    size_t obase[2];
+    const int pi = t >> 5;                           // tile pair: rows 2 pi, 2 pi + 1 of the accumulator tiles
+    const int ez = wave >> 2, ety = wave & 3, etx = 2 * hh;      // sub-block (uniform), tile row (uniform), left tile of the pair
+    unsigned vmask[2], ooff;
+    bool full = true;
+    {
+        const int oy = (ez ? sy0[1] : sy0[0]) + 4 * ety, ox = (ez ? sx0[1] : sx0[0]) + 4 * etx;
 #pragma unroll
-    for (int z = 0; z < 2; ++z) {
-        const int oy = (z ? sy0[1] : sy0[0]) + 4 * ety, ox = (z ? sx0[1] : sx0[0]) + 4 * etx;
-        unsigned m = 0;
+        for (int e = 0; e < 2; ++e) {
+            unsigned m = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) m |= ((z ? sval[1] : sval[0]) && oy + (k >> 2) < p.H && ox + (k & 3) < p.W ? 1u : 0u) << k;
-        vmask[z] = m;
-        obase[z] = (m ? (((size_t)(z ? sn[1] : sn[0]) * p.H + oy) * p.W + ox) * p.Cout : (size_t)0) + n0 + c31;
+            for (int k = 0; k < 16; ++k) m |= ((ez ? sval[1] : sval[0]) && oy + (k >> 2) < p.H && ox + 4 * e + (k & 3) < p.W ? 1u : 0u) << k;
+            vmask[e] = m;
+        }
+        ooff = (unsigned)(((((size_t)(ez ? sn[1] - sn[0] : 0) * p.H + oy) * p.W + ox) * p.Cout + n0 + c31) * 4);
+#pragma unroll
+        for (int z = 0; z < 2; ++z) full = full && (z ? sval[1] : sval[0]) && (z ? sy0[1] : sy0[0]) + 16 <= p.H && (z ? sx0[1] : sx0[0]) + 16 <= p.W;      // (uniform)
     }
-    auto eoff = [&](int k) -> unsigned { return (unsigned)((k >> 2) * p.W + (k & 3)) * (unsigned)p.Cout; };      // uniform
-    auto fetch = [&](const float *src, int z, int r, float (&dst)[16]) {       // branch-free batch of 16 loads
-        const float *bp = src + obase[z] + 32 * r;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) dst[k] = bp[(vmask[z] >> k) & 1u ? eoff(k) : 0u];
+    const size_t img0 = (size_t)sn[0] * p.H * p.W * p.Cout;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(p.out + img0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc((void *)((HAS1 ? p.res1 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc((void *)((HAS2 ? p.res2 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
+    auto soff = [&](int k, int e, int r) -> int { return (((k >> 2) * p.W + 4 * e + (k & 3)) * p.Cout + 32 * r) * 4; };      // uniform bytes
+    // !FULL: all-ones where pixel k of tile e lies outside the image (two shifts on the lane's mask word; OR-ed into the offset,
+    // AND-NOT-ed into the moment operand) - per-lane arithmetic, not 32 exec masks held in scalar registers
+    auto oob = [&](int e, int k) -> unsigned { return ~(unsigned)((int)(vmask[e] << (31 - k)) >> 31); };
+    auto voff = [&](auto fullc, int e, int k) -> unsigned {
+        if (decltype(fullc)::value) return ooff;
+        return ooff | oob(e, k);
     };
-    auto item = [&](int z, int r, float bv, const float (&r1)[16], const float (&r2)[16]) {
-        const float *src = Mx + (z * 16 + tl) * 32 + c31;
-        float tt[4][6];
+    auto fetch = [&](auto fullc, const __amdgpu_buffer_rsrc_t rs, int r, tf2 (&dst)[16]) {       // 32 loads, no waits between
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-            at6(src[(0 * 6 + j) * 1024], src[(1 * 6 + j) * 1024], src[(2 * 6 + j) * 1024], src[(3 * 6 + j) * 1024], src[(4 * 6 + j) * 1024],
-                src[(5 * 6 + j) * 1024], tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
-        float *bo = p.out + obase[z] + 32 * r;
-        double gs = 0.0, gss = 0.0;
+        for (int k = 0; k < 16; ++k) {
+            dst[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 0, k), soff(k, 0, r), 0));
+            dst[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 1, k), soff(k, 1, r), 0));
+        }
+    };
+    auto round = [&](auto fullc, int r) {
+        constexpr bool FULL = decltype(fullc)::value;
+        tf2 r1[16], r2[16];                                // residuals of both tiles
+        if (!FULL) asm volatile("" : "+v"(vmask[0]), "+v"(vmask[1]));      // (opaque: the per-pixel masks are not to be hoisted out of the round loop)
+        if (HAS1) fetch(fullc, rs_r1, r, r1);              // in flight across the barrier and the first transform pass
+        const float bv = p.bias[n0 + 32 * r + c31];
+        __syncthreads();
+        WTT(6)
+        if (!(FEMASR_WINO_ABL & 16)) {
+            // component stride: 16 tile pairs x 32 channels = 4 KiB; three bases keep every read inside the 64-KiB offset field
+            int so1 = (16 * 512 + pi * 32 + c31) * 8, so2 = (32 * 512 + pi * 32 + c31) * 8;
+            asm volatile("" : "+v"(so1), "+v"(so2));
+            const tf2 *src0 = reinterpret_cast<const tf2 *>(Mx) + pi * 32 + c31;
+            const tf2 *src1 = reinterpret_cast<const tf2 *>(reinterpret_cast<const char *>(Mx) + so1), *src2 = reinterpret_cast<const tf2 *>(reinterpret_cast<const char *>(Mx) + so2);
+            auto mx = [&](int c) -> tf2 { return c < 16 ? src0[c * 512] : (c < 32 ? src1[(c - 16) * 512] : src2[(c - 32) * 512]); };
+            tf2 tt[4][6];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            float y[4];
-            at6(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
+            for (int j = 0; j < 6; ++j)
+                at6(mx(0 * 6 + j), mx(1 * 6 + j), mx(2 * 6 + j), mx(3 * 6 + j), mx(4 * 6 + j), mx(5 * 6 + j), tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
+            if (HAS2) fetch(fullc, rs_r2, r, r2);          // (rare: the skip feature of a decoder stage; behind the first pass, whose registers it takes)
+            const tf2 bv2 = {bv, bv};
+            tf2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int k = 4 * a + b;
-                const bool ok = (vmask[z] >> k) & 1u;
-                float v = y[b] + bv;
-                if (p.res1) v = v + r1[k];
-                if (p.res2) v = v + r2[k];
-                if (ok) bo[eoff(k)] = v;
-                if (gnp) {                                   // a masked pixel adds +0 (the oracle skips it: same sums)
-                    const double dv = ok ? (double)v : 0.0;
-                    gs = gs + dv;
-                    gss = __builtin_fma(dv, dv, gss);
+            for (int a = 0; a < 4; ++a) {
+                tf2 y[4];
+                at6(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int k = 4 * a + b;
+                    tf2 v = y[b] + bv2;
+                    if (HAS1) v = v + r1[k];
+                    if (HAS2) v = v + r2[k];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), rs_out, voff(fullc, 0, k), soff(k, 0, r), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), rs_out, voff(fullc, 1, k), soff(k, 1, r), 0);
+                    if (gnp) {
+                        if (!FULL) {
+                            v[0] = __uint_as_float(__float_as_uint(v[0]) & ~oob(0, k));
+                            v[1] = __uint_as_float(__float_as_uint(v[1]) & ~oob(1, k));
+                        }
+                        s2 = s2 + v;
+                        ss2 = __builtin_elementwise_fma(v, v, ss2);
+                    }
+                }
+            }
+            if (gnp) {      // fp64 from here
+                double gs = (double)s2[0] + (double)s2[1], gss = (double)ss2[0] + (double)ss2[1];
+                for (int d = 1; d < cg && d < 32; d <<= 1) {
+                    gs = gs + __shfl_xor(gs, d, 64);
+                    gss = gss + __shfl_xor(gss, d, 64);
+                }
+                const double a2 = gs + __shfl_xor(gs, 32, 64), b2 = gss + __shfl_xor(gss, 32, 64);
+                if (lane < 32 && (c31 & (cg - 1)) == 0) {
+                    double *dst = red + ((size_t)wave * 16 + c31 / cg) * 2;
+                    dst[0] = a2;
+                    dst[1] = b2;
                 }
             }
         }
-        if (gnp) {      // channels of the group (xor butterfly), the tile pair of the wave, then the 8 waves in order
-            for (int d = 1; d < cg && d < 32; d <<= 1) {
-                gs = gs + __shfl_xor(gs, d, 64);
-                gss = gss + __shfl_xor(gss, d, 64);
-            }
-            const double a2 = gs + __shfl_xor(gs, 32, 64), b2 = gss + __shfl_xor(gss, 32, 64);
-            if (lane < 32 && (c31 & (cg - 1)) == 0) {
-                double *dst = red + ((size_t)(wave * 2 + z) * 16 + c31 / cg) * 2;
-                dst[0] = a2;
-                dst[1] = b2;
+        WTT(7)
+    };
+    // (two per-lane bases, pinned: a wave's pairs 0-7 are the four consecutive components 4 wave .., pair 8 is component
+    // 32 + wave / 2; everything else is an immediate offset - left alone the compiler keeps one address register per component)
+    // (the opaque values are integer offsets: an opaque POINTER loses its LDS address space and turns the accesses into flat ones)
+    int wo0 = (4 * wave) * 4096 + hh * 512 + c31 * 8, wo1 = (32 + (wave >> 1)) * 4096 + hh * 512 + c31 * 8;
+    asm volatile("" : "+v"(wo0), "+v"(wo1));
+    char *wb0 = reinterpret_cast<char *>(Mx) + wo0, *wb1 = reinterpret_cast<char *>(Mx) + wo1;
+    auto write_acc = [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (pntl(q) == R) {
+                char *dst = q < 8 ? wb0 + (q >> 1) * 4096 : wb1;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2)      // pair row ((e & 3) + 8 (e >> 2) + 4 hh) / 2, 256 bytes each
+                    *reinterpret_cast<tf2 *>(dst + (((e & 3) >> 1) + 4 * (e >> 2)) * 256) = tf2{acc[q][e], acc[q][e + 1]};
             }
         }
     };
-#pragma unroll
+    write_acc(std::integral_constant<int, 0>{});          // (ahead of the round loop: these tiles' registers are free from here on)
+#pragma unroll 1
     for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            if (pntl(q) == r) {
-                float *dst = Mx + pcomp(q) * 1024 + c31;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32] = acc[q][e];
-            }
-        }
-        float ra1[16], ra2[16], rb1[16], rb2[16];          // residuals of the two items: in flight across the barrier / the first item
-        if (p.res1) fetch(p.res1, 0, r, ra1);
-        if (p.res2) fetch(p.res2, 0, r, ra2);
-        const float bv = p.bias[n0 + 32 * r + c31];
-        __syncthreads();
+        if (r == 1) write_acc(std::integral_constant<int, 1>{});
         WTT(5)
-        if (p.res1) fetch(p.res1, 1, r, rb1);
-        if (p.res2) fetch(p.res2, 1, r, rb2);
-        if (!(FEMASR_WINO_ABL & 16)) {
-            item(0, r, bv, ra1, ra2);
-            item(1, r, bv, rb1, rb2);
-        }
+        if (full) round(std::true_type{}, r); else round(std::false_type{}, r);
         __syncthreads();
-        WTT(6)
+        WTT(8)
         if (gnp && t < 2 * gpt) {
             const int z = t / gpt, gl = t - z * gpt;
             if (z ? sval[1] : sval[0]) {
-                double S = red[((size_t)(0 * 2 + z) * 16 + gl) * 2], SS = red[((size_t)(0 * 2 + z) * 16 + gl) * 2 + 1];
+                double S = red[((size_t)(4 * z) * 16 + gl) * 2], SS = red[((size_t)(4 * z) * 16 + gl) * 2 + 1];
 #pragma unroll
-                for (int w = 1; w < 8; ++w) {
-                    S = S + red[((size_t)(w * 2 + z) * 16 + gl) * 2];
-                    SS = SS + red[((size_t)(w * 2 + z) * 16 + gl) * 2 + 1];
+                for (int w = 1; w < 4; ++w) {
+                    S = S + red[((size_t)(4 * z + w) * 16 + gl) * 2];
+                    SS = SS + red[((size_t)(4 * z + w) * 16 + gl) * 2 + 1];
                 }
                 const int g = (n0 + 32 * r) / cg + gl;
                 double *dst = p.gn_part + (((size_t)(z ? sn[1] : sn[0]) * p.sbY * p.sbX + (z ? sbi[1] : sbi[0])) * 32 + g) * 2;
@@ -518,22 +584,29 @@ struct WVariant {
     unsigned long long attr_devs;
     size_t attr_lds;
 };
-#define FEMASR_WINO(PRO, FAST) { "conv3x3_wino4<2x16x16px x64," #PRO "," #FAST ",waves=8>", conv3x3_wino4_kernel<PRO, FAST>, 0ull, 0 }
-WVariant g_wv[] = {
-    FEMASR_WINO(FEMASR_PRO_NONE, false),
-    FEMASR_WINO(FEMASR_PRO_GN_SILU, false),       // exact SiLU
-    FEMASR_WINO(FEMASR_PRO_GN_SILU, true),        // hardware exp2 / rcp SiLU
+#define FEMASR_WINO(PRO, FAST, NRES) { "conv3x3_wino4<2x16x16px x64," #PRO "," #FAST ",res=" #NRES ",waves=8>", conv3x3_wino4_kernel<PRO, FAST, NRES>, 0ull, 0 }
+#define FEMASR_WINO3(PRO, FAST) FEMASR_WINO(PRO, FAST, 0), FEMASR_WINO(PRO, FAST, 1), FEMASR_WINO(PRO, FAST, 2)
+WVariant g_wv[] = {                               // index = 3 * (prologue form) + residual operands
+    FEMASR_WINO3(FEMASR_PRO_NONE, false),
+    FEMASR_WINO3(FEMASR_PRO_GN_SILU, false),      // exact SiLU
+    FEMASR_WINO3(FEMASR_PRO_GN_SILU, true),       // hardware exp2 / rcp SiLU
 };
 constexpr int kNumW = sizeof(g_wv) / sizeof(g_wv[0]);
 
 }  // namespace
 
+static std::atomic<int> g_log2_total{31}, g_log2_image{27};
+size_t femasr_wino_limit_total() { return (size_t)1 << g_log2_total.load(std::memory_order_relaxed); }
+size_t femasr_wino_limit_image() { return (size_t)1 << g_log2_image.load(std::memory_order_relaxed); }
+
 bool femasr_conv_wino_shape_ok(const femasr_conv_args *a)
 {
+    const size_t tot = femasr_wino_limit_total(), img = femasr_wino_limit_image();
     return a->ksz == 3 && a->stride == 1 && a->pad == 1 && !a->up2 && a->act == FEMASR_ACT_NONE && (a->Cin % BK) == 0 && a->Cin <= 1024 &&
            (a->Cout % 64) == 0 && (a->prologue == FEMASR_PRO_NONE || a->prologue == FEMASR_PRO_GN_SILU) &&
-           (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31) && (size_t)a->B * a->H * a->W * a->Cout < ((size_t)1 << 31) &&
-           (size_t)a->H * a->W * a->Cin < ((size_t)1 << 27) &&          // two images within the 2 GiB range of the input descriptor
+           (size_t)a->B * a->H * a->W * a->Cin < tot && (size_t)a->B * a->H * a->W * a->Cout < tot &&
+           (size_t)a->H * a->W * a->Cin < img &&          // two images within the 2 GiB range of the input descriptor
+           (size_t)a->H * a->W * a->Cout < img &&         // ... and of the output / residual descriptors
            (size_t)36 * a->Cin * a->Cout < ((size_t)1 << 29);
 }
 int femasr_conv_wino_variant_count() { return kNumW; }
@@ -558,7 +631,8 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
     p.NB = a->Cout / 64;
     p.nsteps = a->Cin / 8;
     p.NT32 = a->Cout / 32;
-    const int vi = gn ? (a->fast_act ? 2 : 1) : 0;
+    FEMASR_REQUIRE(a->res1 || !a->res2, "conv_wino: res2 without res1");
+    const int vi = 3 * (gn ? (a->fast_act ? 2 : 1) : 0) + (a->res1 ? (a->res2 ? 2 : 1) : 0);
     WVariant &v = g_wv[vi];
     const size_t lds = wino_lds_bytes(a->Cin, gn);
     int dev = 0;
@@ -578,11 +652,19 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
 
 extern "C" {
 
+int femasr_debug_wino_limits(int log2_total, int log2_image)
+{
+    FEMASR_REQUIRE(log2_total >= 0 && log2_total <= 31 && log2_image >= 0 && log2_image <= 27, "debug_wino_limits: exponents are 0 (default) or up to 31 / 27");
+    g_log2_total.store(log2_total ? log2_total : 31, std::memory_order_relaxed);
+    g_log2_image.store(log2_image ? log2_image : 27, std::memory_order_relaxed);
+    return FEMASR_OK;
+}
+
 #ifdef FEMASR_WINO_TT
 int femasr_debug_wino_time(unsigned long long *buf, int reset)
 {
-    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wi_tt), z, sizeof(z)); }
-    return (int)hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_wi_tt), 8 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wi_tt), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_wi_tt), 16 * sizeof(unsigned long long));
 }
 #endif
 

@@ -25,9 +25,22 @@
 //   epilogue  Mx[25][32][32] per column tile, thread = (tile, channel) applies the 5 -> 4 output transform twice
 #include "conv_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float tf2 __attribute__((ext_vector_type(2)));
+
+#ifdef FEMASR_WINO_TT      // tools/build_debug.sh: per-wave cycle shares of the kernel's phases
+__device__ unsigned long long g_wu_tt[16];
+#define WUTT(slot) { const unsigned long long now_ = __builtin_readcyclecounter(); tt_acc[slot] += now_ - tt_last; tt_last = now_; }
+#define WUTT_INIT unsigned long long tt_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tt_last = __builtin_readcyclecounter(); const unsigned long long tt_first = tt_last;
+#define WUTT_END { if (lane == 0) { for (int i_ = 0; i_ < 15; ++i_) atomicAdd(&g_wu_tt[i_], tt_acc[i_]); atomicAdd(&g_wu_tt[15], __builtin_readcyclecounter() - tt_first); } }
+#else
+#define WUTT(slot) {}
+#define WUTT_INIT
+#define WUTT_END {}
+#endif
 
 namespace {
 
@@ -53,22 +66,26 @@ constexpr int WU_UNITS = 2 * WU_PPIX * 2;         // float4 staging units per st
 
 inline size_t wino_up_lds_bytes() { return (size_t)((WU_MX + WU_RED) > WU_MAIN ? (WU_MX + WU_RED) : WU_MAIN) * sizeof(float); }
 
-// output rows of the 5 -> 4 transform (see the header)
-__device__ __forceinline__ void at5(float m0, float m1, float mP, float mQ, float m5, float &y0, float &y1, float &y2, float &y3)
+// output rows of the 5 -> 4 transform (see the header), on PAIRS (two horizontally adjacent tiles): v_pk_add_f32 / v_pk_fma_f32
+// are IEEE per component
+__device__ __forceinline__ void at5(tf2 m0, tf2 m1, tf2 mP, tf2 mQ, tf2 m5, tf2 &y0, tf2 &y1, tf2 &y2, tf2 &y3)
 {
     y0 = (m0 + m1) + mP;
-    y1 = __builtin_fmaf(2.0f, mQ, m1);
-    y2 = __builtin_fmaf(4.0f, mP, m1);
-    y3 = __builtin_fmaf(8.0f, mQ, m1) + m5;
+    y1 = __builtin_elementwise_fma(tf2{2.0f, 2.0f}, mQ, m1);
+    y2 = __builtin_elementwise_fma(tf2{4.0f, 4.0f}, mP, m1);
+    y3 = __builtin_elementwise_fma(tf2{8.0f, 8.0f}, mQ, m1) + m5;
 }
 
+template <int NRES>
 __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUpParams p)
 {
+    constexpr bool HAS1 = NRES >= 1, HAS2 = NRES >= 2;      // residual operands of the epilogue (compile time; the network's x2 convs have none)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ps = smem;                        // [2][WU_PSZ]
     float *Vs = smem + 2 * WU_PSZ;           // [2][WU_VSZ]
 
     const int t = threadIdx.x, lane = t & 63;
+    WUTT_INIT
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c31 = lane & 31, hh = lane >> 5;
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
@@ -219,6 +236,7 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     store_patch(1);
     issue_early(0);
     __syncthreads();
+    WUTT(0)
 
     // ---- main loop.  Per step: M(s); transform of step s+1 (its patch was staged during step s-1); stage step s+2.
     // (Measured and dropped: 32-channel blocks with half the accumulators, <= 128 VGPRs and a 16-column epilogue exchange, so that
@@ -229,120 +247,159 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     // control flow also costs a spilled accumulator tile per step.)
     for (int s = 0; s < p.nsteps; ++s) {
         mphase(s);
+        WUTT(1)
         transform_read((s + 1) & 1);          // (unconditional: after the last step it transforms a stale patch into a dead buffer)
         __builtin_amdgcn_sched_barrier(0);
         transform_write((s + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         store_patch(s & 1);                   // step s+2 (loaded during the M phase) -> the buffer the transform of step s read a barrier ago
         issue_early(s + 1);
+        WUTT(2)
         __syncthreads();
+        WUTT(7)
     }
 
     // ---------------------------------------------------------------------------------------------------------------
-    // epilogue: Mx[component][tile][32 channels] of one column tile at a time overlays the main-loop buffers
+    // epilogue = the F(4x4,3x3) kernel's (kernels_wino.hip), with 25 components and the 5 -> 4 transform: one 32-column tile
+    // (round) at a time, accumulators -> Mx[component][tile pair][channel][2] (rows e, e + 1 of an accumulator tile = two
+    // horizontally adjacent tiles = one aligned register pair = one ds_write_b64); a thread = (tile pair, channel) runs both tiles
+    // as packed fp32; outputs / residuals through buffer instructions with one per-lane offset; nothing is masked in a block
+    // whose 32 tiles lie inside the image (FULL); GroupNorm partial moments in the order of orc_gn_wino_partial.
     float *Mx = smem;
     double *red = reinterpret_cast<double *>(smem + WU_MX);
     const bool gnp = p.gn_part != nullptr;
     const int cg = p.Cout >> 5;                      // channels per GroupNorm group (>= 2: Cout % 64 == 0)
     const int gpt = 32 / (cg < 32 ? cg : 32);        // groups per 32-channel tile (<= 16)
-    const int tl = t >> 5;                           // tile inside the sub-block: 2 wave + hh
-    const int ety = tl >> 2, etx = tl & 3;
-    // Outputs and residuals go through BUFFER instructions: descriptor in SGPRs (base = the image of sub-block 0), ONE 32-bit byte
-    // offset per lane and sub-block, a uniform offset per pixel of the tile / round; a pixel outside the image gets an offset
-    // beyond num_records (stores are dropped, loads return 0).  No 64-bit address arithmetic, no exec masking per pixel.
-    unsigned vmask[2], ooff[2];
+    const int pi = t >> 5;                           // tile pair: rows 2 pi, 2 pi + 1 of the accumulator tiles
+    const int ez = wave >> 2, ety = wave & 3, etx = 2 * hh;      // sub-block (uniform), tile row (uniform), left tile of the pair
+    unsigned vmask[2], ooff;
+    bool full = true;
+    {
+        const int oy = (ez ? sy0[1] : sy0[0]) + 4 * ety, ox = (ez ? sx0[1] : sx0[0]) + 4 * etx;
 #pragma unroll
-    for (int z = 0; z < 2; ++z) {
-        const int oy = (z ? sy0[1] : sy0[0]) + 4 * ety, ox = (z ? sx0[1] : sx0[0]) + 4 * etx;
-        unsigned m = 0;
+        for (int e = 0; e < 2; ++e) {
+            unsigned m = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) m |= ((z ? sval[1] : sval[0]) && oy + (k >> 2) < p.Ho && ox + (k & 3) < p.Wo ? 1u : 0u) << k;
-        vmask[z] = m;
-        ooff[z] = (unsigned)(((((size_t)(z ? sn[1] - sn[0] : 0) * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + c31) * 4);
+            for (int k = 0; k < 16; ++k) m |= ((ez ? sval[1] : sval[0]) && oy + (k >> 2) < p.Ho && ox + 4 * e + (k & 3) < p.Wo ? 1u : 0u) << k;
+            vmask[e] = m;
+        }
+        ooff = (unsigned)(((((size_t)(ez ? sn[1] - sn[0] : 0) * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + c31) * 4);
+#pragma unroll
+        for (int z = 0; z < 2; ++z) full = full && (z ? sval[1] : sval[0]) && (z ? sy0[1] : sy0[0]) + 16 <= p.Ho && (z ? sx0[1] : sx0[0]) + 16 <= p.Wo;      // (uniform)
     }
     const size_t img0 = (size_t)sn[0] * p.Ho * p.Wo * p.Cout;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(p.out + img0), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc((void *)((p.res1 ? p.res1 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc((void *)((p.res2 ? p.res2 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
-    auto soff = [&](int k, int r) -> int { return (((k >> 2) * p.Wo + (k & 3)) * p.Cout + 32 * r) * 4; };      // uniform bytes
-    auto fetch = [&](const __amdgpu_buffer_rsrc_t rs, int z, int r, float (&dst)[16]) {       // 16 loads, no waits between
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            dst[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (vmask[z] >> k) & 1u ? ooff[z] : 0xffffffffu, soff(k, r), 0));
+    const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc((void *)((HAS1 ? p.res1 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc((void *)((HAS2 ? p.res2 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
+    auto soff = [&](int k, int e, int r) -> int { return (((k >> 2) * p.Wo + 4 * e + (k & 3)) * p.Cout + 32 * r) * 4; };      // uniform bytes
+    auto oob = [&](int e, int k) -> unsigned { return ~(unsigned)((int)(vmask[e] << (31 - k)) >> 31); };      // all-ones: pixel k of tile e is outside
+    auto voff = [&](auto fullc, int e, int k) -> unsigned {
+        if (decltype(fullc)::value) return ooff;
+        return ooff | oob(e, k);
     };
-    auto item = [&](int z, int r, float bv, const float (&r1)[16], const float (&r2)[16]) {
-        const float *src = Mx + (z * 16 + tl) * 32 + c31;
-        float tt[4][5];
+    auto fetch = [&](auto fullc, const __amdgpu_buffer_rsrc_t rs, int r, tf2 (&dst)[16]) {       // 32 loads, no waits between
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
-            at5(src[(0 * 5 + j) * 1024], src[(1 * 5 + j) * 1024], src[(2 * 5 + j) * 1024], src[(3 * 5 + j) * 1024], src[(4 * 5 + j) * 1024],
-                tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
-        double gs = 0.0, gss = 0.0;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            float y[4];
-            at5(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], y[0], y[1], y[2], y[3]);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int k = 4 * a + b;
-                const bool ok = (vmask[z] >> k) & 1u;
-                float v = y[b] + bv;
-                if (p.res1) v = v + r1[k];
-                if (p.res2) v = v + r2[k];
-#ifdef FEMASR_WUP_NOSTORE          // experiment: everything but the output stores (tools/build_debug.sh)
-                if (p.nsteps < 0)
-#endif
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, ok ? ooff[z] : 0xffffffffu, soff(k, r), 0);
-                if (gnp) {                                   // a masked pixel adds +0 (the oracle skips it: same sums)
-                    const double dv = (double)(ok ? v : 0.0f);
-                    gs = gs + dv;
-                    gss = __builtin_fma(dv, dv, gss);
-                }
-            }
-        }
-        if (gnp) {      // channels of the group (xor butterfly), the tile pair of the wave, then the 8 waves in order
-            for (int d = 1; d < cg && d < 32; d <<= 1) {
-                gs = gs + __shfl_xor(gs, d, 64);
-                gss = gss + __shfl_xor(gss, d, 64);
-            }
-            const double a2 = gs + __shfl_xor(gs, 32, 64), b2 = gss + __shfl_xor(gss, 32, 64);
-            if (lane < 32 && (c31 & (cg - 1)) == 0) {
-                double *dst = red + ((size_t)(wave * 2 + z) * 16 + c31 / cg) * 2;
-                dst[0] = a2;
-                dst[1] = b2;
-            }
+        for (int k = 0; k < 16; ++k) {
+            dst[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 0, k), soff(k, 0, r), 0));
+            dst[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 1, k), soff(k, 1, r), 0));
         }
     };
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (wnt == r) {
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                if (q < 6 || has6) {
-                    float *dst = Mx + (wcomp0 + 4 * q) * 1024 + c31;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32] = acc[q][e];
-                }
-            }
-        }
+    auto round = [&](auto fullc, int r) {
+        constexpr bool FULL = decltype(fullc)::value;
+        tf2 r1[16], r2[16];
+        if (!FULL) asm volatile("" : "+v"(vmask[0]), "+v"(vmask[1]));      // (opaque: the per-pixel masks are not to be hoisted out of the round loop)
+        if (HAS1) fetch(fullc, rs_r1, r, r1);
         const float bv = p.bias[n0 + 32 * r + c31];
         __syncthreads();
+        WUTT(4)
+        {
+            // component stride: 16 tile pairs x 32 channels = 4 KiB; two bases keep every read inside the 64-KiB offset field
+            int so1 = (16 * 512 + pi * 32 + c31) * 8;
+            asm volatile("" : "+v"(so1));
+            const tf2 *src0 = reinterpret_cast<const tf2 *>(Mx) + pi * 32 + c31;
+            const tf2 *src1 = reinterpret_cast<const tf2 *>(reinterpret_cast<const char *>(Mx) + so1);
+            auto mx = [&](int c) -> tf2 { return c < 16 ? src0[c * 512] : src1[(c - 16) * 512]; };
+            tf2 tt[4][5];
 #pragma unroll
-        for (int z = 0; z < 2; ++z) {
-            float r1[16], r2[16];                          // (the network's x2 convs have no residual operands: no prefetch across items)
-            if (p.res1) fetch(rs_r1, z, r, r1);
-            if (p.res2) fetch(rs_r2, z, r, r2);
-            item(z, r, bv, r1, r2);
+            for (int j = 0; j < 5; ++j)
+                at5(mx(0 * 5 + j), mx(1 * 5 + j), mx(2 * 5 + j), mx(3 * 5 + j), mx(4 * 5 + j), tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
+            if (HAS2) fetch(fullc, rs_r2, r, r2);
+            const tf2 bv2 = {bv, bv};
+            tf2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                tf2 y[4];
+                at5(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], y[0], y[1], y[2], y[3]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int k = 4 * a + b;
+                    tf2 v = y[b] + bv2;
+                    if (HAS1) v = v + r1[k];
+                    if (HAS2) v = v + r2[k];
+#ifdef FEMASR_WUP_NOSTORE          // experiment: everything but the output stores (tools/build_debug.sh)
+                    if (p.nsteps < 0)
+#endif
+                    {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), rs_out, voff(fullc, 0, k), soff(k, 0, r), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), rs_out, voff(fullc, 1, k), soff(k, 1, r), 0);
+                    }
+                    if (gnp) {
+                        if (!FULL) {
+                            v[0] = __uint_as_float(__float_as_uint(v[0]) & ~oob(0, k));
+                            v[1] = __uint_as_float(__float_as_uint(v[1]) & ~oob(1, k));
+                        }
+                        s2 = s2 + v;
+                        ss2 = __builtin_elementwise_fma(v, v, ss2);
+                    }
+                }
+            }
+            if (gnp) {      // fp64 from here: the two tiles of the pair, the channels of the group (xor butterfly), the two pairs of the tile row
+                double gs = (double)s2[0] + (double)s2[1], gss = (double)ss2[0] + (double)ss2[1];
+                for (int d = 1; d < cg && d < 32; d <<= 1) {
+                    gs = gs + __shfl_xor(gs, d, 64);
+                    gss = gss + __shfl_xor(gss, d, 64);
+                }
+                const double a2 = gs + __shfl_xor(gs, 32, 64), b2 = gss + __shfl_xor(gss, 32, 64);
+                if (lane < 32 && (c31 & (cg - 1)) == 0) {
+                    double *dst = red + ((size_t)wave * 16 + c31 / cg) * 2;
+                    dst[0] = a2;
+                    dst[1] = b2;
+                }
+            }
         }
+        WUTT(5)
+    };
+    // (one per-lane base, pinned as an integer offset: a wave's pairs are the components wave / 2 + 4 q; everything else is an
+    // immediate offset)
+    int wo0 = wcomp0 * 4096 + hh * 512 + c31 * 8;
+    asm volatile("" : "+v"(wo0));
+    char *wb0 = reinterpret_cast<char *>(Mx) + wo0;
+    auto write_acc = [&]() {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            if (q < 6 || has6) {
+                char *dst = wb0 + q * 4 * 4096;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2)      // pair row ((e & 3) + 8 (e >> 2) + 4 hh) / 2, 256 bytes each
+                    *reinterpret_cast<tf2 *>(dst + (((e & 3) >> 1) + 4 * (e >> 2)) * 256) = tf2{acc[q][e], acc[q][e + 1]};
+            }
+        }
+    };
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        if (wnt == r) write_acc();
+        WUTT(3)
+        if (full) round(std::true_type{}, r); else round(std::false_type{}, r);
         __syncthreads();
+        WUTT(6)
         if (gnp && t < 2 * gpt) {
             const int z = t / gpt, gl = t - z * gpt;
             if (z ? sval[1] : sval[0]) {
-                double S = red[((size_t)(0 * 2 + z) * 16 + gl) * 2], SS = red[((size_t)(0 * 2 + z) * 16 + gl) * 2 + 1];
+                double S = red[((size_t)(4 * z) * 16 + gl) * 2], SS = red[((size_t)(4 * z) * 16 + gl) * 2 + 1];
 #pragma unroll
-                for (int w = 1; w < 8; ++w) {
-                    S = S + red[((size_t)(w * 2 + z) * 16 + gl) * 2];
-                    SS = SS + red[((size_t)(w * 2 + z) * 16 + gl) * 2 + 1];
+                for (int w = 1; w < 4; ++w) {
+                    S = S + red[((size_t)(4 * z + w) * 16 + gl) * 2];
+                    SS = SS + red[((size_t)(4 * z + w) * 16 + gl) * 2 + 1];
                 }
                 const int g = (n0 + 32 * r) / cg + gl;
                 double *dst = p.gn_part + (((size_t)(z ? sn[1] : sn[0]) * p.sbY * p.sbX + (z ? sbi[1] : sbi[0])) * 32 + g) * 2;
@@ -351,6 +408,7 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
             }
         }
     }
+    WUTT_END
 }
 
 // the five 1-D filters of the form (header): rows (over ky) then columns (over kx)
@@ -391,7 +449,9 @@ __global__ void repack_wino_up2_kernel(const float *__restrict__ in, int O, int 
     }
 }
 
-unsigned long long g_attr_devs = 0;
+typedef void (*wu_kern_t)(const WinoUpParams);
+wu_kern_t g_wu_kern[3] = {conv3x3_wino_up2_kernel<0>, conv3x3_wino_up2_kernel<1>, conv3x3_wino_up2_kernel<2>};      // by residual operands
+unsigned long long g_attr_devs[3] = {0, 0, 0};
 
 }  // namespace
 
@@ -399,9 +459,9 @@ bool femasr_conv_wino_up2_shape_ok(const femasr_conv_args *a)
 {
     return a->ksz == 3 && a->stride == 1 && a->pad == 1 && a->up2 && a->act == FEMASR_ACT_NONE && a->prologue == FEMASR_PRO_NONE &&
            (a->Cin % BK) == 0 && a->Cin <= 1024 && (a->Cout % 64) == 0 &&
-           (size_t)a->B * a->H * a->W * a->Cin < ((size_t)1 << 31) && (size_t)a->B * 4 * a->H * a->W * a->Cout < ((size_t)1 << 31) &&
-           (size_t)a->H * a->W * a->Cin < ((size_t)1 << 27) &&          // two images within the 2 GiB range of the input descriptor
-           (size_t)4 * a->H * a->W * a->Cout < ((size_t)1 << 27) &&     // ... and of the output descriptor
+           (size_t)a->B * a->H * a->W * a->Cin < femasr_wino_limit_total() && (size_t)a->B * 4 * a->H * a->W * a->Cout < femasr_wino_limit_total() &&
+           (size_t)a->H * a->W * a->Cin < femasr_wino_limit_image() &&          // two images within the 2 GiB range of the input descriptor
+           (size_t)4 * a->H * a->W * a->Cout < femasr_wino_limit_image() &&     // ... and of the output descriptor
            (size_t)25 * a->Cin * a->Cout < ((size_t)1 << 29);
 }
 const char *femasr_conv_wino_up2_variant_name() { return "conv3x3_wino_up2<2x16x16px x64,waves=8>"; }
@@ -422,14 +482,16 @@ int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double
     p.NB = a->Cout / 64;
     p.nsteps = a->Cin / 8;
     p.NT32 = a->Cout / 32;
+    FEMASR_REQUIRE(a->res1 || !a->res2, "conv_wino_up2: res2 without res1");
+    const int nres = a->res1 ? (a->res2 ? 2 : 1) : 0;
     const size_t lds = wino_up_lds_bytes();
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !((g_attr_devs >> dev) & 1ull)) {
-        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wino_up2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev >= 0 && dev < 64) g_attr_devs |= 1ull << dev;
+    if (dev < 0 || dev >= 64 || !((g_attr_devs[nres] >> dev) & 1ull)) {
+        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)g_wu_kern[nres], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) g_attr_devs[nres] |= 1ull << dev;
     }
-    hipLaunchKernelGGL(conv3x3_wino_up2_kernel, dim3((unsigned)(p.MB * p.NB)), dim3(WU_NT), lds, s, p);
+    hipLaunchKernelGGL(g_wu_kern[nres], dim3((unsigned)(p.MB * p.NB)), dim3(WU_NT), lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());
     // ALGORITHMIC flops (the definition's 9 taps per output pixel, like every other conv launcher); the kernel issues 25/144 of them
     if (flops_out) *flops_out = 2.0 * (double)a->B * a->Ho * a->Wo * 9.0 * (double)a->Cin * (double)a->Cout;
@@ -437,6 +499,14 @@ int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double
 }
 
 extern "C" {
+
+#ifdef FEMASR_WINO_TT
+int femasr_debug_wino_up2_time(unsigned long long *buf, int reset)
+{
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wu_tt), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_wu_tt), 16 * sizeof(unsigned long long));
+}
+#endif
 
 size_t femasr_wino_up2_weight_floats(int O, int I) { return (I % 32) == 0 ? (size_t)(I / 8) * 25 * ((O + 31) / 32) * 256 : 0; }
 

@@ -402,6 +402,12 @@ struct Ctx {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) wino_w = h->specs[it->second].wino;
         }
+        if (wino_on && !wino_w) {
+            // the plan sized gn_part for the Winograd form (one partial per 16x16 sub-block); the direct kernels write 2-4x as many:
+            // never fall through to them - set_weight packs the Winograd weights for exactly these shapes
+            rc = femasr_set_error(FEMASR_ERR_WEIGHT, "conv %s: planned in the Winograd form but its weights were not packed for it", prefix.c_str());
+            return y;
+        }
         if (lowp_on) {
             a.w_bf16x3 = split;
             r = femasr_conv_bf16x3_launch(s(), &a, &variant, &flops);

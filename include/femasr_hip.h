@@ -300,6 +300,12 @@ int femasr_gemm_force_config(int cfg);
  * negative = the default (384).  Bit-identical either way (same weights layout, same per-wave pixel tiles, same GroupNorm
  * partial-moment order).  Returns the previous threshold. */
 int femasr_conv_small_launch_blocks(int blocks);
+/* Test hook of the Winograd-form convs' size limits (kernels_wino.hip / kernels_wino_up2.hip address their tensors with 32-bit
+ * byte offsets: a layer whose input or output has 2^31 or more elements, or 2^27 or more per image, runs in the direct /
+ * phase-filter form instead).  log2_total / log2_image replace the two exponents (31 / 27; smaller values move the boundary down
+ * to sizes a test can allocate), 0 = the default.  Process-global, atomic; plans cached by a handle are not re-made - set it
+ * before the first forward of a shape.  Returns FEMASR_OK. */
+int femasr_debug_wino_limits(int log2_total, int log2_image);
 
 #ifdef __cplusplus
 }

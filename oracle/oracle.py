@@ -109,14 +109,18 @@ def winograd_ok(cin, cout, ksz, stride, pad, up2, act=0):
     return ksz == 3 and stride == 1 and pad == 1 and not up2 and act == 0 and cin % 32 == 0 and cout % 64 == 0
 
 
+WINO_LOG2_LIMITS = [31, 27]      # total / per-image element limits; tests move both sides together (femasr_debug_wino_limits)
+
+
 def wino_fits(b, h, w, cin, cout, up2=False):
     """The kernels' size limits (32-bit buffer offsets: femasr_conv_wino_shape_ok / femasr_conv_wino_up2_shape_ok) are part of the
     rule: a larger layer runs in the direct / phase-filter form on the GPU, so it does here.  (b, h, w) = the conv's INPUT."""
-    if not (b * h * w * cin < 2 ** 31 and h * w * cin < 2 ** 27 and cin <= 1024):
+    tot, img = 2 ** WINO_LOG2_LIMITS[0], 2 ** WINO_LOG2_LIMITS[1]
+    if not (b * h * w * cin < tot and h * w * cin < img and cin <= 1024):
         return False
     if up2:
-        return b * 4 * h * w * cout < 2 ** 31 and 4 * h * w * cout < 2 ** 27 and 25 * cin * cout < 2 ** 29
-    return b * h * w * cout < 2 ** 31 and 36 * cin * cout < 2 ** 29
+        return b * 4 * h * w * cout < tot and 4 * h * w * cout < img and 25 * cin * cout < 2 ** 29
+    return b * h * w * cout < tot and h * w * cout < img and 36 * cin * cout < 2 ** 29
 
 
 def winograd_up2_ok(cin, cout, ksz, stride, pad, up2, act=0):

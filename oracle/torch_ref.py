@@ -47,6 +47,8 @@ class TorchRefNet:
         rel = (ys[:, None] - ys[None, :] + _WS - 1) * (2 * _WS - 1) + (xs[:, None] - xs[None, :] + _WS - 1)
         self._rel_index = torch.from_numpy(rel.reshape(-1).astype(np.int64))
         self._masks = {}
+        self.keep_vq_dist = False                    # True: encode_and_decode keeps each lookup's (tokens, n_e) distance matrix in .vq_dist
+        self.vq_dist = []
 
     # ------------------------------------------------------------------ pieces
     def _conv(self, x, p, stride=1, pad=1):
@@ -141,11 +143,14 @@ class TorchRefNet:
         zf = z.permute(0, 2, 3, 1).reshape(-1, d)
         dist = (zf * zf).sum(1, keepdim=True) + (cb * cb).sum(1) - 2.0 * (zf @ cb.t())
         idx = torch.argmin(dist, dim=1)
+        if self.keep_vq_dist:                        # bench.py: the reference arithmetic's own distances, to classify index differences
+            self.vq_dist.append(dist)
         zq = cb[idx]
         zq = zf + (zq - zf)
         return zq.reshape(b, h, w, d).permute(0, 3, 1, 2).contiguous(), idx.reshape(b, 1, h, w)
 
     def encode_and_decode(self, x):
+        self.vq_dist = []
         feats = self._encoder(x)
         feats = feats[-3:] if self.LQ_stage else feats[::-1]
         fuse_skip = self.LQ_stage and self.use_residual

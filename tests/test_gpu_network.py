@@ -125,11 +125,14 @@ def test_full_size_tile_vs_reference(cuda_device):
         torch.cuda.empty_cache()
 
 
-def test_full_size_batch16_properties(cuda_device):
-    """x4, batch 16 of 128x128 tiles (the benchmarked workload): size-independent properties."""
+@pytest.mark.parametrize('math', ['fp32_strict', 'fp32'])
+def test_full_size_batch16_properties(cuda_device, math):
+    """x4, batch 16 of 128x128 tiles (the benchmarked workload): size-independent properties, in the mode that is bit-identical to
+    the oracle and in the product default mode that bench.py times; tiles 0 / 7 / 15 also against the CPU oracle (strict: same
+    bits; default: indices exact, image within 1e-4)."""
     import gpu_utils as G
     w = synth_weights('x4', 0, 'trained')
-    net = G.build_net('x4', w)
+    net = G.build_net('x4', w, decoder_math=math)
     x = torch.from_numpy(synth.synth_input(5, (16, 3, 128, 128))).cuda()
     y, idx = net.test_with_indices(x)
     assert y.shape == (16, 3, 512, 512) and idx.shape == (16, 1, 72, 72) and torch.isfinite(y).all()
@@ -137,9 +140,14 @@ def test_full_size_batch16_properties(cuda_device):
     y2, idx2 = net.test_with_indices(x)
     assert torch.equal(y, y2) and torch.equal(idx, idx2)
     # batch invariance: sample i alone == sample i inside the batch (all ops are per-sample)
+    onet = oracle_net('x4', w)
     for i in (0, 7, 15):
         yi, ii = net.test_with_indices(x[i:i + 1])
         assert torch.equal(yi[0], y[i]) and torch.equal(ii[0], idx[i])
+        yo, io = onet.test(x[i:i + 1].cpu().numpy(), return_indices=True)
+        assert np.array_equal(ii.cpu().numpy(), io), f'tile {i}: VQ indices differ from the oracle'
+        err = float(np.abs(yi.cpu().numpy() - yo).max())
+        assert err <= (0.0 if math == 'fp32_strict' else 1e-4), (math, i, err)
     # tiled == batched: a 512x512 image cut into 16 tiles of 128 with no halo IS the batch of its crops
     img = torch.cat([torch.cat([x[r * 4 + c] for c in range(4)], 2) for r in range(4)], 1)[None]
     yt = net.test_tile(img, 128, 0)

@@ -18,9 +18,11 @@ from helpers import cfg_name_of, check_indices_near_tie, load_golden, synth_weig
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
 # A VQ index other than the reference's is accepted only where the REFERENCE's own fp32 distances of the two codes are this close
-# (d ~ 500 there: 8 ulp = 2.4e-4 absolute, 5e-7 relative - the size of the encoders' summation-order differences; SURVEY 7, hard
+# (d ~ 500 there: 4 ulp = 1.2e-4 absolute, 2.4e-7 relative - the size of the encoders' summation-order differences; SURVEY 7, hard
 # part 1).  The single-tile goldens need no allowance at all; the 173 056-token image has 193 tokens within 16 ulp of a tie.
-NEAR_TIE_ULP = 8.0
+# Measured (rounds 3 and 4): 2 such tokens, gaps 0 and 3 ulp - the bar sits at what is measured (was 8 ulp / 40 flips).
+NEAR_TIE_ULP = 4.0
+MAX_FLIPS = 4
 
 
 @pytest.mark.parametrize('name', ['x2_tile256_trained', 'hq_full512_trained'])
@@ -95,7 +97,7 @@ def test_cli_tiled_branch_on_testset_png(cuda_device, math):
             off += n
             k += 1
     assert off == g['tile_indices'].size
-    assert flips <= 40 and mask.mean() < 0.10, (flips, float(mask.mean()))
+    assert flips <= MAX_FLIPS and mask.mean() < 0.02, (flips, float(mask.mean()))
     yn = y.cpu().numpy()
     dz = np.abs(yn[:, :, ::8, ::8] - g['output_f32_stride8']).max(axis=(0, 1))
     err = float(dz[~mask[::8, ::8]].max())

@@ -84,9 +84,12 @@ def main():
         _lib.check(lib.femasr_conv2d(None, ctypes.byref(args)))
     torch.cuda.synchronize()
     raw = ctypes.CDLL(_lib.SO_PATH) if os.environ.get('FEMASR_SO') else None
-    tt = raw is not None and hasattr(raw, 'femasr_debug_wino_time') and a_.wino
+    tt_fn = None
+    if raw is not None and a_.wino:
+        tt_fn = getattr(raw, 'femasr_debug_wino_up2_time' if a_.up2 else 'femasr_debug_wino_time', None)
+    tt = tt_fn is not None
     if tt:
-        raw.femasr_debug_wino_time(None, 1)
+        tt_fn(None, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a_.iters):
@@ -96,11 +99,15 @@ def main():
     ms = e0.elapsed_time(e1) / a_.iters
     fl = 2.0 * b * ho * wo * cout * ks * ks * cin
     if tt:
-        buf = (ctypes.c_ulonglong * 8)()
-        raw.femasr_debug_wino_time(buf, 0)
-        tot = float(buf[7]) or 1.0
-        names = ['prologue', 'M_phase', 'store_patch', 'transform', 'barrier', 'epi_exchange', 'epi_items']
-        print('  per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in enumerate(names)))
+        buf = (ctypes.c_ulonglong * 16)()
+        tt_fn(buf, 0)
+        tot = float(buf[15]) or 1.0
+        if a_.up2:
+            names = {0: 'prologue', 1: 'M_phase', 2: 'T_phase', 7: 'barrier', 3: 'epi_write_acc', 4: 'epi_fetch+barrier', 5: 'epi_round', 6: 'epi_barrier2'}
+        else:
+            names = {0: 'prologue', 1: 'M_phase', 2: 'store_patch', 3: 'transform', 4: 'barrier', 5: 'epi_write_acc', 6: 'epi_fetch+barrier',
+                     7: 'epi_round', 8: 'epi_barrier2'}
+        print('  per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in sorted(names.items())))
         nsb = b * ((ho + 15) // 16) * ((wo + 15) // 16)
         nwaves = ((nsb + 1) // 2) * (cout // 64) * 8
         print('  cycles per wave: %.0f' % (tot / a_.iters / nwaves))
