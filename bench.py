@@ -123,8 +123,9 @@ class DryNet:
         import types
         import torch.nn.functional as F
 
-        def fake_test(self_, t):
-            return F.interpolate(t, scale_factor=4, mode='nearest') * 0.5 + t.amax(dim=(1, 2, 3), keepdim=True)
+        def fake_test(self_, t, out=None):
+            y = F.interpolate(t, scale_factor=4, mode='nearest') * 0.5 + t.amax(dim=(1, 2, 3), keepdim=True)
+            return y if out is None else out.copy_(y)
         net.test = types.MethodType(fake_test, net)
         self.net = net
 
@@ -216,23 +217,23 @@ def main():
         dist.init_process_group(backend=backend, rank=0, world_size=1)
     use_pg = dist.is_initialized()
 
-    pending = []            # (work handle, tensors kept alive until the collective has run)
+    sg = None
     if args.workload == 'tiles16':
         x = torch.from_numpy(synth.synth_input(1000 + rank, (B, 3, 128, 128))).to(dev)
         do_gather = use_pg and not args.no_gather
         # The all-gather of step k runs on RCCL's stream while step k+1 computes (double-buffered persistent receive
         # buffers, all_gather_into_tensor): the upscaled tiles of a step are only consumed by the paste, so a serving
         # loop pipelines exactly like this.
-        recv = [torch.empty((world, B, 3, 512, 512), dtype=torch.float32, device=dev) for _ in range(2)] if do_gather else None
+        sg = fd.StepGather((B, 3, 512, 512), torch.float32, dev) if do_gather else None      # persistent double-buffered send / receive
         nstep = [0]
 
         def step():
-            y = net.test(x)
             if do_gather:
-                w = dist.all_gather_into_tensor(recv[nstep[0] & 1].view(-1), y.view(-1), async_op=True)
-                pending.append((w, y))
-                if len(pending) > 1:            # the buffer set about to be re-used next step must be free
-                    pending.pop(0)[0].wait()
+                k = nstep[0]
+                y = net.test(x, out=sg.send(k))      # the forward's last kernel writes the send buffer: no copy
+                sg.launch(k)
+            else:
+                y = net.test(x)
             nstep[0] += 1
             return y
         out_mpix = world * B * 512 * 512 / 1e6
@@ -257,8 +258,8 @@ def main():
         units_per_step = (S // 128) ** 2
 
     def fence():
-        while pending:
-            pending.pop(0)[0].wait()
+        if args.workload == 'tiles16' and sg is not None:
+            sg.wait_all()
         if use_pg:
             dist.barrier()
         sync()

@@ -320,19 +320,23 @@ class FeMaSRNet(nn.Module):
         return out
 
     # ------------------------------------------------------------------ the path
-    def _launch(self, lib, h, x, pad_mode, oh, ow, sizes):
+    def _launch(self, lib, h, x, pad_mode, oh, ow, sizes, out=None):
         b, _, hh, ww = x.shape
         nbytes = ctypes.c_size_t()
         _lib.check(lib.femasr_workspace_bytes(h, b, hh, ww, pad_mode, ctypes.byref(nbytes)))
         ws = self._workspace(nbytes.value, x.device)
-        out = torch.empty((b, 3, oh, ow), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((b, 3, oh, ow), dtype=torch.float32, device=x.device)
+        elif (tuple(out.shape) != (b, 3, oh, ow) or out.dtype != torch.float32 or out.device != x.device or not out.is_contiguous()):
+            raise ValueError(f'out= must be a contiguous float32 tensor of shape {(b, 3, oh, ow)} on {x.device}, got '
+                             f'{tuple(out.shape)} {out.dtype} on {out.device}')
         idx_all = torch.empty((sum(sizes),), dtype=torch.int64, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(lib.femasr_forward(h, ctypes.c_void_p(stream), _lib.ptr(x), b, hh, ww, pad_mode,
                                       _lib.ptr(out), _lib.ptr(idx_all), _lib.ptr(ws), ws.numel()))
         return out, idx_all, ws
 
-    def _run(self, x, pad_mode):
+    def _run(self, x, pad_mode, out=None):
         if x.dim() != 4 or x.shape[1] != self.in_channel:
             raise ValueError(f'expected (B,{self.in_channel},H,W), got {tuple(x.shape)}')
         lib, h = self._native(x.device)
@@ -361,9 +365,9 @@ class FeMaSRNet(nn.Module):
             g, xs, so, si, _ = ent
             xs.copy_(x)
             g.replay()
-            out, idx_all = so.clone(), si.clone()
+            out, idx_all = (so.clone() if out is None else out.copy_(so)), si.clone()
         else:
-            out, idx_all, _ = self._launch(lib, h, x, pad_mode, oh.value, ow.value, sizes)
+            out, idx_all, _ = self._launch(lib, h, x, pad_mode, oh.value, ow.value, sizes, out)
         idx, off = [], 0
         for k in range(nq.value):
             idx.append(idx_all[off:off + sizes[k]].view(b, 1, qh[k], qw[k]))
@@ -389,9 +393,11 @@ class FeMaSRNet(nn.Module):
         return self.encode_and_decode(input, gt_indices)
 
     @torch.no_grad()
-    def test(self, input):
-        """femasr_arch.py:449-468: mirror-pad to (h//wsz+1)*wsz, run, crop to (h*s, w*s)."""
-        return self._run(input, 1)[0]
+    def test(self, input, out=None):
+        """femasr_arch.py:449-468: mirror-pad to (h//wsz+1)*wsz, run, crop to (h*s, w*s).  `out` (not in the reference): a
+        contiguous float32 (B, 3, h*s, w*s) tensor the result is written INTO by the last kernel of the forward - the tiled /
+        multi-GPU callers pass slices of their result or all-gather send buffers, so no copy follows."""
+        return self._run(input, 1, out)[0]
 
     @torch.no_grad()
     def test_with_indices(self, input):
@@ -422,11 +428,13 @@ class FeMaSRNet(nn.Module):
 
     # ------------------------------------------------------------------ tiled inference
     @torch.no_grad()
-    def test_tile(self, input, tile_size=240, tile_pad=16, rank=0, world_size=1, gather=None):
+    def test_tile(self, input, tile_size=240, tile_pad=16, rank=0, world_size=1, gather=None, paste=True):
         """Reference semantics of femasr_arch.py:387-447 (overlap-discard paste onto a zero canvas), but
         tiles of one shape class run as batched `test()` calls, and with world_size > 1 each rank
-        computes a contiguous share of every class; `gather(list_of_tensors) -> list per rank` supplies
-        the collective (femasr_amd.distributed.gather_tiles, RCCL all-gather)."""
+        computes a contiguous share of every class; `gather(results, classes, batch, channel, scale) -> list per rank`
+        supplies the collective (femasr_amd.distributed.TileExchange: ONE RCCL all-gather on persistent buffers the tiles were
+        written into).  paste=False (ranks other than the one that needs the image): take part in the collective, skip the
+        canvas (returns None)."""
         batch, channel, height, width = input.shape
         s = self.scale_factor
         tiles = tiling.enumerate_tiles(height, width, tile_size, tile_pad)
@@ -437,13 +445,24 @@ class FeMaSRNet(nn.Module):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (getattr(self, 'time_split', False) and input.is_cuda) else None
         if ev:
             ev[0].record()
-        results = {}
+        # One result buffer per shape class, written in place by the batched test() calls (`out=`).  With a gather object that owns
+        # persistent send buffers (femasr_amd.distributed.TileExchange.send_views) the buffers ARE this rank's all-gather send slab.
+        alloc = getattr(gather, 'send_views', None) if world_size > 1 else None
+        if alloc is not None:
+            results = alloc(classes, batch, channel, s, torch.float32, input.device)
+        else:
+            results = {hw: torch.empty((len(tl) * batch, channel, hw[0] * s, hw[1] * s), dtype=torch.float32, device=input.device)
+                       for hw, tl in mine.items()}
+        per_call = max(1, self.max_tile_batch // batch)
+        in_place = self._test_takes_out()
         for hw, tl in mine.items():
-            outs = []
-            for i in range(0, len(tl), max(1, self.max_tile_batch // batch)):
-                chunk = tl[i:i + max(1, self.max_tile_batch // batch)]
-                outs.append(self.test(self._extract_tiles(input, chunk, hw)))
-            results[hw] = torch.cat(outs, 0) if outs else input.new_zeros((0, channel, hw[0] * s, hw[1] * s))
+            for i in range(0, len(tl), per_call):
+                chunk = tl[i:i + per_call]
+                dst = results[hw][i * batch:(i + len(chunk)) * batch]
+                crops = self._extract_tiles(input, chunk, hw)
+                y = self.test(crops, out=dst) if in_place else self.test(crops)
+                if y.data_ptr() != dst.data_ptr():
+                    dst.copy_(y)
         if ev:
             ev[1].record()
         if world_size > 1:
@@ -454,6 +473,11 @@ class FeMaSRNet(nn.Module):
             per_rank = [results]
         if ev:
             ev[2].record()
+        if not paste:
+            if ev:
+                ev[3].record()
+                self._split_events = (ev, sum(len(tl) for tl in mine.values()))
+            return None
         output = input.new_zeros((batch, channel, height * s, width * s))
         for r, res in enumerate(per_rank):
             owned = tiling.partition(classes, r, world_size)
@@ -464,6 +488,14 @@ class FeMaSRNet(nn.Module):
             ev[3].record()
             self._split_events = (ev, sum(len(tl) for tl in mine.values()))
         return output
+
+    def _test_takes_out(self):
+        """False when `test` was replaced by a stand-in without the `out=` parameter (CPU-side tests of the host logic)."""
+        import inspect
+        try:
+            return 'out' in inspect.signature(self.test).parameters
+        except (TypeError, ValueError):
+            return False
 
     @property
     def last_split_ms(self):

@@ -36,11 +36,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef float tf2 __attribute__((ext_vector_type(2)));
 
-#ifdef FEMASR_WINO_TT      // tools/build_debug.sh: per-wave cycle shares of the kernel's phases
-__device__ unsigned long long g_wi_tt[16];
-#define WTT(slot) { const unsigned long long now_ = __builtin_readcyclecounter(); tt_acc[slot] += now_ - tt_last; tt_last = now_; }
-#define WTT_INIT unsigned long long tt_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tt_last = __builtin_readcyclecounter(); const unsigned long long tt_first = tt_last;
-#define WTT_END { if (lane == 0) { for (int i_ = 0; i_ < 15; ++i_) atomicAdd(&g_wi_tt[i_], tt_acc[i_]); atomicAdd(&g_wi_tt[15], __builtin_readcyclecounter() - tt_first); } }
+#ifdef FEMASR_WINO_TT      // tools/build_debug.sh tt: cycle stamps (s_memtime) of waves 0 and 7 of every block, written straight to a global
+// buffer [block][wave 0 | 7][128] - no accumulators in registers, one scalar read + one 8-byte store per stamp.  Slots: 63 block start,
+// 0 prologue done, 16 + s main-loop step s done (s < 40), 1 main loop done, per epilogue round r: 2 + 4r accumulators in LDS,
+// 3 + 4r residuals requested + barrier passed, 4 + 4r round computed / stored, 5 + 4r second barrier; 10 end; inside step s < 24:
+// 64 + 2s M phase issued (+ hoisted transform reads), 65 + 2s T phase done (before the barrier).
+__device__ unsigned long long *g_wi_ttbuf;
+#define WTT(slot) { if (lane == 0 && (wave == 0 || wave == 7)) g_wi_ttbuf[((size_t)blockIdx.x * 2 + (wave == 7 ? 1 : 0)) * 128 + (slot)] = __builtin_readcyclecounter(); }
+#define WTTR(slot) { if (lane == 0 && (wave == 0 || wave == 7)) g_wi_ttbuf[((size_t)blockIdx.x * 2 + (wave == 7 ? 1 : 0)) * 128 + (slot)] = wall_clock64(); }
+#define WTT_INIT { WTTR(62) WTT(63) }
+#define WTT_END { WTT(10) WTTR(11) }
 #else
 #define WTT(slot) {}
 #define WTT_INIT
@@ -105,6 +110,12 @@ __device__ __forceinline__ void at6(tf2 m0, tf2 m1, tf2 m2, tf2 m3, tf2 m4, tf2 
     y3 = __builtin_elementwise_fma(tf2{8.0f, 8.0f}, ss, qq) + m5;
 }
 
+#ifndef FEMASR_WINO_V        // schedule variants (tools/build_debug.sh v<N>), all bit-identical, A/B-measured in round 4 (profiles/r04_wino_variants.txt):
+#define FEMASR_WINO_V 16     //   bit 0  the patch of step s+2 requested at the start of the M phase instead of at pair 5: 4 % SLOWER (loads return in
+#endif                       //          order: the slow HBM request ahead of the L2-resident U fragments delays them)
+                             //   bit 1  staging ahead of the transform arithmetic (its LDS reads in flight meanwhile): 0 .. +1 %
+                             //   bit 2  the transform's patch reads at the start of the M phase / bit 3 the whole transform inside the M phase: +-1 %
+                             //   bit 4  prologue: the patches of steps 0 and 1 requested together, second register set: 1 % faster (default)
 #ifndef FEMASR_WINO_ABL      // ablation experiments (tools/build_debug.sh): bit 0 no patch loads, 1 no U loads, 2 no transform, 3 no MFMAs,
 #define FEMASR_WINO_ABL 0    // 4 no output items, 5 no activation, 6 no staging stores
 #endif
@@ -121,8 +132,8 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     float *ABs = smem + W4_MAIN;             // [2 sub-blocks][a | b][Cin]
 
     const int t = threadIdx.x, lane = t & 63;
-    WTT_INIT
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    WTT_INIT
     const int c31 = lane & 31, hh = lane >> 5;
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
     const int nb = L % p.NB, mb = L / p.NB;
@@ -174,21 +185,22 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void *)(p.in + (size_t)sn[0] * p.H * p.W * p.Cin), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, 0x7fffffff, 0x00020000);
     float4 rp[3];
-    auto load_patch = [&](int s) {       // unconditional (steps past the end re-read the last one): the wait counters stay static
+    auto load_patch_to = [&](float4 (&rr)[3], int s) {       // unconditional (steps past the end re-read the last one): the wait counters stay static
         const int sc = s < p.nsteps ? s : p.nsteps - 1;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            if (FEMASR_WINO_ABL & 1) { rp[i] = make_float4(0.1f * sc, 0.2f, 0.3f, 0.4f); continue; }
+            if (FEMASR_WINO_ABL & 1) { rr[i] = make_float4(0.1f * sc, 0.2f, 0.3f, 0.4f); continue; }
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[i], sc * 32, 0);
-            rp[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            rr[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
-    auto store_patch = [&](int s, int buf) {
+    auto load_patch = [&](int s) { load_patch_to(rp, s); };
+    auto store_patch_from = [&](const float4 (&rr)[3], int s, int buf) {
         float *Pb = Ps + buf * W4_PSZ;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            if (FEMASR_WINO_ABL & 64) { asm volatile("" :: "v"(rp[i].x), "v"(rp[i].y), "v"(rp[i].z), "v"(rp[i].w)); continue; }
-            float4 v = rp[i];
+            if (FEMASR_WINO_ABL & 64) { asm volatile("" :: "v"(rr[i].x), "v"(rr[i].y), "v"(rr[i].z), "v"(rr[i].w)); continue; }
+            float4 v = rr[i];
             if (PRO == FEMASR_PRO_GN_SILU && !(FEMASR_WINO_ABL & 32)) {
                 const float *ab = ABs + (i == 0 ? 0 : (i == 1 ? zo1 : KINDS * p.Cin)) + s * 8 + 4 * quad;
                 const float4 ga = ld4(ab), gb = ld4(ab + p.Cin);
@@ -216,6 +228,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
             }
         }
     };
+    auto store_patch = [&](int s, int buf) { store_patch_from(rp, s, buf); };
 
     // ---- input transform item: tile tm, channel lane&7, rows 3*thalf .. 3*thalf+2 of B^T d (uniform per wave)
     const int thalf = wave & 1;
@@ -299,7 +312,11 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         const float *Vb = Vs + (s & 1) * W4_VSZ + aoff;
 #pragma unroll
         for (int q = 6; q < 9; ++q) late[q - 6] = ldU(s, q);
+        // (variant bit 0) the patch of step s+2 the whole M phase ahead of its use; BEHIND the late fragments - loads return in order, and
+        // those are waited for at pair 6
+        if (FEMASR_WINO_V & 1) load_patch(s + 2);
         f32x4_t an = *reinterpret_cast<const f32x4_t *>(Vb + pcomp(0) * 256);
+        if (FEMASR_WINO_V & 12) transform_read((s + 1) & 1);      // (variant bits 2, 3) the next step's patch was staged a barrier ago
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -312,12 +329,19 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
             }
             if (q < 3) ring[q] = ldU(s + 1, q);
-            if (q == 5) load_patch(s + 2);           // into the registers the early fragments just left; 3 pairs + the transform ahead of its use
+            if (!(FEMASR_WINO_V & 1) && q == 5) load_patch(s + 2);           // into the registers the early fragments just left; 3 pairs + the transform ahead of its use
+            if ((FEMASR_WINO_V & 8) && q == 4) transform_write((s + 1) & 1);      // V of the NEXT step: not the buffer this M phase reads
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // ---- prologue
+    // ---- prologue: every global request first (patch of step 0 - and, variant bit 4, of step 1 in a second register set - the first U
+    // fragments, the GN table), then the LDS work that needs none of them
+    float4 rq[3];
+    load_patch(0);
+    if (FEMASR_WINO_V & 16) load_patch_to(rq, 1);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ring[q] = ldU(0, q);
     if (PRO == FEMASR_PRO_GN_SILU) {     // GN table [sub-block][a | b][Cin]
         for (int i = t; i < 2 * KINDS * p.Cin; i += W4_NT) {
             const int z = i / (KINDS * p.Cin), r = i - z * KINDS * p.Cin, kind = r / p.Cin, c = r - kind * p.Cin;
@@ -335,16 +359,20 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
             *reinterpret_cast<float2 *>(dst + W4_PSZ + 2) = make_float2(0.f, 0.f);
         }
     }
-    load_patch(0);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) ring[q] = ldU(0, q);
     __syncthreads();
     store_patch(0, 0);
-    load_patch(1);
-    __syncthreads();
-    transform_read(0);
-    transform_write(0);
-    if (1 < p.nsteps) store_patch(1, 1);
+    if (FEMASR_WINO_V & 16) {
+        if (1 < p.nsteps) store_patch_from(rq, 1, 1);
+        __syncthreads();
+        transform_read(0);
+        transform_write(0);
+    } else {
+        load_patch(1);
+        __syncthreads();
+        transform_read(0);
+        transform_write(0);
+        if (1 < p.nsteps) store_patch(1, 1);
+    }
     issue_early(0);
     __syncthreads();
     WTT(0)
@@ -357,27 +385,35 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     constexpr bool HOIST = FAST || PRO == FEMASR_PRO_NONE;       // the lean variants have the registers to read the next transform's
     for (int s = 0; s < p.nsteps; ++s) {                         // patch values right behind the last MFMA issue
         mphase(s);
-        if (HOIST) transform_read((s + 1) & 1);       // (unconditional: after the last step it transforms a stale patch into a dead buffer)
+        constexpr bool INM = (FEMASR_WINO_V & 12) != 0;      // the transform's reads were issued inside the M phase
+        if (HOIST && !INM) transform_read((s + 1) & 1);       // (unconditional: after the last step it transforms a stale patch into a dead buffer)
         __builtin_amdgcn_sched_barrier(0);
-        WTT(1)
-        if (HOIST) {
-            transform_write((s + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+        if (s < 24) WTT(64 + 2 * s)
+        if (FEMASR_WINO_V & 8) {
             if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);
-            WTT(2)
+        } else if (HOIST || INM) {
+            if (FEMASR_WINO_V & 2) {      // the transform's LDS reads in flight under the staging arithmetic (other buffer: no conflict)
+                if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                transform_write((s + 1) & 1);
+            } else {
+                transform_write((s + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);
+            }
         } else {
             if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);          // first: frees the staging registers ahead of the transform
-            WTT(2)
             __builtin_amdgcn_sched_barrier(0);
             transform_read((s + 1) & 1);
             transform_write((s + 1) & 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         issue_early(s + 1);                                       // in flight across the barrier
-        WTT(3)
+        if (s < 24) WTT(65 + 2 * s)
         __syncthreads();
-        WTT(4)
+        if (s < 40) WTT(16 + s)
     }
+    WTT(1)
 
     // ---------------------------------------------------------------------------------------------------------------
     // epilogue, one 32-column tile (round) at a time: accumulators -> Mx[component][tile pair][channel][2] (overlays the main-loop
@@ -398,26 +434,32 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     const int gpt = 32 / (cg < 32 ? cg : 32);        // groups per 32-channel tile (<= 16)
     const int pi = t >> 5;                           // tile pair: rows 2 pi, 2 pi + 1 of the accumulator tiles
     const int ez = wave >> 2, ety = wave & 3, etx = 2 * hh;      // sub-block (uniform), tile row (uniform), left tile of the pair
-    unsigned vmask[2], ooff;
+    unsigned vmask[2] = {0xffffu, 0xffffu}, ooff;
     bool full = true;
+#pragma unroll
+    for (int z = 0; z < 2; ++z) full = full && (z ? sval[1] : sval[0]) && (z ? sy0[1] : sy0[0]) + 16 <= p.H && (z ? sx0[1] : sx0[0]) + 16 <= p.W;      // (uniform)
     {
         const int oy = (ez ? sy0[1] : sy0[0]) + 4 * ety, ox = (ez ? sx0[1] : sx0[0]) + 4 * etx;
+        if (!full) {         // per-pixel validity of the thread's two tiles (bit 4a + b): only a block that touches the image border needs it
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            unsigned m = 0;
+            for (int e = 0; e < 2; ++e) {
+                unsigned m = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) m |= ((ez ? sval[1] : sval[0]) && oy + (k >> 2) < p.H && ox + 4 * e + (k & 3) < p.W ? 1u : 0u) << k;
-            vmask[e] = m;
+                for (int k = 0; k < 16; ++k) m |= ((ez ? sval[1] : sval[0]) && oy + (k >> 2) < p.H && ox + 4 * e + (k & 3) < p.W ? 1u : 0u) << k;
+                vmask[e] = m;
+            }
         }
-        ooff = (unsigned)(((((size_t)(ez ? sn[1] - sn[0] : 0) * p.H + oy) * p.W + ox) * p.Cout + n0 + c31) * 4);
-#pragma unroll
-        for (int z = 0; z < 2; ++z) full = full && (z ? sval[1] : sval[0]) && (z ? sy0[1] : sy0[0]) + 16 <= p.H && (z ? sx0[1] : sx0[0]) + 16 <= p.W;      // (uniform)
+        ooff = (unsigned)((((ez ? sn[1] - sn[0] : 0) * p.H + oy) * p.W + ox) * p.Cout + n0 + c31) * 4u;      // (< 2^30: two images of < 2^27 elements)
     }
     const size_t img0 = (size_t)sn[0] * p.H * p.W * p.Cout;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(p.out + img0), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc((void *)((HAS1 ? p.res1 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc((void *)((HAS2 ? p.res2 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
-    auto soff = [&](int k, int e, int r) -> int { return (((k >> 2) * p.W + 4 * e + (k & 3)) * p.Cout + 32 * r) * 4; };      // uniform bytes
+    // uniform byte offset of pixel k = 4a + b of tile e of the pair, round r: a * rs + (4e + b) * cs + 128 r.  The two strides are made
+    // opaque once per round so that the 32 sums are formed where they are used (two scalar adds each) - hoisted out of the round loop
+    // they do not fit the scalar registers and come back through v_readlane, which stalls every load / store on a scalar dependency
+    int cs_u = 0, rs_u = 0;      // set (opaque) at the top of every round
+    auto soff = [&](int k, int e, int r) -> int { return (k >> 2) * rs_u + (4 * e + (k & 3)) * cs_u + 128 * r; };
     // !FULL: all-ones where pixel k of tile e lies outside the image (two shifts on the lane's mask word; OR-ed into the offset,
     // AND-NOT-ed into the moment operand) - per-lane arithmetic, not 32 exec masks held in scalar registers
     auto oob = [&](int e, int k) -> unsigned { return ~(unsigned)((int)(vmask[e] << (31 - k)) >> 31); };
@@ -436,10 +478,13 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         constexpr bool FULL = decltype(fullc)::value;
         tf2 r1[16], r2[16];                                // residuals of both tiles
         if (!FULL) asm volatile("" : "+v"(vmask[0]), "+v"(vmask[1]));      // (opaque: the per-pixel masks are not to be hoisted out of the round loop)
+        cs_u = __builtin_amdgcn_readfirstlane(p.Cout * 4);
+        rs_u = __builtin_amdgcn_readfirstlane(p.W * p.Cout * 4);
+        asm volatile("" : "+s"(cs_u), "+s"(rs_u));
         if (HAS1) fetch(fullc, rs_r1, r, r1);              // in flight across the barrier and the first transform pass
         const float bv = p.bias[n0 + 32 * r + c31];
         __syncthreads();
-        WTT(6)
+        WTT(3 + 4 * r)
         if (!(FEMASR_WINO_ABL & 16)) {
             // component stride: 16 tile pairs x 32 channels = 4 KiB; three bases keep every read inside the 64-KiB offset field
             int so1 = (16 * 512 + pi * 32 + c31) * 8, so2 = (32 * 512 + pi * 32 + c31) * 8;
@@ -490,7 +535,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
                 }
             }
         }
-        WTT(7)
+        WTT(4 + 4 * r)
     };
     // (two per-lane bases, pinned: a wave's pairs 0-7 are the four consecutive components 4 wave .., pair 8 is component
     // 32 + wave / 2; everything else is an immediate offset - left alone the compiler keeps one address register per component)
@@ -514,10 +559,10 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
 #pragma unroll 1
     for (int r = 0; r < 2; ++r) {
         if (r == 1) write_acc(std::integral_constant<int, 1>{});
-        WTT(5)
+        WTT(2 + 4 * r)
         if (full) round(std::true_type{}, r); else round(std::false_type{}, r);
         __syncthreads();
-        WTT(8)
+        WTT(5 + 4 * r)
         if (gnp && t < 2 * gpt) {
             const int z = t / gpt, gl = t - z * gpt;
             if (z ? sval[1] : sval[0]) {
@@ -661,10 +706,9 @@ int femasr_debug_wino_limits(int log2_total, int log2_image)
 }
 
 #ifdef FEMASR_WINO_TT
-int femasr_debug_wino_time(unsigned long long *buf, int reset)
+int femasr_debug_wino_ttbuf(unsigned long long *dev_buf)      // [blocks][2][64] on the device, zero-filled by the caller
 {
-    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wi_tt), z, sizeof(z)); }
-    return (int)hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_wi_tt), 16 * sizeof(unsigned long long));
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wi_ttbuf), &dev_buf, sizeof(dev_buf));
 }
 #endif
 

@@ -31,15 +31,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef float tf2 __attribute__((ext_vector_type(2)));
 
-#ifdef FEMASR_WINO_TT      // tools/build_debug.sh: per-wave cycle shares of the kernel's phases
-__device__ unsigned long long g_wu_tt[16];
-#define WUTT(slot) { const unsigned long long now_ = __builtin_readcyclecounter(); tt_acc[slot] += now_ - tt_last; tt_last = now_; }
-#define WUTT_INIT unsigned long long tt_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tt_last = __builtin_readcyclecounter(); const unsigned long long tt_first = tt_last;
-#define WUTT_END { if (lane == 0) { for (int i_ = 0; i_ < 15; ++i_) atomicAdd(&g_wu_tt[i_], tt_acc[i_]); atomicAdd(&g_wu_tt[15], __builtin_readcyclecounter() - tt_first); } }
+#ifdef FEMASR_WINO_TT      // tools/build_debug.sh tt: cycle stamps of waves 0 and 7 of every block in a global buffer, see kernels_wino.hip
+// (same slots: 63 start, 0 prologue done, 16 + s step s done, 1 main loop done, 2..5 + 4r epilogue round r, 10 end)
+__device__ unsigned long long *g_wu_ttbuf;
+#define WUTT(slot) { if (lane == 0 && (wave == 0 || wave == 7)) g_wu_ttbuf[((size_t)blockIdx.x * 2 + (wave == 7 ? 1 : 0)) * 64 + (slot)] = __builtin_readcyclecounter(); }
+#define WUTTR(slot) { if (lane == 0 && (wave == 0 || wave == 7)) g_wu_ttbuf[((size_t)blockIdx.x * 2 + (wave == 7 ? 1 : 0)) * 64 + (slot)] = wall_clock64(); }
+#define WUTT_INIT { WUTTR(62) WUTT(63) }
+#define WUTT_END { WUTT(10) WUTTR(11) }
 #else
 #define WUTT(slot) {}
 #define WUTT_INIT
 #define WUTT_END {}
+#endif
+
+#ifndef FEMASR_WUP_V         // schedule variants (tools/build_debug.sh v<N>): bit 2 the transform's patch reads at the start of the M phase, bit 3 the whole
+#define FEMASR_WUP_V 0       // transform of the next step inside the M phase (behind pair 3)
 #endif
 
 namespace {
@@ -85,8 +91,8 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     float *Vs = smem + 2 * WU_PSZ;           // [2][WU_VSZ]
 
     const int t = threadIdx.x, lane = t & 63;
-    WUTT_INIT
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    WUTT_INIT
     const int c31 = lane & 31, hh = lane >> 5;
     const int L = xcd_remap(blockIdx.x, p.MB * p.NB);
     const int nb = L % p.NB, mb = L / p.NB;
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         // left alone the scheduler reuses one set and sinks the read below the MFMAs - an LDS round trip exposed per pair)
         f32x4_t af[2];
         af[0] = *reinterpret_cast<const f32x4_t *>(Vb + vcomp(0) * 256);
+        if (FEMASR_WUP_V & 12) transform_read((s + 1) & 1);      // the next step's patch was staged a barrier ago
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
@@ -220,6 +227,7 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
             }
             if (q < 3) ring[q] = ldU(s + 1, q);
             if (q == 4) load_patch(s + 2);
+            if ((FEMASR_WUP_V & 8) && q == 3) transform_write((s + 1) & 1);      // V of the NEXT step: not the buffer this M phase reads
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -247,17 +255,16 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     // control flow also costs a spilled accumulator tile per step.)
     for (int s = 0; s < p.nsteps; ++s) {
         mphase(s);
-        WUTT(1)
-        transform_read((s + 1) & 1);          // (unconditional: after the last step it transforms a stale patch into a dead buffer)
+        if (!(FEMASR_WUP_V & 12)) transform_read((s + 1) & 1);          // (unconditional: after the last step it transforms a stale patch into a dead buffer)
         __builtin_amdgcn_sched_barrier(0);
-        transform_write((s + 1) & 1);
+        if (!(FEMASR_WUP_V & 8)) transform_write((s + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         store_patch(s & 1);                   // step s+2 (loaded during the M phase) -> the buffer the transform of step s read a barrier ago
         issue_early(s + 1);
-        WUTT(2)
         __syncthreads();
-        WUTT(7)
+        if (s < 40) WUTT(16 + s)
     }
+    WUTT(1)
 
     // ---------------------------------------------------------------------------------------------------------------
     // epilogue = the F(4x4,3x3) kernel's (kernels_wino.hip), with 25 components and the 5 -> 4 transform: one 32-column tile
@@ -272,26 +279,30 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     const int gpt = 32 / (cg < 32 ? cg : 32);        // groups per 32-channel tile (<= 16)
     const int pi = t >> 5;                           // tile pair: rows 2 pi, 2 pi + 1 of the accumulator tiles
     const int ez = wave >> 2, ety = wave & 3, etx = 2 * hh;      // sub-block (uniform), tile row (uniform), left tile of the pair
-    unsigned vmask[2], ooff;
+    unsigned vmask[2] = {0xffffu, 0xffffu}, ooff;
     bool full = true;
+#pragma unroll
+    for (int z = 0; z < 2; ++z) full = full && (z ? sval[1] : sval[0]) && (z ? sy0[1] : sy0[0]) + 16 <= p.Ho && (z ? sx0[1] : sx0[0]) + 16 <= p.Wo;      // (uniform)
     {
         const int oy = (ez ? sy0[1] : sy0[0]) + 4 * ety, ox = (ez ? sx0[1] : sx0[0]) + 4 * etx;
+        if (!full) {         // per-pixel validity of the thread's two tiles (bit 4a + b): only a block that touches the image border needs it
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            unsigned m = 0;
+            for (int e = 0; e < 2; ++e) {
+                unsigned m = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) m |= ((ez ? sval[1] : sval[0]) && oy + (k >> 2) < p.Ho && ox + 4 * e + (k & 3) < p.Wo ? 1u : 0u) << k;
-            vmask[e] = m;
+                for (int k = 0; k < 16; ++k) m |= ((ez ? sval[1] : sval[0]) && oy + (k >> 2) < p.Ho && ox + 4 * e + (k & 3) < p.Wo ? 1u : 0u) << k;
+                vmask[e] = m;
+            }
         }
-        ooff = (unsigned)(((((size_t)(ez ? sn[1] - sn[0] : 0) * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + c31) * 4);
-#pragma unroll
-        for (int z = 0; z < 2; ++z) full = full && (z ? sval[1] : sval[0]) && (z ? sy0[1] : sy0[0]) + 16 <= p.Ho && (z ? sx0[1] : sx0[0]) + 16 <= p.Wo;      // (uniform)
+        ooff = (unsigned)((((ez ? sn[1] - sn[0] : 0) * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + c31) * 4u;      // (< 2^30: two images of < 2^27 elements)
     }
     const size_t img0 = (size_t)sn[0] * p.Ho * p.Wo * p.Cout;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(p.out + img0), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc((void *)((HAS1 ? p.res1 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc((void *)((HAS2 ? p.res2 : p.out) + img0), 0, 0x7fffffff, 0x00020000);
-    auto soff = [&](int k, int e, int r) -> int { return (((k >> 2) * p.Wo + 4 * e + (k & 3)) * p.Cout + 32 * r) * 4; };      // uniform bytes
+    // uniform byte offset of pixel k = 4a + b of tile e, round r; the two strides are made opaque once per round (kernels_wino.hip)
+    int cs_u = 0, rs_u = 0;
+    auto soff = [&](int k, int e, int r) -> int { return (k >> 2) * rs_u + (4 * e + (k & 3)) * cs_u + 128 * r; };
     auto oob = [&](int e, int k) -> unsigned { return ~(unsigned)((int)(vmask[e] << (31 - k)) >> 31); };      // all-ones: pixel k of tile e is outside
     auto voff = [&](auto fullc, int e, int k) -> unsigned {
         if (decltype(fullc)::value) return ooff;
@@ -308,10 +319,13 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         constexpr bool FULL = decltype(fullc)::value;
         tf2 r1[16], r2[16];
         if (!FULL) asm volatile("" : "+v"(vmask[0]), "+v"(vmask[1]));      // (opaque: the per-pixel masks are not to be hoisted out of the round loop)
+        cs_u = __builtin_amdgcn_readfirstlane(p.Cout * 4);
+        rs_u = __builtin_amdgcn_readfirstlane(p.Wo * p.Cout * 4);
+        asm volatile("" : "+s"(cs_u), "+s"(rs_u));
         if (HAS1) fetch(fullc, rs_r1, r, r1);
         const float bv = p.bias[n0 + 32 * r + c31];
         __syncthreads();
-        WUTT(4)
+        WUTT(3 + 4 * r)
         {
             // component stride: 16 tile pairs x 32 channels = 4 KiB; two bases keep every read inside the 64-KiB offset field
             int so1 = (16 * 512 + pi * 32 + c31) * 8;
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
                 }
             }
         }
-        WUTT(5)
+        WUTT(4 + 4 * r)
     };
     // (one per-lane base, pinned as an integer offset: a wave's pairs are the components wave / 2 + 4 q; everything else is an
     // immediate offset)
@@ -388,10 +402,10 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
 #pragma unroll 1
     for (int r = 0; r < 2; ++r) {
         if (wnt == r) write_acc();
-        WUTT(3)
+        WUTT(2 + 4 * r)
         if (full) round(std::true_type{}, r); else round(std::false_type{}, r);
         __syncthreads();
-        WUTT(6)
+        WUTT(5 + 4 * r)
         if (gnp && t < 2 * gpt) {
             const int z = t / gpt, gl = t - z * gpt;
             if (z ? sval[1] : sval[0]) {
@@ -501,10 +515,9 @@ int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double
 extern "C" {
 
 #ifdef FEMASR_WINO_TT
-int femasr_debug_wino_up2_time(unsigned long long *buf, int reset)
+int femasr_debug_wino_up2_ttbuf(unsigned long long *dev_buf)
 {
-    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wu_tt), z, sizeof(z)); }
-    return (int)hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_wu_tt), 16 * sizeof(unsigned long long));
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wu_ttbuf), &dev_buf, sizeof(dev_buf));
 }
 #endif
 

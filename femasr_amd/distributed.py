@@ -11,10 +11,15 @@ exactly as `test_tile` does (overlap-discard).
 xGMI is point-to-point (7 links/GPU): a single large all-gather lets RCCL use
 all links at once; the payload (3 MiB fp32 per 512x512 tile) is <3 % of the
 tile's compute time, so it is issued once, un-bucketed, as
-`all_gather_into_tensor` on a persistent (world, cap) buffer: tiles are written
-straight into this rank's send slab by the batched `test()` calls' consumers
-(one copy per class), nothing is zero-filled and nothing is re-copied on receive
-— the per-rank results are views into the receive buffer.
+`all_gather_into_tensor` on a persistent (world, cap) buffer.  The batched
+`test()` calls write their tiles STRAIGHT into this rank's send slab
+(`FeMaSRNet.test(x, out=slab_view)`: the forward's last kernel stores there -
+`TileExchange.send_views`), nothing is zero-filled and nothing is re-copied on
+receive - the per-rank results are views into the receive buffer.  A rank that
+does not need the image (`paste=False`) joins the collective and skips the canvas.
+
+Not measured: no node with more than one GPU was available to this build; the
+scaling curve is the driver's to record (bench.py --gpus N).
 """
 import os
 
@@ -79,31 +84,91 @@ class TileGather:
         return [self._views(self.recv[r], r) for r in range(self.world)], work
 
 
-_gathers = {}
+class StepGather:
+    """Weak-scaling serving loop (bench.py tiles16: every rank upscales its own batch each step): the all-gather of step k runs on
+    the collective's stream while step k+1 computes.  Double-buffered persistent send and receive buffers; `send(k)` is the tensor
+    the forward of step k writes into (`net.test(x, out=...)`), `launch(k)` starts the collective of step k and - before the
+    buffer pair of step k-1 can be re-used by step k+1 - waits for that older one; `result(k)` = (world, *shape) view, valid
+    after `wait_all()` or once `launch(k+1)` has returned."""
+
+    def __init__(self, shape, dtype, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self._send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(2)]
+        self._recv = [torch.empty((self.world,) + tuple(shape), dtype=dtype, device=device) for _ in range(2)]
+        self._pending = []
+
+    def send(self, k):
+        return self._send[k & 1]
+
+    def launch(self, k):
+        w = dist.all_gather_into_tensor(self._recv[k & 1].view(-1), self._send[k & 1].view(-1), group=self.group, async_op=True)
+        self._pending.append(w)
+        if len(self._pending) > 1:
+            self._pending.pop(0).wait()
+
+    def result(self, k):
+        return self._recv[k & 1]
+
+    def wait_all(self):
+        while self._pending:
+            self._pending.pop(0).wait()
+
+
+class TileExchange:
+    """The `gather` object `FeMaSRNet.test_tile` takes: owns the persistent buffers of ONE image geometry at a time.
+
+    `send_views(...)` hands test_tile this rank's send slab as {(h, w): tensor}, so the tiles are produced in place;
+    calling the object runs the collective (tiles handed over in other tensors - a stand-in network without `out=` - are copied
+    into the slab first)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._key = None
+        self._tg = None
+
+    def _get(self, classes, batch, channel, scale, dtype, device):
+        key = (tuple((hw, tuple(t.index for t in tl)) for hw, tl in classes.items()), batch, channel, scale, dtype, str(device))
+        if key != self._key:
+            self._tg = None                 # one geometry at a time keeps the footprint bounded
+            self._tg = TileGather(classes, batch, channel, scale, dtype, device, self.group)
+            self._key = key
+        return self._tg
+
+    def send_views(self, classes, batch, channel, scale, dtype, device):
+        return self._get(classes, batch, channel, scale, dtype, torch.device(device)).send_views()
+
+    def __call__(self, results, classes, batch, channel, scale):
+        ref = next(iter(results.values()))
+        tg = self._get(classes, batch, channel, scale, ref.dtype, ref.device)
+        for hw, dst in tg.send_views().items():
+            src = results[hw]
+            if src.data_ptr() != dst.data_ptr() or src.numel() != dst.numel():
+                dst.copy_(src)
+        out, _ = tg.gather()
+        return out
+
+
+_exchanges = {}
 
 
 def gather_tiles(results, classes, batch, channel, scale, group=None):
-    """All-gather every rank's upscaled tiles with ONE `all_gather_into_tensor` on persistent buffers.
+    """All-gather every rank's upscaled tiles with ONE `all_gather_into_tensor` on persistent buffers (functional form of
+    TileExchange; the tiles are copied into the send slab unless they already live there).
 
     results: {(h,w): tensor (n_owned*batch, channel, h*s, w*s)} of THIS rank.
     Returns a list (one entry per rank) of dicts with the same structure (views into the receive buffer,
     valid until the next call with the same geometry)."""
-    ref = next(iter(results.values()))
-    key = (tuple((hw, tuple(t.index for t in tl)) for hw, tl in classes.items()), batch, channel, scale, ref.dtype,
-           str(ref.device), id(group))
-    tg = _gathers.get(key)
-    if tg is None:
-        _gathers.clear()            # one geometry at a time keeps the footprint bounded
-        tg = _gathers[key] = TileGather(classes, batch, channel, scale, ref.dtype, ref.device, group)
-    for hw, dst in tg.send_views().items():
-        dst.copy_(results[hw])
-    out, _ = tg.gather()
-    return out
+    ex = _exchanges.setdefault(id(group), TileExchange(group))
+    return ex(results, classes, batch, channel, scale)
 
 
-def test_tile_parallel(net, x, tile_size=240, tile_pad=16, group=None):
-    """`net.test_tile` sharded over the process group; every rank returns the full upscaled image."""
+def test_tile_parallel(net, x, tile_size=240, tile_pad=16, group=None, root_only=False):
+    """`net.test_tile` sharded over the process group.  Every rank returns the full upscaled image, or - root_only=True - only
+    rank 0 pastes it (the others return None): one canvas write per job instead of one per rank."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return net.test_tile(x, tile_size, tile_pad)
-    return net.test_tile(x, tile_size, tile_pad, rank=dist.get_rank(group), world_size=dist.get_world_size(group),
-                         gather=lambda res, cls, b, c, s: gather_tiles(res, cls, b, c, s, group))
+    ex = _exchanges.setdefault(id(group), TileExchange(group))
+    rank = dist.get_rank(group)
+    return net.test_tile(x, tile_size, tile_pad, rank=rank, world_size=dist.get_world_size(group), gather=ex,
+                         paste=(rank == 0 or not root_only))

@@ -18,3 +18,11 @@ def cuda_device():
     if not torch.cuda.is_available():
         pytest.skip('no GPU visible')
     return torch.device('cuda:0')
+
+
+def pytest_sessionstart(session):
+    """FEMASR_TEST_SO=<path>: run the suite against an experiment build of the library (tools/build_debug.sh)."""
+    so = os.environ.get('FEMASR_TEST_SO')
+    if so:
+        from femasr_amd import _lib
+        _lib.SO_PATH = so

@@ -134,3 +134,80 @@ def test_eight_rank_tile_parallel_config3_geometries():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert sorted(res) == [(r, [True, True, True]) for r in range(world)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The weak-scaling serving loop of bench.py --workload tiles16 on 8 ranks: every rank upscales its own batch each step (written
+# straight into the persistent send buffer, `out=`), the all-gather of step k is in flight while step k+1 computes
+# (femasr_amd.distributed.StepGather, double-buffered).  Checked: after every step's collective has been waited for - either by
+# the next launch or by wait_all - the receive buffer of step k holds exactly what each rank produced in step k.
+def _fake_test_out(t, out):
+    return out.copy_(F.interpolate(t, scale_factor=4, mode='nearest') * 0.5 + t.amax(dim=(1, 2, 3), keepdim=True))
+
+
+def _worker_steps(rank, world, port, steps, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    fd.init_from_env('gloo')
+    B, S = 2, 8
+    sg = fd.StepGather((B, 3, 4 * S, 4 * S), torch.float32, torch.device('cpu'))
+
+    def x_of(r, k):                                      # every rank can rebuild every other rank's input of every step
+        g = torch.Generator().manual_seed(1000 * k + r)
+        return torch.rand((B, 3, S, S), generator=g)
+    ok = True
+    for k in range(steps):
+        _fake_test_out(x_of(rank, k), sg.send(k))
+        sg.launch(k)
+        if k >= 1:                                       # launch(k) has waited for step k-1: its result is complete and still intact
+            res = sg.result(k - 1)
+            for r in range(world):
+                ok = ok and bool(torch.equal(res[r], _fake_test_out(x_of(r, k - 1), torch.empty_like(res[r]))))
+    sg.wait_all()
+    res = sg.result(steps - 1)
+    for r in range(world):
+        ok = ok and bool(torch.equal(res[r], _fake_test_out(x_of(r, steps - 1), torch.empty_like(res[r]))))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_weak_scaling_step_loop():
+    world, steps = 8, 5
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_steps, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def _worker_root(rank, world, port, x, ts, pad, expect, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    fd.init_from_env('gloo')
+    y = fd.test_tile_parallel(_make_net(), x, ts, pad, root_only=True)
+    q.put((rank, bool(torch.equal(y, expect)) if rank == 0 else y is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_root_only_paste():
+    """root_only=True: every rank takes part in the all-gather, only rank 0 pastes the canvas (the others return None)."""
+    torch.manual_seed(3)
+    x = torch.rand((1, 3, 70, 100))
+    expect = _make_net().test_tile(x, 32, 8)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_root, args=(r, 2, port, x, 32, 8, expect, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]

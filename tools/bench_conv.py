@@ -13,6 +13,45 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 from femasr_amd import _lib  # noqa: E402
 
 
+def tt_report(T, nsteps):
+    """Cycle stamps of the last launch (tools/build_debug.sh tt): T[block][wave 0 | 7][slot], slots as in kernels_wino.hip."""
+    import numpy as np
+    T = T.astype(np.float64)
+    w0 = T[:, 0]
+    cyc = w0[:, 10] - w0[:, 63]
+    rt = (w0[:, 11] - w0[:, 62]) * 10.0                      # s_memrealtime: 100 MHz -> ns
+    ghz = float(np.median(cyc / np.maximum(rt, 1.0)))
+    span_ns = (T[:, :, 11].max() - T[:, :, 62].min()) * 10.0
+    us = lambda c: c / ghz / 1e3
+    ns = min(nsteps, 40)
+    steps = np.diff(np.concatenate([w0[:, 0:1], w0[:, 16:16 + ns]], axis=1), axis=1)
+    print('  clock %.3f GHz; %d blocks; kernel span %.1f us; block life mean %.1f us (min %.1f, max %.1f); sum(block life) / (span x 256 CUs) = %.3f'
+          % (ghz, len(cyc), span_ns / 1e3, us(cyc.mean()), us(cyc.min()), us(cyc.max()), rt.sum() / (span_ns * 256)))
+    ph = [('prologue', w0[:, 0] - w0[:, 63]), ('main loop', w0[:, 1] - w0[:, 0])]
+    for r in range(2):
+        base = w0[:, 1] if r == 0 else w0[:, 5]
+        ph += [('r%d acc->LDS' % r, w0[:, 2 + 4 * r] - base), ('r%d fetch+barrier' % r, w0[:, 3 + 4 * r] - w0[:, 2 + 4 * r]),
+               ('r%d transform+store' % r, w0[:, 4 + 4 * r] - w0[:, 3 + 4 * r]), ('r%d barrier2' % r, w0[:, 5 + 4 * r] - w0[:, 4 + 4 * r])]
+    ph += [('tail (moments out)', w0[:, 10] - w0[:, 9])]
+    for n, v in ph:
+        print('    %-22s %8.2f us  %5.1f %%   (min %.2f max %.2f)' % (n, us(v.mean()), 100 * v.mean() / cyc.mean(), us(v.min()), us(v.max())))
+    print('    per step: mean %.3f us (%.0f cycles; first %.0f, median step %.0f, last %.0f; MFMA floor 4608)'
+          % (us(steps.mean()), steps.mean(), steps[:, 0].mean(), np.median(steps.mean(axis=0)), steps[:, -1].mean()))
+    if T.shape[2] > 64:        # inside the steps: M phase issued / T phase done / barrier passed
+        n2 = min(ns, 24)
+        m_end, t_end = w0[:, 64:64 + 2 * n2:2], w0[:, 65:65 + 2 * n2:2]
+        start = np.concatenate([w0[:, 0:1], w0[:, 16:16 + n2 - 1]], axis=1)
+        bar = w0[:, 16:16 + n2]
+        print('    inside a step (cycles, mean over blocks and steps): M phase %.0f   T phase %.0f   barrier wait %.0f   | wave 7: M %.0f T %.0f barrier %.0f'
+              % ((m_end - start).mean(), (t_end - m_end).mean(), (bar - t_end).mean(),
+                 (T[:, 1, 64:64 + 2 * n2:2] - np.concatenate([T[:, 1, 0:1], T[:, 1, 16:16 + n2 - 1]], axis=1)).mean(),
+                 (T[:, 1, 65:65 + 2 * n2:2] - T[:, 1, 64:64 + 2 * n2:2]).mean(), (T[:, 1, 16:16 + n2] - T[:, 1, 65:65 + 2 * n2:2]).mean()))
+    d7 = T[:, 1, 10] - T[:, 0, 10]
+    print('    wave 7 ends %.2f us after wave 0 on average (|max| %.2f)' % (us(d7.mean()), us(np.abs(d7).max())))
+    st = np.sort((w0[:, 62] - w0[:, 62].min()) * 10.0 / 1e3)
+    print('    block starts (us from the first): 10%% %.1f  50%% %.1f  90%% %.1f  last %.1f' % (st[len(st) // 10], st[len(st) // 2], st[len(st) * 9 // 10], st[-1]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('dims', type=int, nargs=5)
@@ -80,16 +119,21 @@ def main():
             tiles = 4 * ((h + 7) // 8) * ((w + 15) // 16)
         part = torch.empty(b, tiles, 32, 2, dtype=torch.float64, device=dev)
         args.gn_part = part.data_ptr(); keep.append(part)
-    for _ in range(2):
-        _lib.check(lib.femasr_conv2d(None, ctypes.byref(args)))
-    torch.cuda.synchronize()
     raw = ctypes.CDLL(_lib.SO_PATH) if os.environ.get('FEMASR_SO') else None
     tt_fn = None
     if raw is not None and a_.wino:
-        tt_fn = getattr(raw, 'femasr_debug_wino_up2_time' if a_.up2 else 'femasr_debug_wino_time', None)
+        tt_fn = getattr(raw, 'femasr_debug_wino_up2_ttbuf' if a_.up2 else 'femasr_debug_wino_ttbuf', None)
     tt = tt_fn is not None
     if tt:
-        tt_fn(None, 1)
+        nsb = b * ((ho + 15) // 16) * ((wo + 15) // 16)
+        nblk = ((nsb + 1) // 2) * (cout // 64)
+        TTS = 64 if a_.up2 else 128
+        ttbuf = torch.zeros(nblk * 2 * TTS, dtype=torch.int64, device=dev)
+        tt_fn.argtypes = [ctypes.c_void_p]
+        assert tt_fn(ttbuf.data_ptr()) == 0
+    for _ in range(2):
+        _lib.check(lib.femasr_conv2d(None, ctypes.byref(args)))
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a_.iters):
@@ -99,18 +143,7 @@ def main():
     ms = e0.elapsed_time(e1) / a_.iters
     fl = 2.0 * b * ho * wo * cout * ks * ks * cin
     if tt:
-        buf = (ctypes.c_ulonglong * 16)()
-        tt_fn(buf, 0)
-        tot = float(buf[15]) or 1.0
-        if a_.up2:
-            names = {0: 'prologue', 1: 'M_phase', 2: 'T_phase', 7: 'barrier', 3: 'epi_write_acc', 4: 'epi_fetch+barrier', 5: 'epi_round', 6: 'epi_barrier2'}
-        else:
-            names = {0: 'prologue', 1: 'M_phase', 2: 'store_patch', 3: 'transform', 4: 'barrier', 5: 'epi_write_acc', 6: 'epi_fetch+barrier',
-                     7: 'epi_round', 8: 'epi_barrier2'}
-        print('  per-wave cycle shares: ' + ' '.join('%s=%.3f' % (n, buf[i] / tot) for i, n in sorted(names.items())))
-        nsb = b * ((ho + 15) // 16) * ((wo + 15) // 16)
-        nwaves = ((nsb + 1) // 2) * (cout // 64) * 8
-        print('  cycles per wave: %.0f' % (tot / a_.iters / nwaves))
+        tt_report(ttbuf.cpu().numpy().reshape(nblk, 2, TTS), cin // 8)
     print('conv %s dbg=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_DBG', '0') + '/' + os.environ.get('FEMASR_DBG16', '0'),
                                                                     os.environ.get('FEMASR_BF16_CLS', '-'), ms, fl / ms / 1e9))
 
