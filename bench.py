@@ -159,7 +159,7 @@ def main():
     ap.add_argument('--workload', choices=['tiles16', 'tile2048'], default='tiles16')
     ap.add_argument('--batch', type=int, default=16, help='128x128 LR tiles per GPU per step (tiles16) / per batched test() call (tile2048)')
     ap.add_argument('--image', type=int, default=2048, help='tile2048: LR image side')
-    ap.add_argument('--streams', type=int, default=2, help='sub-batch streams inside one forward (femasr_set_streams)')
+    ap.add_argument('--streams', type=int, default=3, help='sub-batch streams inside one forward (femasr_set_streams)')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra serialized steps (streams=1) for the roofline object')
     ap.add_argument('--decoder-math', choices=['fp32', 'fp32_strict', 'bf16x3', 'fp32_direct'], default='fp32',
                     help="'fp32' (bench of record, the product default): every layer fp32; the 3x3 convs behind the VQ lookup in the Winograd "
@@ -270,11 +270,11 @@ def main():
             return None
         from femasr_amd import _lib
         lib = _lib.load()
-        nb = 256 * 4
-        ticks = torch.zeros(nb, dtype=torch.int64, device=dev)
+        ticks = torch.zeros(int(lib.femasr_clock_probe_entries()), dtype=torch.int64, device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st = torch.cuda.current_stream(dev)
-        _lib.check(lib.femasr_clock_probe(st.cuda_stream, 4000, _lib.ptr(ticks)))        # warm
+        # two back-to-back probes, the SECOND one timed: launch and clock ramp are behind it (a single cold probe read low)
+        _lib.check(lib.femasr_clock_probe(st.cuda_stream, 40000, _lib.ptr(ticks)))
         e0.record(st)
         _lib.check(lib.femasr_clock_probe(st.cuda_stream, 40000, _lib.ptr(ticks)))       # ~1.1 ms of MFMAs per wave
         e1.record(st)

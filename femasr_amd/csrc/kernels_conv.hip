@@ -31,6 +31,7 @@
 // Grid: 1-D, n-blocks fastest, bijective XCD remap (block b runs on XCD b % 8) so tiles sharing activations /
 //   halo rows share an L2.
 #include "conv_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 #include "detmath.h"
@@ -785,16 +786,24 @@ Variant g_variants[] = {
 constexpr int kNumVariants = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr int kFirstHalo = 9;
 
-int g_small_blocks = -1;         // -1: not read yet (FEMASR_CONV_SMALL_BLOCKS or the default)
-constexpr int kSmallBlocksDefault = 384;
+std::atomic<int> g_small_blocks{-1};         // -1: not set (FEMASR_CONV_SMALL_BLOCKS or the default); test hook, process-global
+// default threshold: 1.5 x the device's CUs (384 on the 256-CU MI355X in SPX mode; a partition with fewer CUs gets its own value)
+int small_blocks_default()
+{
+    static const int v = [] {
+        const char *e = getenv("FEMASR_CONV_SMALL_BLOCKS");
+        if (e && atoi(e) >= 0) return atoi(e);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            return cus + cus / 2;
+        return 384;
+    }();
+    return v;
+}
 int small_launch_blocks()
 {
-    if (g_small_blocks < 0) {
-        const char *e = getenv("FEMASR_CONV_SMALL_BLOCKS");
-        g_small_blocks = e ? atoi(e) : kSmallBlocksDefault;
-        if (g_small_blocks < 0) g_small_blocks = kSmallBlocksDefault;
-    }
-    return g_small_blocks;
+    const int v = g_small_blocks.load(std::memory_order_relaxed);
+    return v >= 0 ? v : small_blocks_default();
 }
 
 int pick_variant(const femasr_conv_args *a, int Ho, int Wo)
@@ -822,7 +831,7 @@ int pick_variant(const femasr_conv_args *a, int Ho, int Wo)
 extern "C" int femasr_conv_small_launch_blocks(int blocks)
 {
     const int prev = small_launch_blocks();
-    g_small_blocks = blocks >= 0 ? blocks : kSmallBlocksDefault;
+    g_small_blocks.store(blocks >= 0 ? blocks : -1, std::memory_order_relaxed);
     return prev;
 }
 
@@ -908,9 +917,9 @@ int femasr_conv2d_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq
                    "conv2d: gn_part (fused GroupNorm partial moments) needs a 3x3 stride-1 halo conv and 32 | Cout, Cout/32 a power of two <= 32");
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull)) {
+    if (dev < 0 || dev >= 64 || !((__atomic_load_n(&v.attr_devs, __ATOMIC_ACQUIRE) >> dev) & 1ull)) {      // (idempotent: a race only repeats the call)
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
-        if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
+        if (dev >= 0 && dev < 64) __atomic_fetch_or(&v.attr_devs, 1ull << dev, __ATOMIC_RELEASE);
     }
     hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3((unsigned)v.threads), v.lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());

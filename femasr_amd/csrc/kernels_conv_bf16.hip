@@ -634,9 +634,9 @@ int femasr_conv_bf16x3_launch(hipStream_t s, const femasr_conv_args *a, int *var
     p.NB = (a->Cout + v.bn - 1) / v.bn;
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull)) {
+    if (dev < 0 || dev >= 64 || !((__atomic_load_n(&v.attr_devs, __ATOMIC_ACQUIRE) >> dev) & 1ull)) {      // (idempotent: a race only repeats the call)
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds + 40 * 1024));
-        if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
+        if (dev >= 0 && dev < 64) __atomic_fetch_or(&v.attr_devs, 1ull << dev, __ATOMIC_RELEASE);
     }
     size_t lds = v.lds + (a->prologue == FEMASR_PRO_GN_SILU ? (size_t)2 * a->Cin * sizeof(float) : 0);
     const size_t epi = 8192 + (size_t)(v.threads / 64) * 32 * 36 * sizeof(float);       // epilogue transpose scratch

@@ -28,6 +28,7 @@
 //     transposed through a per-wave LDS scratch and stored as float4 rows; or the VQ first-min epilogue.
 #include "conv_common.h"
 #include <type_traits>
+#include <atomic>
 #include "detmath.h"
 #include <stdlib.h>
 
@@ -326,7 +327,7 @@ GVariant g_gv[] = { G_CFG(2, 4, 2, true), G_CFG(2, 2, 3, true), G_CFG(1, 4, 2, f
 constexpr int kPerCfg = 7;
 constexpr int kTileOf[] = { 128, 128, 64 };
 constexpr int kNumG = sizeof(g_gv) / sizeof(g_gv[0]);
-int g_cfg = -1;          // -1: not read yet, -2: automatic, 0 / 1: forced by FEMASR_GEMM_CFG (A/B runs)
+std::atomic<int> g_cfg{-1};          // -1: not read yet, -2: automatic, 0 / 1 / 2: forced (FEMASR_GEMM_CFG, femasr_gemm_force_config; test hooks, process-global)
 
 // [chunk][n/32][j][lane][t] <- W[n][k]  (torch (out,in) / OIHW with 1x1 taps), zero padded in n
 __global__ void repack_k1_kernel(const float *__restrict__ in, int O, int I, float *__restrict__ out, size_t total)
@@ -352,12 +353,12 @@ int femasr_gemm_variant_count() { return kNumG; }
 
 extern "C" int femasr_gemm_force_config(int cfg)
 {
-    if (g_cfg == -1) {
+    int prev = g_cfg.load();
+    if (prev == -1) {
         const char *e = getenv("FEMASR_GEMM_CFG");
-        g_cfg = e ? atoi(e) : -2;
+        prev = e ? atoi(e) : -2;
     }
-    const int prev = g_cfg;
-    g_cfg = (cfg >= 0 && cfg < kNumG / kPerCfg) ? cfg : -2;
+    g_cfg.store((cfg >= 0 && cfg < kNumG / kPerCfg) ? cfg : -2);
     return prev;
 }
 const char *femasr_gemm_variant_name(int v) { return (v >= 0 && v < kNumG) ? g_gv[v].name : "?"; }
@@ -395,10 +396,12 @@ int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_e
         const int nres = (a->res1 ? 1 : 0) + (a->res2 ? 1 : 0);
         vi = (a->act == FEMASR_ACT_GELU ? 3 : 0) + nres;
     }
-    if (g_cfg == -1) {
+    if (g_cfg.load() == -1) {
         const char *e = getenv("FEMASR_GEMM_CFG");          // A/B runs: force one configuration
-        g_cfg = e ? atoi(e) : -2;
-        if (g_cfg >= kNumG / kPerCfg) g_cfg = -2;
+        int c0 = e ? atoi(e) : -2;
+        if (c0 >= kNumG / kPerCfg || c0 < 0) c0 = -2;
+        int expect = -1;
+        g_cfg.compare_exchange_strong(expect, c0);
     }
     // Configuration by tile count.  All tiles of a launch cost the same, so it takes ceil(tiles / resident slots) rounds:
     //   * fewer 128 x 128 tiles than FEMASR_GEMM_SMALL_TILES (small batches: B = 1 has 82 of them for proj / fc2 on 256 CUs,
@@ -408,14 +411,13 @@ int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_e
     //     in the network the second sub-batch stream already fills those tails and the step gets 0.4 ms SLOWER: 79.65 vs 79.27.)
     //   * otherwise <4,2> (32-deep chunks, 2 blocks per CU) unless the 3-blocks-per-CU configuration <2,3> wastes less of its
     //     last round.
-    int cfg = g_cfg;
+    int cfg = g_cfg.load();
     if (cfg < 0 || (vq && kTileOf[cfg] != 128)) {
         const double tiles = (double)mb128 * nb128;
         auto eff = [&](double slots) { const double r = tiles / slots; return r / (double)(long long)(r + 0.999999); };
-        static int small_tiles = -1;
-        if (small_tiles < 0) { const char *e = getenv("FEMASR_GEMM_SMALL_TILES"); small_tiles = e ? atoi(e) : 700; }
-        static int tail_pct = -1;             // 128 x 128 tiles whose last round would be emptier than this also go to 64 x 64 tiles
-        if (tail_pct < 0) { const char *e = getenv("FEMASR_GEMM_TAIL_PCT"); tail_pct = e ? atoi(e) : 0; }
+        static const int small_tiles = [] { const char *e = getenv("FEMASR_GEMM_SMALL_TILES"); return e ? atoi(e) : 700; }();
+        // 128 x 128 tiles whose last round would be emptier than this also go to 64 x 64 tiles
+        static const int tail_pct = [] { const char *e = getenv("FEMASR_GEMM_TAIL_PCT"); return e ? atoi(e) : 0; }();
         const double e2 = eff(512.0), e3 = eff(768.0);
         const bool small = tiles < (double)small_tiles || (e2 > e3 ? e2 : e3) * 100.0 < (double)tail_pct;
         cfg = (!vq && small) ? 2 : (e3 > e2 + 0.02 ? 1 : 0);
@@ -426,9 +428,9 @@ int femasr_gemm_launch(hipStream_t s, const femasr_conv_args *a, const conv_vq_e
     GVariant &v = g_gv[vi];
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull)) {
+    if (dev < 0 || dev >= 64 || !((__atomic_load_n(&v.attr_devs, __ATOMIC_ACQUIRE) >> dev) & 1ull)) {      // (idempotent: a race only repeats the call)
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds));
-        if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
+        if (dev >= 0 && dev < 64) __atomic_fetch_or(&v.attr_devs, 1ull << dev, __ATOMIC_RELEASE);
     }
     hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(256), (size_t)v.lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());

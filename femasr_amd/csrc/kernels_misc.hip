@@ -987,6 +987,8 @@ int femasr_image_f32_to_u8(void *stream, const float *in_chw, int H, int W, int 
     return FEMASR_OK;
 }
 
+int femasr_clock_probe_entries(void) { return FEMASR_CLOCK_PROBE_BLOCKS * 4; }      // what femasr_clock_probe writes: one tick count per wave
+
 int femasr_clock_probe(void *stream, int mfmas_per_wave, unsigned long long *ticks)
 {
     FEMASR_REQUIRE(ticks && mfmas_per_wave >= 4, "clock_probe: bad args");

@@ -446,11 +446,7 @@ unsigned long long g_cand_attr_devs = 0ull;
 
 int exact_slots()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("FEMASR_VQ_SLOTS");
-        v = (e && atoi(e) == 4) ? 4 : 8;
-    }
+    static const int v = [] { const char *e = getenv("FEMASR_VQ_SLOTS"); return (e && atoi(e) == 4) ? 4 : 8; }();      // (thread-safe one-time init)
     return v;
 }
 
@@ -503,9 +499,9 @@ int femasr_vq_candidates(void *stream, const float *z, int64_t M, int D, const v
     const int lds = (int)cand_lds_bytes(n_e, D);
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    if (!(g_cand_attr_devs >> (dev & 63) & 1ull)) {
+    if (!(__atomic_load_n(&g_cand_attr_devs, __ATOMIC_ACQUIRE) >> (dev & 63) & 1ull)) {
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)vq_candidates_kernel<VQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        g_cand_attr_devs |= 1ull << (dev & 63);
+        __atomic_fetch_or(&g_cand_attr_devs, 1ull << (dev & 63), __ATOMIC_RELEASE);
     }
     VqCandParams p{z, (long long)M, D, n_e, (const uint4 *)aux, ee, en, cand, cnt};
     hipLaunchKernelGGL(vq_candidates_kernel<VQ_NW>, dim3((unsigned)((M + VQ_R - 1) / VQ_R)), dim3(VQ_NW * 64), lds, s, p);

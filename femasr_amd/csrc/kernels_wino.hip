@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <atomic>
+#include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -116,6 +117,9 @@ __device__ __forceinline__ void at6(tf2 m0, tf2 m1, tf2 m2, tf2 m3, tf2 m4, tf2 
                              //   bit 1  staging ahead of the transform arithmetic (its LDS reads in flight meanwhile): 0 .. +1 %
                              //   bit 2  the transform's patch reads at the start of the M phase / bit 3 the whole transform inside the M phase: +-1 %
                              //   bit 4  prologue: the patches of steps 0 and 1 requested together, second register set: 1 % faster (default)
+                             // Also measured and removed again: the input transform on (tile, channel PAIR) items - both passes packed, 72 instead of 2 x 57
+                             // instructions per SIMD and step, but only on waves 0-3: 2 - 9 % SLOWER (profiles/r04_wino_variants.txt): one wave's VALU stream
+                             // alone does not reach the issue rate two interleaved waves do; the work has to stay balanced over the SIMD's two waves.
 #ifndef FEMASR_WINO_ABL      // ablation experiments (tools/build_debug.sh): bit 0 no patch loads, 1 no U loads, 2 no transform, 3 no MFMAs,
 #define FEMASR_WINO_ABL 0    // 4 no output items, 5 no activation, 6 no staging stores
 #endif
@@ -246,10 +250,10 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
 #pragma unroll
             for (int b = 0; b < 3; ++b) td[a][b] = tf2{src[(a * W4_PW + 2 * b) * W4_PS], src[(a * W4_PW + 2 * b + 1) * W4_PS]};
     };
+    auto fma2 = [](float c, tf2 x, tf2 y) -> tf2 { return __builtin_elementwise_fma(tf2{c, c}, x, y); };
     auto transform_write = [&](int vbuf) {
         if (FEMASR_WINO_ABL & 4) return;
         float *dst = Vs + vbuf * W4_VSZ + tdst;
-        auto fma2 = [](float c, tf2 x, tf2 y) -> tf2 { return __builtin_elementwise_fma(tf2{c, c}, x, y); };
         tf2 r[3][3];
         if (thalf == 0) {        // bt_lo on rows 0..4, two columns at a time (component-wise the same IEEE sequence)
 #pragma unroll
@@ -682,10 +686,15 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
     const size_t lds = wino_lds_bytes(a->Cin, gn);
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull) || v.attr_lds < lds) {
-        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
-        if (v.attr_lds < lds) { v.attr_lds = lds; v.attr_devs = dev >= 0 && dev < 64 ? 1ull << dev : 0ull; }
+    {   // the attribute is per device and grows with Cin (GN table): bookkeeping under a lock (several handles / threads share the variants)
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !((v.attr_devs >> dev) & 1ull) || v.attr_lds < lds) {
+            const size_t want = v.attr_lds > lds ? v.attr_lds : lds;
+            FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+            if (v.attr_lds < want) { v.attr_lds = want; v.attr_devs = 0ull; }
+            if (dev >= 0 && dev < 64) v.attr_devs |= 1ull << dev;
+        }
     }
     hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(W4_NT), lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());

@@ -501,9 +501,9 @@ int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double
     const size_t lds = wino_up_lds_bytes();
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !((g_attr_devs[nres] >> dev) & 1ull)) {
+    if (dev < 0 || dev >= 64 || !((__atomic_load_n(&g_attr_devs[nres], __ATOMIC_ACQUIRE) >> dev) & 1ull)) {
         FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)g_wu_kern[nres], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev >= 0 && dev < 64) g_attr_devs[nres] |= 1ull << dev;
+        if (dev >= 0 && dev < 64) __atomic_fetch_or(&g_attr_devs[nres], 1ull << dev, __ATOMIC_RELEASE);
     }
     hipLaunchKernelGGL(g_wu_kern[nres], dim3((unsigned)(p.MB * p.NB)), dim3(WU_NT), lds, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());

@@ -290,6 +290,7 @@ int femasr_image_f32_to_u8(void *stream, const float *in_chw, int H, int W, int 
  * region: the network's kernels are clock-bound, so a throttling box shows up here and not as a kernel regression). */
 #define FEMASR_CLOCK_PROBE_BLOCKS 256
 int femasr_clock_probe(void *stream, int mfmas_per_wave, unsigned long long *ticks);
+int femasr_clock_probe_entries(void);      /* number of 64-bit entries femasr_clock_probe writes (size the buffer from this) */
 /* Tuning / test hook of the 1x1-conv and linear GEMM (kernels_gemm.hip): force one block configuration for every later launch -
  * 0: 128x128 tiles, 32-deep chunks, 2 stages;  1: 128x128, 16-deep, 3 stages;  2: 64x64 tiles (what small launches get);
  * any negative value: automatic choice by tile count (the default).  Results are bit-identical in every configuration (each
@@ -297,7 +298,7 @@ int femasr_clock_probe(void *stream, int mfmas_per_wave, unsigned long long *tic
 int femasr_gemm_force_config(int cfg);
 /* Same kind of hook for the 3x3 / strided convs with more than 64 output channels: a launch of fewer than `blocks` 128-column
  * blocks runs with 64-column blocks instead (twice the blocks, half the serial chain each: batch-1 latency).  0 = never,
- * negative = the default (384).  Bit-identical either way (same weights layout, same per-wave pixel tiles, same GroupNorm
+ * negative = the default (1.5 x the device's compute units: 384 on a 256-CU MI355X).  Bit-identical either way (same weights layout, same per-wave pixel tiles, same GroupNorm
  * partial-moment order).  Returns the previous threshold. */
 int femasr_conv_small_launch_blocks(int blocks);
 /* Test hook of the Winograd-form convs' size limits (kernels_wino.hip / kernels_wino_up2.hip address their tensors with 32-bit
