@@ -51,6 +51,12 @@ int femasr_gemm_variant_count();
 const char *femasr_gemm_variant_name(int v);
 int femasr_repack_k1(hipStream_t s, const float *in, int O, int I, float *out);
 
+// the Swin MLP in one kernel (kernels_mlp.hip): fc1 + exact GELU + fc2 + residual, hidden activation on chip
+bool femasr_mlp_fused_shape_ok(int C, int hidden);
+int femasr_mlp_fused_launch(hipStream_t s, const float *x, long long M, const float *w1p, const float *b1, const float *w2p, const float *b2,
+                            const float *res, float *out, double *flops_out);
+const char *femasr_mlp_fused_variant_name();
+
 // Winograd F(4x4,3x3) 3x3 convs (kernels_wino.hip)
 size_t femasr_wino_limit_total();       // element limits of the Winograd-form kernels (2^31 / 2^27 per image; femasr_debug_wino_limits)
 size_t femasr_wino_limit_image();

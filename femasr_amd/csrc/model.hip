@@ -174,9 +174,9 @@ struct femasr_handle {
 
 namespace {
 
-enum { SLOT_GN = 0, SLOT_LN, SLOT_ATTN, SLOT_VQ, SLOT_LAYOUT, SLOT_SMALL_COUNT };
+enum { SLOT_GN = 0, SLOT_LN, SLOT_ATTN, SLOT_VQ, SLOT_LAYOUT, SLOT_MLP, SLOT_SMALL_COUNT };
 const char *kSmallNames[SLOT_SMALL_COUNT] = {"gn_moments", "layernorm", "window_attention", "vq(codebook lookup)",
-                                             "pad/crop/gather layout"};
+                                             "pad/crop/gather layout", "mlp_fused<128 tokens,fc1+gelu+fc2,waves=8>"};
 
 struct Scope {   // event pair around one launch (or a small group of launches)
     femasr_handle *h;
@@ -503,6 +503,23 @@ struct Ctx {
         T y1 = conv(att, bp + ".attn.proj", C, op);
         release(att);
         T n2 = ln(y1, bp + ".norm2");
+        // FEMASR_MLP=fused: fc1 + GELU + fc2 + residual in one kernel (kernels_mlp.hip) - bit-identical to the two launches below, measured
+        // 18 % SLOWER than them at B = 16 (0.94 vs 0.80 ms per block-layer, profiles/r04_mlp_fused.txt), so it is not the default
+        static const bool fused_mlp = [] { const char *e = getenv("FEMASR_MLP"); return e && !strcmp(e, "fused"); }();
+        if (fused_mlp && femasr_mlp_fused_shape_ok(C, 4 * C)) {
+            T y2 = alloc_t(1, rows, 1, C);
+            if (!rc && !dry()) {
+                Scope sc(h, s(), dry(), SLOT_MLP, 0.0, (double)rows * C * 12.0);
+                double flops = 0;
+                const int r = femasr_mlp_fused_launch(s(), n2.p, rows, Wt(bp + ".mlp.fc1.weight"), Wt(bp + ".mlp.fc1.bias"), Wt(bp + ".mlp.fc2.weight"),
+                                                      Wt(bp + ".mlp.fc2.bias"), y1.p, y2.p, &flops);
+                sc.set_flops(flops);
+                if (r && !rc) rc = r;
+            }
+            release(n2);
+            release(y1);
+            return y2;
+        }
         ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.act = FEMASR_ACT_GELU;
         T hdn = conv(n2, bp + ".mlp.fc1", 4 * C, o1);
         release(n2);

@@ -301,6 +301,14 @@ int femasr_gemm_force_config(int cfg);
  * negative = the default (1.5 x the device's compute units: 384 on a 256-CU MI355X).  Bit-identical either way (same weights layout, same per-wave pixel tiles, same GroupNorm
  * partial-moment order).  Returns the previous threshold. */
 int femasr_conv_small_launch_blocks(int blocks);
+/* The Swin MLP (network_swinir.py:14-30,276-277) in ONE kernel: out = res + fc2(gelu(fc1(x))), x / res / out (M, C) row-major,
+ * w1_packed / w2_packed = fc1.weight (hidden, C) / fc2.weight (C, hidden) through femasr_repack_oihw(.., kh = kw = 1) (the GEMM layout);
+ * res may be NULL.  Built for C = 256, hidden = 1024 (the reference's only configuration: embed_dim 256, mlp_ratio 4); every output
+ * is the same fp32 fmaf chain as femasr_conv2d's two launches (fc1 with FEMASR_ACT_GELU, fc2 with res1), i.e. bit-identical.
+ * Measured slower than the two launches on MI355X (one 8-wave block per CU in lockstep loses more at its barriers than the hidden
+ * tensor's HBM round trip, already hidden, cost): FeMaSRNet's forward keeps the two launches unless FEMASR_MLP=fused is set. */
+int femasr_mlp_fused(void *stream, const float *x, int64_t M, int C, int hidden, const float *w1_packed, const float *b1,
+                     const float *w2_packed, const float *b2, const float *res, float *out);
 /* Test hook of the Winograd-form convs' size limits (kernels_wino.hip / kernels_wino_up2.hip address their tensors with 32-bit
  * byte offsets: a layer whose input or output has 2^31 or more elements, or 2^27 or more per image, runs in the direct /
  * phase-filter form instead).  log2_total / log2_image replace the two exponents (31 / 27; smaller values move the boundary down

@@ -194,3 +194,43 @@ def test_test_out_parameter_writes_in_place(cuda_device):
         a, b, c, d = t.out_dst(4)
         seq[:, :, a:b, c:d] = o[:, :, ys:ye, xs:xe]
     assert torch.equal(yt, seq)
+
+
+@pytest.mark.parametrize('rows,res', [(128, True), (300, True), (4096 + 17, True), (200, False)])
+def test_mlp_fused_bit_exact(cuda_device, rows, res):
+    """The Swin MLP in one kernel (kernels_mlp.hip: fc1 + exact GELU + fc2 + residual, the 1024-wide hidden activation stays on
+    the CU): bit-identical to the oracle's two linears and to the two-launch GEMM form, also with a ragged last 128-token tile."""
+    import ctypes
+    import gpu_utils as G
+    from oracle import oracle as orc
+    lib = _lib.load()
+    C, Hd = 256, 1024
+    x = synth.uniform(31, 'mx', (rows, C), -2.0, 2.0)
+    w1 = synth.uniform(31, 'mw1', (C, Hd), -0.08, 0.08)          # (in, out)
+    b1 = synth.uniform(31, 'mb1', (Hd,), -0.3, 0.3)
+    w2 = synth.uniform(31, 'mw2', (Hd, C), -0.05, 0.05)
+    b2 = synth.uniform(31, 'mb2', (C,), -0.3, 0.3)
+    r = synth.uniform(31, 'mr', (rows, C), -1.0, 1.0) if res else None
+    ref = orc.linear(orc.linear(x, w1, b1, act=_lib.ACT_GELU), w2, b2, res=r)
+    dev = cuda_device
+    xg = torch.from_numpy(x).to(dev)
+    # torch Linear weights are (out, in): pack them as set_weight does (femasr_repack_oihw with 1x1 taps -> the GEMM layout)
+    w1_oi = torch.from_numpy(np.ascontiguousarray(w1.T)).to(dev)
+    w2_oi = torch.from_numpy(np.ascontiguousarray(w2.T)).to(dev)
+    w1p = torch.empty(int(lib.femasr_packed_weight_floats(Hd, C, 1, 1)), device=dev)
+    w2p = torch.empty(int(lib.femasr_packed_weight_floats(C, Hd, 1, 1)), device=dev)
+    _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(w1_oi), Hd, C, 1, 1, _lib.ptr(w1p)))
+    _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(w2_oi), C, Hd, 1, 1, _lib.ptr(w2p)))
+    b1g, b2g = torch.from_numpy(b1).to(dev), torch.from_numpy(b2).to(dev)
+    rg = torch.from_numpy(r).to(dev) if res else None
+    out = torch.full((rows + 3, C), 123.0, device=dev)          # canary rows behind the last one
+    _lib.check(lib.femasr_mlp_fused(None, _lib.ptr(xg), rows, C, Hd, _lib.ptr(w1p), _lib.ptr(b1g), _lib.ptr(w2p), _lib.ptr(b2g),
+                                    _lib.ptr(rg) if res else None, _lib.ptr(out)))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert (got[rows:] == 123.0).all(), 'rows past M were written'
+    assert np.array_equal(got[:rows], ref), f'fused MLP vs oracle: max-abs {np.abs(got[:rows] - ref).max():.3e}'
+    # ... and the two-launch form it replaces
+    hid = G.conv2d(x.reshape(1, rows, 1, C), w1.reshape(1, 1, C, Hd), b1, 1, act=_lib.ACT_GELU)
+    two = G.conv2d(hid, w2.reshape(1, 1, Hd, C), b2, 1, res1=None if r is None else r.reshape(1, rows, 1, C))
+    assert np.array_equal(got[:rows], two.reshape(rows, C))
