@@ -111,15 +111,23 @@ __device__ __forceinline__ void at6(tf2 m0, tf2 m1, tf2 m2, tf2 m3, tf2 m4, tf2 
     y3 = __builtin_elementwise_fma(tf2{8.0f, 8.0f}, ss, qq) + m5;
 }
 
-#ifndef FEMASR_WINO_V        // schedule variants (tools/build_debug.sh v<N>), all bit-identical, A/B-measured in round 4 (profiles/r04_wino_variants.txt):
-#define FEMASR_WINO_V 16     //   bit 0  the patch of step s+2 requested at the start of the M phase instead of at pair 5: 4 % SLOWER (loads return in
-#endif                       //          order: the slow HBM request ahead of the L2-resident U fragments delays them)
-                             //   bit 1  staging ahead of the transform arithmetic (its LDS reads in flight meanwhile): 0 .. +1 %
-                             //   bit 2  the transform's patch reads at the start of the M phase / bit 3 the whole transform inside the M phase: +-1 %
-                             //   bit 4  prologue: the patches of steps 0 and 1 requested together, second register set: 1 % faster (default)
-                             // Also measured and removed again: the input transform on (tile, channel PAIR) items - both passes packed, 72 instead of 2 x 57
-                             // instructions per SIMD and step, but only on waves 0-3: 2 - 9 % SLOWER (profiles/r04_wino_variants.txt): one wave's VALU stream
-                             // alone does not reach the issue rate two interleaved waves do; the work has to stay balanced over the SIMD's two waves.
+// Schedule variants built and A/B-measured in round 4 (all bit-identical; profiles/r04_wino_variants.txt), removed again except the last two:
+//   * the patch of step s+2 requested at the start of the M phase instead of at pair 5: 4 % SLOWER - loads return in order, the slow HBM
+//     request ahead of the L2-resident U fragments delays them;
+//   * staging ahead of the transform arithmetic (its LDS reads in flight meanwhile): 0 .. +1 %;
+//   * the transform's patch reads at the start of the M phase, or the whole transform inside the M phase: +-1 %;
+//   * the input transform on (tile, channel PAIR) items - both passes packed, 72 instead of 2 x 57 instructions per SIMD and step, but
+//     only on waves 0-3: 2 - 9 % SLOWER: one wave's VALU stream alone does not reach the issue rate two interleaved waves do;
+//   * prologue: every global request first, the patches of steps 0 and 1 requested together (second register set): 1 % faster - kept;
+//   * FEMASR_WINO_DEEP (below): the second register set also used in the main loop - see the main loop.
+#ifndef FEMASR_WINO_DEEP
+#define FEMASR_WINO_DEEP 1
+#endif
+#ifndef FEMASR_WINO_NT       // experiment: cache-policy bits of the streaming accesses (bit 1 = nt): 1 = input patches, 2 = residual loads / output stores
+#define FEMASR_WINO_NT 0
+#endif
+#define W_NT_IN ((FEMASR_WINO_NT & 1) ? 2 : 0)
+#define W_NT_IO ((FEMASR_WINO_NT & 2) ? 2 : 0)
 #ifndef FEMASR_WINO_ABL      // ablation experiments (tools/build_debug.sh): bit 0 no patch loads, 1 no U loads, 2 no transform, 3 no MFMAs,
 #define FEMASR_WINO_ABL 0    // 4 no output items, 5 no activation, 6 no staging stores
 #endif
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (FEMASR_WINO_ABL & 1) { rr[i] = make_float4(0.1f * sc, 0.2f, 0.3f, 0.4f); continue; }
-            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[i], sc * 32, 0);
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[i], sc * 32, W_NT_IN);
             rr[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
@@ -232,7 +240,12 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
             }
         }
     };
-    auto store_patch = [&](int s, int buf) { store_patch_from(rp, s, buf); };
+    // Two register sets (FEMASR_WINO_DEEP): the patch requested in step s - at pair 5, behind the step's U requests, because loads return
+    // in order - is the one staged in step s+1, a whole step later: its HBM latency is never waited for.  (With one set the request of
+    // pair 5 was waited for in the same step's T phase; removing the patch loads altogether was worth 10 %, tools/build_debug.sh abl1.)
+    // The set a step stages is a COMPILE-TIME choice (the main loop is unrolled by two): the wait-count bookkeeping is per register.
+    constexpr bool DEEP = FEMASR_WINO_DEEP != 0;
+    float4 rq[3];
 
     // ---- input transform item: tile tm, channel lane&7, rows 3*thalf .. 3*thalf+2 of B^T d (uniform per wave)
     const int thalf = wave & 1;
@@ -312,15 +325,12 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
 #pragma unroll
         for (int q = 3; q < 6; ++q) early[q - 3] = ldU(s, q);
     };
-    auto mphase = [&](int s) {
-        const float *Vb = Vs + (s & 1) * W4_VSZ + aoff;
+    auto mphase = [&](int s, auto par_c) {      // par_c = s & 1 at compile time
+        constexpr int PAR = decltype(par_c)::value;
+        const float *Vb = Vs + PAR * W4_VSZ + aoff;
 #pragma unroll
         for (int q = 6; q < 9; ++q) late[q - 6] = ldU(s, q);
-        // (variant bit 0) the patch of step s+2 the whole M phase ahead of its use; BEHIND the late fragments - loads return in order, and
-        // those are waited for at pair 6
-        if (FEMASR_WINO_V & 1) load_patch(s + 2);
         f32x4_t an = *reinterpret_cast<const f32x4_t *>(Vb + pcomp(0) * 256);
-        if (FEMASR_WINO_V & 12) transform_read((s + 1) & 1);      // (variant bits 2, 3) the next step's patch was staged a barrier ago
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -333,17 +343,19 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
             }
             if (q < 3) ring[q] = ldU(s + 1, q);
-            if (!(FEMASR_WINO_V & 1) && q == 5) load_patch(s + 2);           // into the registers the early fragments just left; 3 pairs + the transform ahead of its use
-            if ((FEMASR_WINO_V & 8) && q == 4) transform_write((s + 1) & 1);      // V of the NEXT step: not the buffer this M phase reads
+            if (q == 5) {      // behind the step's U requests (earlier it delays them: loads return in order)
+                if (!DEEP) load_patch(s + 2);                     // staged in THIS step's T phase: 3 pairs + the transform ahead of its use
+                else if (PAR) load_patch_to(rp, s + 3);           // staged in the NEXT step's T phase, from the other set
+                else load_patch_to(rq, s + 3);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     // ---- prologue: every global request first (patch of step 0 - and, variant bit 4, of step 1 in a second register set - the first U
     // fragments, the GN table), then the LDS work that needs none of them
-    float4 rq[3];
     load_patch(0);
-    if (FEMASR_WINO_V & 16) load_patch_to(rq, 1);
+    load_patch_to(rq, 1);
 #pragma unroll
     for (int q = 0; q < 3; ++q) ring[q] = ldU(0, q);
     if (PRO == FEMASR_PRO_GN_SILU) {     // GN table [sub-block][a | b][Cin]
@@ -364,19 +376,12 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         }
     }
     __syncthreads();
-    store_patch(0, 0);
-    if (FEMASR_WINO_V & 16) {
-        if (1 < p.nsteps) store_patch_from(rq, 1, 1);
-        __syncthreads();
-        transform_read(0);
-        transform_write(0);
-    } else {
-        load_patch(1);
-        __syncthreads();
-        transform_read(0);
-        transform_write(0);
-        if (1 < p.nsteps) store_patch(1, 1);
-    }
+    store_patch_from(rp, 0, 0);
+    if (DEEP) load_patch_to(rp, 2);              // (set 0 is free again: the patch step 0 stages)
+    if (1 < p.nsteps) store_patch_from(rq, 1, 1);
+    __syncthreads();
+    transform_read(0);
+    transform_write(0);
     issue_early(0);
     __syncthreads();
     WTT(0)
@@ -387,35 +392,34 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     // A staggered order (waves 0-3 M then T, waves 4-7 T then M, with an s_sleep after every MFMA group so that the partner's
     // VALU advances in the gap) was built and measured 3-5 % SLOWER than this plain order: every wave M(s), then T(s).
     constexpr bool HOIST = FAST || PRO == FEMASR_PRO_NONE;       // the lean variants have the registers to read the next transform's
-    for (int s = 0; s < p.nsteps; ++s) {                         // patch values right behind the last MFMA issue
-        mphase(s);
-        constexpr bool INM = (FEMASR_WINO_V & 12) != 0;      // the transform's reads were issued inside the M phase
-        if (HOIST && !INM) transform_read((s + 1) & 1);       // (unconditional: after the last step it transforms a stale patch into a dead buffer)
+    auto step = [&](int s, auto par_c) {                         // patch values right behind the last MFMA issue
+        constexpr int PAR = decltype(par_c)::value;
+        mphase(s, par_c);
+        if (HOIST) transform_read(PAR ^ 1);           // (unconditional: after the last step it transforms a stale patch into a dead buffer)
         __builtin_amdgcn_sched_barrier(0);
         if (s < 24) WTT(64 + 2 * s)
-        if (FEMASR_WINO_V & 8) {
-            if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);
-        } else if (HOIST || INM) {
-            if (FEMASR_WINO_V & 2) {      // the transform's LDS reads in flight under the staging arithmetic (other buffer: no conflict)
-                if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                transform_write((s + 1) & 1);
-            } else {
-                transform_write((s + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);
-            }
-        } else {
-            if (s + 2 < p.nsteps) store_patch(s + 2, s & 1);          // first: frees the staging registers ahead of the transform
+        auto stage = [&]() {                          // the patch of step s+2 -> buffer PAR (DEEP: from the set of this parity, requested a step ago)
+            if (s + 2 < p.nsteps) { if (DEEP && PAR) store_patch_from(rq, s + 2, PAR); else store_patch_from(rp, s + 2, PAR); }
+        };
+        if (HOIST) {
+            transform_write(PAR ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            transform_read((s + 1) & 1);
-            transform_write((s + 1) & 1);
+            stage();
+        } else {
+            stage();                                  // first: frees the staging registers ahead of the transform
+            __builtin_amdgcn_sched_barrier(0);
+            transform_read(PAR ^ 1);
+            transform_write(PAR ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         issue_early(s + 1);                                       // in flight across the barrier
         if (s < 24) WTT(65 + 2 * s)
         __syncthreads();
         if (s < 40) WTT(16 + s)
+    };
+    for (int s = 0; s < p.nsteps; s += 2) {           // (nsteps = Cin / 8 is a multiple of 4)
+        step(s, std::integral_constant<int, 0>{});
+        step(s + 1, std::integral_constant<int, 1>{});
     }
     WTT(1)
 
@@ -474,8 +478,8 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     auto fetch = [&](auto fullc, const __amdgpu_buffer_rsrc_t rs, int r, tf2 (&dst)[16]) {       // 32 loads, no waits between
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            dst[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 0, k), soff(k, 0, r), 0));
-            dst[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 1, k), soff(k, 1, r), 0));
+            dst[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 0, k), soff(k, 0, r), W_NT_IO));
+            dst[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 1, k), soff(k, 1, r), W_NT_IO));
         }
     };
     auto round = [&](auto fullc, int r) {
@@ -513,8 +517,8 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
                     tf2 v = y[b] + bv2;
                     if (HAS1) v = v + r1[k];
                     if (HAS2) v = v + r2[k];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), rs_out, voff(fullc, 0, k), soff(k, 0, r), 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), rs_out, voff(fullc, 1, k), soff(k, 1, r), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), rs_out, voff(fullc, 0, k), soff(k, 0, r), W_NT_IO);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), rs_out, voff(fullc, 1, k), soff(k, 1, r), W_NT_IO);
                     if (gnp) {
                         if (!FULL) {
                             v[0] = __uint_as_float(__float_as_uint(v[0]) & ~oob(0, k));

@@ -44,9 +44,16 @@ __device__ unsigned long long *g_wu_ttbuf;
 #define WUTT_END {}
 #endif
 
-#ifndef FEMASR_WUP_V         // schedule variants (tools/build_debug.sh v<N>): bit 2 the transform's patch reads at the start of the M phase, bit 3 the whole
-#define FEMASR_WUP_V 0       // transform of the next step inside the M phase (behind pair 3)
+// (Measured in round 4 and removed: the transform's patch reads at the start of the M phase, or the whole transform inside the M phase -
+// +-1 %, profiles/r04_wino_variants.txt.  Kept: FEMASR_WINO_DEEP, the two-set patch prefetch of kernels_wino.hip.)
+#ifndef FEMASR_WINO_DEEP
+#define FEMASR_WINO_DEEP 1
 #endif
+#ifndef FEMASR_WINO_NT       // experiment: cache-policy bits of the streaming accesses (bit 1 = nt): 1 = input patches, 2 = residual loads / output stores
+#define FEMASR_WINO_NT 0
+#endif
+#define W_NT_IN ((FEMASR_WINO_NT & 1) ? 2 : 0)
+#define W_NT_IO ((FEMASR_WINO_NT & 2) ? 2 : 0)
 
 namespace {
 
@@ -127,10 +134,11 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         if (ok) goff = (unsigned)((((size_t)(z ? sn[1] - sn[0] : 0) * p.H + y) * p.W + x) * p.Cin + 4 * quad) * 4u;
         sdst = (z * WU_PPIX + pix) * WU_PS + 4 * quad;
     }
-    f32x4_t rp;
+    constexpr bool DEEP = FEMASR_WINO_DEEP != 0;      // two register sets: the patch requested in step s is staged in step s+1 (kernels_wino.hip)
+    f32x4_t rp, rq;
     auto load_patch_to = [&](f32x4_t &rr, int s) {       // unconditional (steps past the end re-read the last one): the wait counters stay static
         const int sc = s < p.nsteps ? s : p.nsteps - 1;
-        rr = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff, sc * 32, 0));
+        rr = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff, sc * 32, W_NT_IN));
     };
     auto load_patch = [&](int s) { load_patch_to(rp, s); };
     auto store_patch_from = [&](const f32x4_t &rr, int buf) {
@@ -206,14 +214,14 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
 #pragma unroll
         for (int q = 3; q < 6; ++q) early[q - 3] = ldU(s, q);
     };
-    auto mphase = [&](int s) {
-        const float *Vb = Vs + (s & 1) * WU_VSZ + aoff;
+    auto mphase = [&](int s, auto par_c) {      // par_c = s & 1 at compile time
+        constexpr int PAR = decltype(par_c)::value;
+        const float *Vb = Vs + PAR * WU_VSZ + aoff;
         late = ldU(s, 6);
         // A fragments: the one of pair q+1 is REQUESTED before the MFMAs of pair q (two register sets, pinned with sched_barrier:
         // left alone the scheduler reuses one set and sinks the read below the MFMAs - an LDS round trip exposed per pair)
         f32x4_t af[2];
         af[0] = *reinterpret_cast<const f32x4_t *>(Vb + vcomp(0) * 256);
-        if (FEMASR_WUP_V & 12) transform_read((s + 1) & 1);      // the next step's patch was staged a barrier ago
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
@@ -226,22 +234,26 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
                 for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
             }
             if (q < 3) ring[q] = ldU(s + 1, q);
-            if (q == 4) load_patch(s + 2);
-            if ((FEMASR_WUP_V & 8) && q == 3) transform_write((s + 1) & 1);      // V of the NEXT step: not the buffer this M phase reads
+            if (q == 4) {      // behind the step's U requests (loads return in order)
+                if (!DEEP) load_patch(s + 2);                     // staged in THIS step's T phase
+                else if (PAR) load_patch_to(rp, s + 3);           // staged in the NEXT step's T phase, from the other set
+                else load_patch_to(rq, s + 3);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // ---- prologue (requesting the patches of steps 0 and 1 together was measured on the F(4x4) kernel: 1-2 % slower)
+    // ---- prologue: the patches of steps 0 and 1 requested together (two register sets), then - DEEP - the one step 0 stages
     load_patch(0);
+    load_patch_to(rq, 1);
 #pragma unroll
     for (int q = 0; q < 3; ++q) ring[q] = ldU(0, q);
     store_patch(0);
-    load_patch(1);
+    if (DEEP) load_patch(2);
+    store_patch_from(rq, 1);
     __syncthreads();
     transform_read(0);
     transform_write(0);
-    store_patch(1);
     issue_early(0);
     __syncthreads();
     WUTT(0)
@@ -253,16 +265,22 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     // Also measured and dropped: the two waves of a SIMD taking the phases in opposite order - waves 0-3 M then T, waves 4-7 T then
     // M - so that one wave's LDS round trips run under its partner's MFMAs: 2.10 vs 1.68 ms on 256 -> 128 channels; the merged
     // control flow also costs a spilled accumulator tile per step.)
-    for (int s = 0; s < p.nsteps; ++s) {
-        mphase(s);
-        if (!(FEMASR_WUP_V & 12)) transform_read((s + 1) & 1);          // (unconditional: after the last step it transforms a stale patch into a dead buffer)
+    auto step = [&](int s, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
+        mphase(s, par_c);
+        transform_read(PAR ^ 1);              // (unconditional: after the last step it transforms a stale patch into a dead buffer)
         __builtin_amdgcn_sched_barrier(0);
-        if (!(FEMASR_WUP_V & 8)) transform_write((s + 1) & 1);
+        transform_write(PAR ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        store_patch(s & 1);                   // step s+2 (loaded during the M phase) -> the buffer the transform of step s read a barrier ago
+        // step s+2 -> the buffer the transform of step s read a barrier ago (DEEP: from the set of this parity, requested a step ago)
+        if (DEEP && PAR) store_patch_from(rq, PAR); else store_patch_from(rp, PAR);
         issue_early(s + 1);
         __syncthreads();
         if (s < 40) WUTT(16 + s)
+    };
+    for (int s = 0; s < p.nsteps; s += 2) {       // (nsteps = Cin / 8 is a multiple of 4)
+        step(s, std::integral_constant<int, 0>{});
+        step(s + 1, std::integral_constant<int, 1>{});
     }
     WUTT(1)
 
@@ -311,8 +329,8 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
     auto fetch = [&](auto fullc, const __amdgpu_buffer_rsrc_t rs, int r, tf2 (&dst)[16]) {       // 32 loads, no waits between
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            dst[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 0, k), soff(k, 0, r), 0));
-            dst[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 1, k), soff(k, 1, r), 0));
+            dst[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 0, k), soff(k, 0, r), W_NT_IO));
+            dst[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 1, k), soff(k, 1, r), W_NT_IO));
         }
     };
     auto round = [&](auto fullc, int r) {
@@ -354,8 +372,8 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
                     if (p.nsteps < 0)
 #endif
                     {
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), rs_out, voff(fullc, 0, k), soff(k, 0, r), 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), rs_out, voff(fullc, 1, k), soff(k, 1, r), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), rs_out, voff(fullc, 0, k), soff(k, 0, r), W_NT_IO);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), rs_out, voff(fullc, 1, k), soff(k, 1, r), W_NT_IO);
                     }
                     if (gnp) {
                         if (!FULL) {
