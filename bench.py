@@ -57,7 +57,7 @@ def rocprof_kernel_name(bench_name):
     if m:
         return f'conv_igemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(5)}, {m.group(6)}, {pro[m.group(3)]}, {m.group(4)}>'
     if bench_name.startswith('conv3x3_wino_up2<'):
-        return 'conv3x3_wino_up2_kernel<0>'
+        return 'conv3x3_wino_up2_kernel<'          # (a prefix: pmc_record averages the instantiations launch-weighted)
     m = re.match(r'conv3x3_wino4<2x16x16px x64,(\w+),(\w+),res=(\*|\d),waves=8>', bench_name)
     if m:      # (res=*: the merged slot of the three residual-operand instantiations, see merge_wino_slots / pmc_record)
         return f'conv3x3_wino4_kernel<{pro[m.group(1)]}, {m.group(2)}' + ('' if m.group(3) == '*' else f', {m.group(3)}>')
@@ -317,6 +317,9 @@ def main():
                    'global_batch': units_per_step, 'tile': '128x128->512x512', 'parallelism': f'tile-parallel x{world}',
                    'backend': ('RCCL (torch.distributed nccl)' if backend == 'nccl' else backend) if use_pg else 'none (single process)',
                    'gather': bool(do_gather), 'streams': args.streams, 'decoder_math': args.decoder_math,
+                   'decoder_math_note': ("product default: all fp32; the SiLU of the Winograd convs' GroupNorm prologue on the hardware exp2 / rcp units - "
+                                         "VQ indices exact, image within 1e-5 of 'fp32_strict' (the mode that is bit-identical to the CPU oracle, timed as a secondary leg)"
+                                         if args.decoder_math == 'fp32' else None),
                    'algorithmic_gflop_per_tile': TILE_GFLOP,
                    'end_to_end_algorithmic_tflops': None if dry else round(TILE_GFLOP * units_per_step * args.steps / dt / 1e3, 2),
                    'flops_note': ('algorithmic = the layer DEFINITIONS (964.47 GFLOP per tile, direct form); the default fp32 mode ISSUES far '

@@ -38,7 +38,7 @@ class ConvArgs(ctypes.Structure):
         ('act', ctypes.c_int32),
         ('res1', vp), ('res2', vp), ('out', vp),
         ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32),
-        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp), ('w_wino', vp), ('fast_act', ctypes.c_int32),
+        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp), ('w_wino', vp), ('fast_act', ctypes.c_int32), ('in_add', vp),
     ]
 
 

@@ -339,6 +339,10 @@ __global__ __launch_bounds__(64, 2) void window_attention_reg_kernel(const float
     const int wy = bid % nwy;
     const int n = bid / nwy;
     for (int i = lane; i < 225; i += 64) Ts[i] = table[i * heads + h];      // one wave: its own LDS writes are ordered before its reads
+    // the shift mask is non-zero only in the last window row / column of the shifted frame (network_swinir.py:216-237): everywhere else
+    // every key shares its query's region and the reference adds 0.0 - which a wave-uniform test skips (same bits: s + 0.0 == s up to
+    // the sign of a zero, which neither the max nor the exponential sees)
+    const bool masked = shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
 
     // token offsets of window positions: row part (8 window rows) + column part (8 window columns), roll folded in
     auto rowtok = [&](int iy) { int y = wy * 8 + iy + shift; if (y >= H) y -= H; return y * W; };
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(64, 2) void window_attention_reg_kernel(const float
         const int i = 32 * ti + c, iy = i >> 3, ix = i & 7;
         const int tb = (iy + 7) * 15 + ix + 7 - 4 * hf;          // bias index of key (jy, jx) is tb - 15*jy - (jx - 4*hf)
         unsigned rowdiff = 0, coldiff = 0;                         // bit jy / bit (jx - 4*hf): key in another mask region
-        if (shift > 0) {
+        if (masked) {
             const int ysi = wy * 8 + iy, xsi = wx * 8 + ix;
             const int ryi = ysi < H - 8 ? 0 : (ysi < H - shift ? 1 : 2), rxi = xsi < W - 8 ? 0 : (xsi < W - shift ? 1 : 2);
 #pragma unroll
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(64, 2) void window_attention_reg_kernel(const float
             for (int r = 0; r < 16; ++r) {
                 const int jy = (r >> 2) + 4 * tj, jxl = r & 3;
                 float a1 = sc[tj][ti][r] + Ts[tb - 15 * jy - jxl];
-                if (shift > 0) a1 = a1 + ((((rowdiff >> jy) | (coldiff >> jxl)) & 1u) ? -100.0f : 0.0f);
+                if (masked) a1 = a1 + ((((rowdiff >> jy) | (coldiff >> jxl)) & 1u) ? -100.0f : 0.0f);
                 sc[tj][ti][r] = a1;
                 m = a1 > m ? a1 : m;
             }
@@ -430,17 +434,17 @@ __global__ __launch_bounds__(64, 2) void window_attention_reg_kernel(const float
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = det_expf(sc[tj][ti][r] - m);
-                sc[tj][ti][r] = e;
-                part = part + e;
+            for (int r = 0; r < 16; r += 2) {      // the exponential two keys at a time on the packed ALU (bit-identical per element); the sum stays one chain
+                const det_f32x2 e = det_expf2(det_f32x2{sc[tj][ti][r] - m, sc[tj][ti][r + 1] - m});
+                sc[tj][ti][r] = e[0];
+                sc[tj][ti][r + 1] = e[1];
+                part = part + e[0];
+                part = part + e[1];
             }
         const float other = __shfl_xor(part, 32, 64);
         const float rinv = 1.0f / (hf ? other + part : part + other);          // half 0 + half 1; one IEEE division per row
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[tj][ti][r] = sc[tj][ti][r] * rinv;
+        for (int tj = 0; tj < 2; ++tj) sc[tj][ti] = sc[tj][ti] * rinv;          // (vector form: v_pk_mul_f32 on register pairs)
     }
 
     // ---- O = P V: A = probabilities (accumulator registers of S^T), B = V
@@ -999,6 +1003,7 @@ int femasr_clock_probe(void *stream, int mfmas_per_wave, unsigned long long *tic
 
 int femasr_conv2d(void *stream, const femasr_conv_args *a)
 {
+    FEMASR_REQUIRE(!a || !a->in_add || (a->w_wino && a->up2), "conv2d: in_add is only taken by the x2 Winograd-type form (up2 = 1 with w_wino)");
     if (a && a->w_bf16x3) {
         FEMASR_REQUIRE(femasr_conv_bf16x3_eligible(a), "conv2d: w_bf16x3 given but the layer is not eligible for the bf16x3 path");
         return femasr_conv_bf16x3_launch((hipStream_t)stream, a, nullptr, nullptr);

@@ -475,9 +475,10 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         if (decltype(fullc)::value) return ooff;
         return ooff | oob(e, k);
     };
-    auto fetch = [&](auto fullc, const __amdgpu_buffer_rsrc_t rs, int r, tf2 (&dst)[16]) {       // 32 loads, no waits between
+    auto fetch = [&](auto fullc, const __amdgpu_buffer_rsrc_t rs, int r, tf2 (&dst)[16], int k0, int k1) {       // pixels k0 .. k1-1, no waits between
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
+            if (k < k0 || k >= k1) continue;
             dst[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 0, k), soff(k, 0, r), W_NT_IO));
             dst[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 1, k), soff(k, 1, r), W_NT_IO));
         }
@@ -489,7 +490,12 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         cs_u = __builtin_amdgcn_readfirstlane(p.Cout * 4);
         rs_u = __builtin_amdgcn_readfirstlane(p.W * p.Cout * 4);
         asm volatile("" : "+s"(cs_u), "+s"(rs_u));
-        if (HAS1) fetch(fullc, rs_r1, r, r1);              // in flight across the barrier and the first transform pass
+        // residuals in flight across the barrier and the first transform pass.  Two operands (the skip feature of a decoder stage, 2 of the
+        // network's 20 launches): only the upper two tile rows of both now, the lower two behind the first pass, whose registers they take -
+        // all 64 values next to the other column tile's accumulators made the allocator spill accumulator tiles INSIDE the main loop
+        // (5.6 GB of scratch writes per launch, 2.46 ms instead of 1.5: profiles/r04_run3_pmc_summary_streams1.txt)
+        if (HAS1) fetch(fullc, rs_r1, r, r1, 0, HAS2 ? 8 : 16);
+        if (HAS2) fetch(fullc, rs_r2, r, r2, 0, 8);
         const float bv = p.bias[n0 + 32 * r + c31];
         __syncthreads();
         WTT(3 + 4 * r)
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
 #pragma unroll
             for (int j = 0; j < 6; ++j)
                 at6(mx(0 * 6 + j), mx(1 * 6 + j), mx(2 * 6 + j), mx(3 * 6 + j), mx(4 * 6 + j), mx(5 * 6 + j), tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
-            if (HAS2) fetch(fullc, rs_r2, r, r2);          // (rare: the skip feature of a decoder stage; behind the first pass, whose registers it takes)
+            if (HAS2) { fetch(fullc, rs_r1, r, r1, 8, 16); fetch(fullc, rs_r2, r, r2, 8, 16); }
             const tf2 bv2 = {bv, bv};
             tf2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
 #pragma unroll
@@ -685,6 +691,7 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
     p.nsteps = a->Cin / 8;
     p.NT32 = a->Cout / 32;
     FEMASR_REQUIRE(a->res1 || !a->res2, "conv_wino: res2 without res1");
+    FEMASR_REQUIRE(!a->in_add, "conv_wino: in_add is only taken by the x2 form");
     const int vi = 3 * (gn ? (a->fast_act ? 2 : 1) : 0) + (a->res1 ? (a->res2 ? 2 : 1) : 0);
     WVariant &v = g_wv[vi];
     const size_t lds = wino_lds_bytes(a->Cin, gn);

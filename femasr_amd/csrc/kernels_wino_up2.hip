@@ -58,7 +58,7 @@ __device__ unsigned long long *g_wu_ttbuf;
 namespace {
 
 struct WinoUpParams {
-    const float *in, *u, *bias, *res1, *res2;
+    const float *in, *in2, *u, *bias, *res1, *res2;      // in2: optional second input, added to `in` while staging (femasr_conv_args.in_add)
     float *out;
     double *gn_part;
     int B, H, W, Cin, Cout, Ho, Wo;     // H, W: low-resolution input; Ho = 2H, Wo = 2W
@@ -89,7 +89,7 @@ __device__ __forceinline__ void at5(tf2 m0, tf2 m1, tf2 mP, tf2 mQ, tf2 m5, tf2 
     y3 = __builtin_elementwise_fma(tf2{8.0f, 8.0f}, mQ, m1) + m5;
 }
 
-template <int NRES>
+template <int NRES, bool ADD>
 __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUpParams p)
 {
     constexpr bool HAS1 = NRES >= 1, HAS2 = NRES >= 2;      // residual operands of the epilogue (compile time; the network's x2 convs have none)
@@ -135,14 +135,19 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         sdst = (z * WU_PPIX + pix) * WU_PS + 4 * quad;
     }
     constexpr bool DEEP = FEMASR_WINO_DEEP != 0;      // two register sets: the patch requested in step s is staged in step s+1 (kernels_wino.hip)
-    f32x4_t rp, rq;
-    auto load_patch_to = [&](f32x4_t &rr, int s) {       // unconditional (steps past the end re-read the last one): the wait counters stay static
+    // ADD: the conv reads in + in2 (the decoder's `x + enc_feats[i]`, femasr_arch.py:361-362): a second request with the same offsets, one
+    // packed add pair per unit while staging (zero padding stays zero: both requests return 0 there)
+    const __amdgpu_buffer_rsrc_t rsrc_in2 = __builtin_amdgcn_make_buffer_rsrc((void *)((ADD ? p.in2 : p.in) + (size_t)sn[0] * p.H * p.W * p.Cin), 0, 0x7fffffff, 0x00020000);
+    struct Unit { f32x4_t a, b; };
+    Unit rp, rq;
+    auto load_patch_to = [&](Unit &rr, int s) {       // unconditional (steps past the end re-read the last one): the wait counters stay static
         const int sc = s < p.nsteps ? s : p.nsteps - 1;
-        rr = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff, sc * 32, W_NT_IN));
+        rr.a = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff, sc * 32, W_NT_IN));
+        if (ADD) rr.b = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in2, goff, sc * 32, W_NT_IN));
     };
     auto load_patch = [&](int s) { load_patch_to(rp, s); };
-    auto store_patch_from = [&](const f32x4_t &rr, int buf) {
-        if (t < WU_UNITS) *reinterpret_cast<f32x4_t *>(Ps + buf * WU_PSZ + sdst) = rr;
+    auto store_patch_from = [&](const Unit &rr, int buf) {
+        if (t < WU_UNITS) *reinterpret_cast<f32x4_t *>(Ps + buf * WU_PSZ + sdst) = ADD ? rr.a + rr.b : rr.a;
     };
     auto store_patch = [&](int buf) { store_patch_from(rp, buf); };
 
@@ -326,9 +331,10 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         if (decltype(fullc)::value) return ooff;
         return ooff | oob(e, k);
     };
-    auto fetch = [&](auto fullc, const __amdgpu_buffer_rsrc_t rs, int r, tf2 (&dst)[16]) {       // 32 loads, no waits between
+    auto fetch = [&](auto fullc, const __amdgpu_buffer_rsrc_t rs, int r, tf2 (&dst)[16], int k0, int k1) {       // pixels k0 .. k1-1, no waits between
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
+            if (k < k0 || k >= k1) continue;
             dst[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 0, k), soff(k, 0, r), W_NT_IO));
             dst[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff(fullc, 1, k), soff(k, 1, r), W_NT_IO));
         }
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         cs_u = __builtin_amdgcn_readfirstlane(p.Cout * 4);
         rs_u = __builtin_amdgcn_readfirstlane(p.Wo * p.Cout * 4);
         asm volatile("" : "+s"(cs_u), "+s"(rs_u));
-        if (HAS1) fetch(fullc, rs_r1, r, r1);
+        if (HAS1) fetch(fullc, rs_r1, r, r1, 0, HAS2 ? 8 : 16);      // (two operands: upper tile rows now, lower ones behind the first pass - kernels_wino.hip)
+        if (HAS2) fetch(fullc, rs_r2, r, r2, 0, 8);
         const float bv = p.bias[n0 + 32 * r + c31];
         __syncthreads();
         WUTT(3 + 4 * r)
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
 #pragma unroll
             for (int j = 0; j < 5; ++j)
                 at5(mx(0 * 5 + j), mx(1 * 5 + j), mx(2 * 5 + j), mx(3 * 5 + j), mx(4 * 5 + j), tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
-            if (HAS2) fetch(fullc, rs_r2, r, r2);
+            if (HAS2) { fetch(fullc, rs_r1, r, r1, 8, 16); fetch(fullc, rs_r2, r, r2, 8, 16); }
             const tf2 bv2 = {bv, bv};
             tf2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
 #pragma unroll
@@ -482,8 +489,9 @@ __global__ void repack_wino_up2_kernel(const float *__restrict__ in, int O, int 
 }
 
 typedef void (*wu_kern_t)(const WinoUpParams);
-wu_kern_t g_wu_kern[3] = {conv3x3_wino_up2_kernel<0>, conv3x3_wino_up2_kernel<1>, conv3x3_wino_up2_kernel<2>};      // by residual operands
-unsigned long long g_attr_devs[3] = {0, 0, 0};
+wu_kern_t g_wu_kern[6] = {conv3x3_wino_up2_kernel<0, false>, conv3x3_wino_up2_kernel<1, false>, conv3x3_wino_up2_kernel<2, false>,      // [2 * ... ]: by residual
+                          conv3x3_wino_up2_kernel<0, true>, conv3x3_wino_up2_kernel<1, true>, conv3x3_wino_up2_kernel<2, true>};          // operands, then + second input
+unsigned long long g_attr_devs[6] = {0, 0, 0, 0, 0, 0};
 
 }  // namespace
 
@@ -504,7 +512,7 @@ int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double
     FEMASR_REQUIRE(a->Ho == 2 * a->H && a->Wo == 2 * a->W, "conv_wino_up2: Ho/Wo mismatch");
     FEMASR_REQUIRE(!a->gn_part || femasr_gn_fusable(a->Cout), "conv_wino_up2: gn_part needs 32 | Cout and Cout/32 a power of two <= 32");
     WinoUpParams p{};
-    p.in = a->in; p.u = (const float *)a->w_wino; p.bias = a->bias;
+    p.in = a->in; p.in2 = a->in_add; p.u = (const float *)a->w_wino; p.bias = a->bias;
     p.res1 = a->res1; p.res2 = a->res2; p.out = a->out; p.gn_part = a->gn_part;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.Ho = a->Ho; p.Wo = a->Wo;
     p.sbX = (p.Wo + 15) / 16;
@@ -515,7 +523,7 @@ int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double
     p.nsteps = a->Cin / 8;
     p.NT32 = a->Cout / 32;
     FEMASR_REQUIRE(a->res1 || !a->res2, "conv_wino_up2: res2 without res1");
-    const int nres = a->res1 ? (a->res2 ? 2 : 1) : 0;
+    const int nres = (a->res1 ? (a->res2 ? 2 : 1) : 0) + (a->in_add ? 3 : 0);      // (index into the instantiation table)
     const size_t lds = wino_up_lds_bytes();
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));

@@ -348,6 +348,7 @@ struct Ctx {
         int pro = FEMASR_PRO_NONE;
         const float *pa = nullptr, *pb = nullptr, *pc = nullptr;
         const float *res1 = nullptr, *res2 = nullptr;
+        const float *in_add = nullptr;   // second input, added while staging: only when up2_wino_ok() said the x2 Winograd-type form will run
         bool lowp = false;       // behind the VQ lookup: may use the bf16x3 path when the handle opts in
         bool want_gn = false;    // the output feeds a GroupNorm: let a bf16x3 conv emit its partial moments
     };
@@ -363,6 +364,7 @@ struct Ctx {
         a.Cout = cout; a.ksz = o.ksz; a.stride = o.stride; a.pad = o.pad; a.up2 = o.up2;
         a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
         a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
+        a.in_add = o.in_add;
         const void *split = nullptr;
         // (several codebooks: the decoder feeds later lookups through before_quant_group[q > 0], so NO conv is 'behind' every
         // lookup - the inexact bf16x3 form, like the Winograd form below, is only taken by single-codebook networks)
@@ -401,6 +403,10 @@ struct Ctx {
         if (wino_on) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) wino_w = h->specs[it->second].wino;
+        }
+        if (o.in_add && !(wino_on && o.up2)) {
+            rc = femasr_set_error(FEMASR_ERR_INVALID, "conv %s: a second input was scheduled for a conv that does not run in the x2 Winograd-type form", prefix.c_str());
+            return y;
         }
         if (wino_on && !wino_w) {
             // the plan sized gn_part for the Winograd form (one partial per 16x16 sub-block); the direct kernels write 2-4x as many:
@@ -552,9 +558,19 @@ struct Ctx {
         return x;
     }
 
-    T up_block(const T &x, const std::string &p, int cout, const float *res2_last, bool lowp = false)   // Upsample x2 -> conv -> RB -> RB
+    // Will the x2 conv of a decoder stage with this input run in the Winograd-type form (the same test conv() makes)?  Then the skip
+    // feature of that stage is added by ITS staging (in_add) instead of by the previous stage's last epilogue (a second residual operand).
+    bool up2_wino_ok(int B, int H, int W, int Cin, int Cout) const
     {
-        ConvOpt o; o.up2 = 1; o.lowp = lowp; o.want_gn = true;
+        femasr_conv_args a{};
+        a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ksz = 3; a.stride = 1; a.pad = 1; a.up2 = 1;
+        a.prologue = FEMASR_PRO_NONE; a.act = FEMASR_ACT_NONE; a.Ho = 2 * H; a.Wo = 2 * W;
+        return (h->decoder_math == 0 || h->decoder_math == 3) && h->cfg.n_codebooks == 1 && femasr_conv_wino_up2_shape_ok(&a);
+    }
+
+    T up_block(const T &x, const std::string &p, int cout, const float *res2_last, bool lowp = false, const float *in_add = nullptr)   // Upsample x2 -> conv -> RB -> RB
+    {
+        ConvOpt o; o.up2 = 1; o.lowp = lowp; o.want_gn = true; o.in_add = in_add;
         T c = conv(x, p + ".1", cout, o);
         T r1 = resblock(c, p + ".2", nullptr, true, lowp, true);
         return resblock(r1, p + ".3", res2_last, true, lowp, false);
@@ -618,7 +634,7 @@ int run_tail(Ctx &c, T x, std::vector<T> &feats, bool fuse_skip, bool with_encod
 {
     femasr_handle *h = c.h;
     const femasr_config &cfg = h->cfg;
-    T prev_dec, prev_q;
+    T prev_dec, prev_q, pending_add;      // pending_add: the skip feature the NEXT stage's x2 conv adds to its input
     int nq_done = 0;
     for (int i = 0; i < h->max_depth; ++i) {
         const int r = cfg.gt_resolution / (1 << h->max_depth) * (1 << i);
@@ -681,12 +697,17 @@ int run_tail(Ctx &c, T x, std::vector<T> &feats, bool fuse_skip, bool with_encod
             for (int k = i + 1; k < h->max_depth; ++k) later = later || quant_at(h, k, nullptr);
             if (later) prev_q = qv; else c.release(qv);
         }
-        // `x = x + enc_feats[i+1]` of the NEXT iteration (femasr_arch.py:361-362), folded into this block's last epilogue
+        // `x = x + enc_feats[i+1]` of the NEXT iteration (femasr_arch.py:361-362): added by the next stage's x2 conv while it stages its
+        // input when that conv runs in the Winograd-type form (same fp32 add, no third operand in this block's last epilogue - the
+        // two-residual epilogue was the slowest instantiation of the F(4x4) kernel); otherwise folded into this block's last epilogue
         const bool next_skip = with_encoder && fuse_skip && i + 1 < h->max_depth && !quant_at(h, i + 1, nullptr);
-        const float *skip = next_skip ? feats[i + 1].p : nullptr;
-        T y = c.up_block(x, "decoder_group." + std::to_string(i) + ".block", channels_at(r * 2), skip, true);
+        const int cout_i = channels_at(r * 2);
+        const bool skip_by_next = next_skip && c.up2_wino_ok(x.B, 2 * x.H, 2 * x.W, cout_i, channels_at(r * 4));
+        const float *skip = (next_skip && !skip_by_next) ? feats[i + 1].p : nullptr;
+        T y = c.up_block(x, "decoder_group." + std::to_string(i) + ".block", cout_i, skip, true, pending_add.p);
         c.release(x);
-        if (next_skip) c.release(feats[i + 1]);
+        if (pending_add.p) { c.release(pending_add); pending_add = T{}; }
+        if (next_skip) { if (skip_by_next) pending_add = feats[i + 1]; else c.release(feats[i + 1]); }
         x = y;
         prev_dec = x;
     }

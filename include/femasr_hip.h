@@ -175,6 +175,10 @@ typedef struct {
                              (v_exp_f32, v_rcp_f32: 1 ulp each) instead of the IEEE-exact polynomial + division - ~6x fewer
                              VALU instructions in the staging; output within ~1e-6 relative of the exact form (no longer
                              bit-identical to the oracle).  0 = exact. */
+    const float *in_add;  /* optional second INPUT tensor of the same (B,H,W,Cin) shape: the conv reads in + in_add (one fp32 add per
+                             element while staging).  Only the x2 Winograd-type form takes it (up2 = 1 with w_wino; anything else refuses):
+                             FeMaSRNet's decoder adds the encoder's skip feature to a stage's input (`x = x + enc_feats[i]`,
+                             femasr_arch.py:361-362) right in front of that stage's x2 conv, so the sum never makes a pass of its own. */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 

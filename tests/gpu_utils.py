@@ -41,7 +41,7 @@ def lib_weight_layout(w_khwc):
 
 
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
-           res1=None, res2=None, bf16x3=False, gn_part=False, wino=False, fast_act=False):
+           res1=None, res2=None, bf16x3=False, gn_part=False, wino=False, fast_act=False, in_add=None):
     """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout)."""
     lib = _lib.load()
     cout = np.asarray(w_khwc).shape[-1]
@@ -89,6 +89,8 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     a.w_up2 = None if wup2 is None else wup2.data_ptr()
     a.w_wino = None if wwino is None else wwino.data_ptr()
     a.fast_act = int(bool(fast_act))
+    tadd = None if in_add is None else dev(in_add)
+    a.in_add = None if tadd is None else tadd.data_ptr()
     part = None
     if gn_part:
         tiles = ((ho + 7) // 8) * ((wo + 15) // 16)

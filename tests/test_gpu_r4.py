@@ -234,3 +234,27 @@ def test_mlp_fused_bit_exact(cuda_device, rows, res):
     hid = G.conv2d(x.reshape(1, rows, 1, C), w1.reshape(1, 1, C, Hd), b1, 1, act=_lib.ACT_GELU)
     two = G.conv2d(hid, w2.reshape(1, 1, Hd, C), b2, 1, res1=None if r is None else r.reshape(1, rows, 1, C))
     assert np.array_equal(got[:rows], two.reshape(rows, C))
+
+
+@pytest.mark.parametrize('cin,cout,shape,nres', [(64, 128, (2, 9, 13), 0), (256, 128, (1, 12, 20), 1), (128, 64, (2, 16, 16), 0)])
+def test_conv_up2_winograd_second_input(cuda_device, cin, cout, shape, nres):
+    """femasr_conv_args.in_add: the x2 Winograd-type conv reads in + in_add (the decoder's `x = x + enc_feats[i]`, femasr_arch.py:361-362,
+    added while the conv stages its input): bit-identical to the conv of the pre-added tensor; every other form refuses the field."""
+    import gpu_utils as G
+    from oracle import oracle as orc
+    from femasr_amd._lib import FemasrError
+    b, h, w = shape
+    x = synth.uniform(41, 'ax', (b, h, w, cin), -2.0, 2.0)
+    sk = synth.uniform(41, 'as', (b, h, w, cin), -1.0, 1.0)
+    wt = synth.uniform(41, 'aw', (3, 3, cin, cout), -0.1, 0.1)
+    bias = synth.uniform(41, 'ab', (cout,), -0.5, 0.5)
+    r1 = synth.uniform(41, 'ar', (b, 2 * h, 2 * w, cout), -1, 1) if nres else None
+    got, part = G.conv2d(x, wt, bias, 3, 1, 1, True, res1=r1, wino=True, gn_part=True, in_add=sk)
+    ref = orc.conv2d((x + sk).astype(np.float32), wt, bias, 3, 1, 1, True, res1=r1, wino=True)
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+    same, part2 = G.conv2d((x + sk).astype(np.float32), wt, bias, 3, 1, 1, True, res1=r1, wino=True, gn_part=True)
+    assert np.array_equal(got, same) and np.array_equal(part.cpu().numpy(), part2.cpu().numpy())
+    with pytest.raises(FemasrError):
+        G.conv2d(x, wt, bias, 3, 1, 1, True, in_add=sk)              # phase-filter form
+    with pytest.raises(FemasrError):
+        G.conv2d(x, wt, bias, 3, 1, 1, False, wino=True, in_add=sk)   # F(4x4,3x3) form
