@@ -44,6 +44,7 @@ def main(argv=None):
     ap.add_argument('--synthetic-seed', type=int, default=None, help='use deterministic synthetic weights (no checkpoint)')
     ap.add_argument('--tile_size', type=int, default=240)
     ap.add_argument('--tile_pad', type=int, default=16)
+    ap.add_argument('--streams', type=int, default=3, help='sub-batch streams inside one batched forward of the tiled branch (3 measured fastest on MI355X)')
     ap.add_argument('--decoder-math', choices=['fp32', 'fp32_strict', 'fp32_direct', 'bf16x3'], default='fp32',
                     help="arithmetic of the convs behind the codebook lookup (FeMaSRNet.decoder_math); 'fp32_strict' is bit-identical to the CPU oracle")
     args = ap.parse_args(argv)
@@ -63,6 +64,7 @@ def main(argv=None):
     else:
         raise SystemExit('no network here: pass -w <weights.pth> (FeMaSR_SRX4/SRX2_model_g.pth) or --synthetic-seed N')
     model.decoder_math = args.decoder_math
+    model.num_streams = args.streams          # tiled images run as batched test() calls: sub-batches on internal streams (bit-identical for any split)
     model = model.to(dev).eval()
 
     if rank == 0:
