@@ -61,6 +61,9 @@ def rocprof_kernel_name(bench_name):
     m = re.match(r'conv3x3_wino4<2x16x16px x64,(\w+),(\w+),res=(\*|\d),waves=8>', bench_name)
     if m:      # (res=*: the merged slot of the three residual-operand instantiations, see merge_wino_slots / pmc_record)
         return f'conv3x3_wino4_kernel<{pro[m.group(1)]}, {m.group(2)}' + ('' if m.group(3) == '*' else f', {m.group(3)}>')
+    m = re.match(r'conv3x3_wino4<16x16px x128,(\w+),(\w+),res=(\*|\d),waves=8>', bench_name)
+    if m:      # the 16x16-pixel x 128-channel block shape (kernels_wino_c128.hip)
+        return f'conv3x3_wino4c_kernel<{pro[m.group(1)]}, {m.group(2)}' + ('' if m.group(3) == '*' else f', {m.group(3)}>')
     m = re.match(r'gemm_dma<tile=64\*(\d),k=8\*(\d),stages=(\d),act=(\d),nres=(\d),vq=(\w+)>', bench_name)
     if m:
         return f'gemm_dma_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}, {m.group(6)}>'

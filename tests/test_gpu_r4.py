@@ -258,3 +258,51 @@ def test_conv_up2_winograd_second_input(cuda_device, cin, cout, shape, nres):
         G.conv2d(x, wt, bias, 3, 1, 1, True, in_add=sk)              # phase-filter form
     with pytest.raises(FemasrError):
         G.conv2d(x, wt, bias, 3, 1, 1, False, wino=True, in_add=sk)   # F(4x4,3x3) form
+
+
+@pytest.fixture
+def wino_form():
+    """femasr_debug_wino_form(...) for the duration of a test; the default (x128 blocks where Cout % 128 == 0) is restored afterwards."""
+    lib = _lib.load()
+
+    def set_(c128):
+        _lib.check(lib.femasr_debug_wino_form(1 if c128 else 0))
+    yield set_
+    _lib.check(lib.femasr_debug_wino_form(1))
+
+
+@pytest.mark.parametrize('cin,cout,shape,gn,fast,nres', [
+    (32, 128, (1, 16, 16), False, False, 0),      # one full sub-block, two steps
+    (64, 128, (2, 21, 35), True, False, 1),       # ragged both ways, two images
+    (128, 256, (1, 40, 24), True, False, 2),      # two 128-channel column blocks, both residual operands
+    (256, 128, (3, 7, 50), False, False, 1),      # narrow image: sub-blocks cut at the bottom and the right
+    (128, 384, (1, 16, 33), True, True, 1),       # three column blocks, hardware-SiLU staging
+    (512, 256, (1, 72, 72), False, False, 0)])    # after_quant at the benchmarked size
+def test_conv_winograd_both_block_shapes(cuda_device, wino_form, cin, cout, shape, gn, fast, nres):
+    """Layers with Cout % 128 == 0 run the F(4x4,3x3) form as 16x16 pixels x 128 channels per block (kernels_wino_c128.hip:
+    v_mfma_f32_16x16x1_f32, 16-channel steps, its own weight layout); the 2 x 16x16 x 64 form of kernels_wino.hip is kept for
+    the other layers.  Both must give the same bits - outputs and the fused GroupNorm partial moments - and, with the exact SiLU,
+    the oracle's."""
+    import gpu_utils as G
+    from oracle import oracle as orc
+    b, h, w = shape
+    x = synth.uniform(43, 'cx', (b, h, w, cin), -2.0, 2.0)
+    wt = synth.uniform(43, 'cw', (3, 3, cin, cout), -0.1, 0.1)
+    bias = synth.uniform(43, 'cb', (cout,), -0.5, 0.5)
+    res = [synth.uniform(43, f'cr{k}', (b, h, w, cout), -1, 1) for k in range(nres)]
+    r1, r2 = (res + [None, None])[:2]
+    pro, xin = (None, None, None), x
+    if gn:
+        ga = synth.uniform(43, 'cga', (b, cin), 0.5, 1.5)
+        gb = synth.uniform(43, 'cgb', (b, cin), -0.5, 0.5)
+        pro, xin = (ga, gb, None), orc.scale_shift_silu(x, ga, gb)
+    kw = dict(prologue=_lib.PRO_GN_SILU if gn else 0, pro=pro, res1=r1, res2=r2, wino=True, gn_part=True, fast_act=fast)
+    wino_form(False)
+    y64, p64 = G.conv2d(x, wt, bias, 3, 1, 1, **kw)
+    wino_form(True)
+    y128, p128 = G.conv2d(x, wt, bias, 3, 1, 1, **kw)
+    assert np.array_equal(y128, y64), f'x128 vs x64 blocks: max-abs {np.abs(y128 - y64).max():.3e}'
+    assert np.array_equal(p128.cpu().numpy(), p64.cpu().numpy()), 'fused GroupNorm partial moments differ between the block shapes'
+    if not fast:
+        ref = orc.conv2d(xin, wt, bias, 3, 1, 1, res1=r1, res2=r2, wino=True)
+        assert np.array_equal(y128, ref), f'x128 blocks vs oracle: max-abs {np.abs(y128 - ref).max():.3e}'

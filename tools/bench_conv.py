@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 from femasr_amd import _lib  # noqa: E402
 
 
-def tt_report(T, nsteps):
+def tt_report(T, nsteps, floor=4608):
     """Cycle stamps of the last launch (tools/build_debug.sh tt): T[block][wave 0 | 7][slot], slots as in kernels_wino.hip."""
     import numpy as np
     T = T.astype(np.float64)
@@ -35,8 +35,8 @@ def tt_report(T, nsteps):
     ph += [('tail (moments out)', w0[:, 10] - w0[:, 9])]
     for n, v in ph:
         print('    %-22s %8.2f us  %5.1f %%   (min %.2f max %.2f)' % (n, us(v.mean()), 100 * v.mean() / cyc.mean(), us(v.min()), us(v.max())))
-    print('    per step: mean %.3f us (%.0f cycles; first %.0f, median step %.0f, last %.0f; MFMA floor 4608)'
-          % (us(steps.mean()), steps.mean(), steps[:, 0].mean(), np.median(steps.mean(axis=0)), steps[:, -1].mean()))
+    print('    per step: mean %.3f us (%.0f cycles; first %.0f, median step %.0f, last %.0f; MFMA floor %d)'
+          % (us(steps.mean()), steps.mean(), steps[:, 0].mean(), np.median(steps.mean(axis=0)), steps[:, -1].mean(), floor))
     if T.shape[2] > 64:        # inside the steps: M phase issued / T phase done / barrier passed
         n2 = min(ns, 24)
         m_end, t_end = w0[:, 64:64 + 2 * n2:2], w0[:, 65:65 + 2 * n2:2]
@@ -121,12 +121,14 @@ def main():
         args.gn_part = part.data_ptr(); keep.append(part)
     raw = ctypes.CDLL(_lib.SO_PATH) if os.environ.get('FEMASR_SO') else None
     tt_fn = None
+    # the 16x16-pixel x 128-channel block shape of kernels_wino_c128.hip (layers with Cout % 128 == 0, unless FEMASR_WINO_C128=0)
+    c128 = a_.wino and not a_.up2 and cout % 128 == 0 and cin % 32 == 0 and os.environ.get('FEMASR_WINO_C128', '1') != '0'
     if raw is not None and a_.wino:
-        tt_fn = getattr(raw, 'femasr_debug_wino_up2_ttbuf' if a_.up2 else 'femasr_debug_wino_ttbuf', None)
+        tt_fn = getattr(raw, 'femasr_debug_wino_up2_ttbuf' if a_.up2 else ('femasr_debug_wino_c128_ttbuf' if c128 else 'femasr_debug_wino_ttbuf'), None)
     tt = tt_fn is not None
     if tt:
         nsb = b * ((ho + 15) // 16) * ((wo + 15) // 16)
-        nblk = ((nsb + 1) // 2) * (cout // 64)
+        nblk = nsb * (cout // 128) if c128 else ((nsb + 1) // 2) * (cout // 64)
         TTS = 64 if a_.up2 else 128
         ttbuf = torch.zeros(nblk * 2 * TTS, dtype=torch.int64, device=dev)
         tt_fn.argtypes = [ctypes.c_void_p]
@@ -143,7 +145,7 @@ def main():
     ms = e0.elapsed_time(e1) / a_.iters
     fl = 2.0 * b * ho * wo * cout * ks * ks * cin
     if tt:
-        tt_report(ttbuf.cpu().numpy().reshape(nblk, 2, TTS), cin // 8)
+        tt_report(ttbuf.cpu().numpy().reshape(nblk, 2, TTS), cin // 16 if c128 else cin // 8, 9216 if c128 else 4608)
     print('conv %s dbg=%s cls=%s: %.3f ms  %.1f TFLOP/s (algorithmic)' % (' '.join(sys.argv[1:]), os.environ.get('FEMASR_DBG', '0') + '/' + os.environ.get('FEMASR_DBG16', '0'),
                                                                     os.environ.get('FEMASR_BF16_CLS', '-'), ms, fl / ms / 1e9))
 
