@@ -276,7 +276,7 @@ def wino_form():
     (64, 128, (2, 21, 35), True, False, 1),       # ragged both ways, two images
     (128, 256, (1, 40, 24), True, False, 2),      # two 128-channel column blocks, both residual operands
     (256, 128, (3, 7, 50), False, False, 1),      # narrow image: sub-blocks cut at the bottom and the right
-    (128, 384, (1, 16, 33), True, True, 1),       # three column blocks, hardware-SiLU staging
+    (128, 512, (1, 16, 33), True, True, 1),       # four column blocks, hardware-SiLU staging
     (512, 256, (1, 72, 72), False, False, 0)])    # after_quant at the benchmarked size
 def test_conv_winograd_both_block_shapes(cuda_device, wino_form, cin, cout, shape, gn, fast, nres):
     """Layers with Cout % 128 == 0 run the F(4x4,3x3) form as 16x16 pixels x 128 channels per block (kernels_wino_c128.hip:
