@@ -133,6 +133,82 @@ class DryNet:
         self.net = net
 
 
+class PowerWatch:
+    """Package power and engine clock of one GPU while steps run: the amdgpu hwmon files (power1_average / power1_input in uW,
+    freq1_input in Hz, power1_cap) read by a host thread at ~25 Hz - no GPU work, no effect on the timed region; `rocm-smi` polled
+    at ~2 Hz when the files are not there.  Round 4 found the MFMA kernels of this network within 2-6 % of the 1400 W package limit
+    (profiles/r04_k_power_clock.txt): the clock the step runs at is set by power, so the line carries both."""
+
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.dir, self.samples, self._stop, self._thr = None, [], False, None
+        for d in sorted(glob.glob('/sys/class/drm/card*/device')):
+            hw = sorted(glob.glob(os.path.join(d, 'hwmon', 'hwmon*')))
+            if not hw:
+                continue
+            if pci_bus_id is not None:
+                try:
+                    if int(os.path.basename(os.path.realpath(d)).split(':')[1], 16) != int(pci_bus_id):
+                        continue
+                except (ValueError, IndexError):
+                    pass
+            for h in hw:
+                if any(os.path.exists(os.path.join(h, f)) for f in ('power1_average', 'power1_input')):
+                    self.dir = h
+                    break
+            if self.dir:
+                break
+        self.source = f'amdgpu hwmon ({self.dir})' if self.dir else 'rocm-smi --showpower --showclocks'
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _sample(self):
+        if self.dir:
+            p = self._read('power1_average')
+            if p is None:
+                p = self._read('power1_input')
+            f = self._read('freq1_input')
+            return (p / 1e6 if p else None, f / 1e6 if f else None)
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(['rocm-smi', '--showpower', '--showclocks'], capture_output=True, text=True, timeout=10).stdout
+        except (OSError, subprocess.SubprocessError):
+            return (None, None)
+        mp = re.search(r'GPU\[0\].*Power \(W\):\s*([\d.]+)', out)
+        mc = re.search(r'GPU\[0\].*sclk clock level:.*\((\d+)Mhz\)', out)
+        return (float(mp.group(1)) if mp else None, float(mc.group(1)) if mc else None)
+
+    def _loop(self):
+        while not self._stop:
+            self.samples.append(self._sample())
+            time.sleep(0.04 if self.dir else 0.1)
+
+    def start(self):
+        import threading
+        self.samples, self._stop = [], False
+        self._thr = threading.Thread(target=self._loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thr:
+            self._thr.join(timeout=15)
+        pw = [a for a, _ in self.samples if a]
+        ck = sorted(b for _, b in self.samples if b)
+        cap = self._read('power1_cap') if self.dir else None
+        if not pw and not ck:
+            return None
+        return {'package_w_mean': round(sum(pw) / len(pw), 1) if pw else None, 'package_w_max': round(max(pw), 1) if pw else None,
+                'cap_w': round(cap / 1e6, 1) if cap else None, 'sclk_mhz_median': round(ck[len(ck) // 2], 1) if ck else None,
+                'sclk_mhz_min_max': [round(ck[0], 1), round(ck[-1], 1)] if ck else None, 'samples': len(self.samples), 'source': self.source}
+
+
 def cpu_model_name():
     try:
         for line in open('/proc/cpuinfo'):
@@ -288,6 +364,11 @@ def main():
         step()
     fence()
     clk_before = clock_probe()
+    watch = None
+    if rank == 0 and not dry:
+        watch = PowerWatch(getattr(torch.cuda.get_device_properties(dev), 'pci_bus_id', None) if world > 1 else None)
+        if watch.dir:                      # file reads on a host thread: safe inside the timed region (rocm-smi is sampled in its own loop below)
+            watch.start()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if not dry else None
     t0 = time.perf_counter()
     if step_ev:
@@ -299,6 +380,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     dt_rank = dt
+    power = watch.stop() if (watch and watch.dir) else None
     clk_after = clock_probe()
     per_rank_ms = [round(dt / args.steps * 1e3, 3)]
     if world > 1:
@@ -338,6 +420,20 @@ def main():
                                         'right after the timed steps: the hot kernels are clock-bound, so box-to-box / thermal differences '
                                         'show here')},
     }
+    if watch and not watch.dir and world == 1:      # no hwmon files: rocm-smi (slow to poll) while ~3 s of extra, untimed steps run
+        watch.start()
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < 3.0:
+            step()
+        fence()
+        power = watch.stop()
+        if power:
+            power['sampled_in'] = 'about 3 s of extra steps right after the timed region (rocm-smi is too slow to poll inside it)'
+    if power:
+        power.setdefault('sampled_in', 'the timed steps')
+        power['note'] = ('package power and engine clock while the steps run.  The fp32 MFMA kernels of this network draw 1.3-1.4 kW at 50-80 % '
+                         'MFMA issue: the 1400 W package limit, not the issue slots, sets the clock (DESIGN.md 5, "the power limit")')
+        res['power'] = power
     if args.workload == 'tile2048' and not dry:
         # where the last step went on every rank: batched test() calls / the RCCL all-gather / the paste of all ranks' tiles
         split = net.last_split_ms

@@ -615,8 +615,9 @@ int femasr_debug_wino_limits(int log2_total, int log2_image)
     return FEMASR_OK;
 }
 
-// tests / A-B measurements: 0 = every layer in the 2 x 16x16-pixel x 64-channel form, 1 = layers with Cout % 128 == 0 in the 16x16 x 128 form
-// (the default; FEMASR_WINO_C128=0 in the environment selects 0).  Weights packed under one setting must be launched under the same one.
+// tests / A-B measurements: 0 = every layer in the 2 x 16x16-pixel x 64-channel form (the default), 1 = layers with Cout % 128 == 0 in the
+// 16x16 x 128 form of kernels_wino_c128.hip, < 0 = what the environment says (FEMASR_WINO_C128, default 0).  Weights packed under one
+// setting must be launched under the same one.
 int femasr_debug_wino_form(int c128)
 {
     femasr_wino_c128_set_form(c128);

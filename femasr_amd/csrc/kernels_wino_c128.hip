@@ -505,14 +505,14 @@ WCVariant g_wc[] = {                              // index = 3 * (prologue form)
 };
 constexpr int kNumWC = sizeof(g_wc) / sizeof(g_wc[0]);
 
-std::atomic<int> g_form{-1};       // -1: not decided yet (FEMASR_WINO_C128 read once), 0: the x64 form everywhere, 1: x128 where the shape allows
+std::atomic<int> g_form{-1};       // -1: ask the environment (FEMASR_WINO_C128, default 0), 0: the x64 form everywhere, 1: x128 where the shape allows
 
 int form_enabled()
 {
     int v = g_form.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("FEMASR_WINO_C128");
-        v = (e && atoi(e) == 0) ? 0 : 1;
+        v = (e && atoi(e) != 0) ? 1 : 0;
         g_form.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -522,7 +522,7 @@ int form_enabled()
 
 // the layers that take this block shape: decided by (Cin, Cout) alone, so that the packed weights of a layer have one layout
 bool femasr_wino_c128_shape(int Cin, int Cout) { return form_enabled() && (Cout % 128) == 0 && (Cin % 32) == 0; }
-void femasr_wino_c128_set_form(int on) { g_form.store(on ? 1 : 0, std::memory_order_relaxed); }
+void femasr_wino_c128_set_form(int on) { g_form.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }
 int femasr_conv_wino_c128_variant_count() { return kNumWC; }
 const char *femasr_conv_wino_c128_variant_name(int v) { return v >= 0 && v < kNumWC ? g_wc[v].name : "?"; }
 

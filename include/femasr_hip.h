@@ -255,7 +255,7 @@ size_t femasr_up2_weight_floats(int O, int I);
 /* 3x3 OIHW -> femasr_conv_args.w_wino: U = G g G^T (6x6 per (o, i)) of F(4x4,3x3), down the columns then along the rows in
  * the operation order of oracle/femasr_oracle.c orc_g6, stored [Cin/8][36 components][Cout/32][lane][4] (the MFMA B fragments
  * of one 8-channel step: 1 KiB per wave load).  out: femasr_wino_weight_floats(O, I) floats = 36 * I * 32*ceil(O/32).
- * Layers with O % 128 == 0 (unless femasr_debug_wino_form(0)) run in the 16x16-pixel x 128-channel block shape and are stored
+ * Under femasr_debug_wino_form(1) / FEMASR_WINO_C128=1 layers with O % 128 == 0 run in the 16x16-pixel x 128-channel block shape and are stored
  * [Cin/16][36][Cout/64][channel quad 4][lane = output channel % 64][4 channels] instead - the same number of floats; the layout is
  * private to the library (pack and launch through it). */
 size_t femasr_wino_weight_floats(int O, int I);
@@ -322,9 +322,11 @@ int femasr_mlp_fused(void *stream, const float *x, int64_t M, int C, int hidden,
  * to sizes a test can allocate), 0 = the default.  Process-global, atomic; plans cached by a handle are not re-made - set it
  * before the first forward of a shape.  Returns FEMASR_OK. */
 int femasr_debug_wino_limits(int log2_total, int log2_image);
-/* Test / measurement hook of the F(4x4,3x3) convs' block shape: c128 != 0 (the default; FEMASR_WINO_C128=0 in the environment selects 0)
- * runs layers with Cout % 128 == 0 as 16x16 pixels x 128 output channels per block (kernels_wino_c128.hip), 0 runs every layer as
- * 2 x 16x16 pixels x 64 channels (kernels_wino.hip).  The two forms produce the same bits and have different packed-weight layouts
+/* Test / measurement hook of the F(4x4,3x3) convs' block shape.  c128 = 0 (the default): every layer runs as 2 x 16x16 pixels x 64
+ * output channels per block (kernels_wino.hip); c128 > 0: layers with Cout % 128 == 0 run as 16x16 pixels x 128 channels per block
+ * (kernels_wino_c128.hip: half the staging / transform work per MFMA, twice the weight-fragment traffic; measured 23 % fewer cycles
+ * and the same time - it reaches the 1400 W package limit and the clock drops); c128 < 0: what the environment says
+ * (FEMASR_WINO_C128=1 selects the x128 form).  The two forms produce the same bits and have different packed-weight layouts
  * (femasr_repack_oihw_wino follows the setting): weights packed under one setting must be launched under the same one - set it
  * before femasr_finalize_weights / femasr_repack_oihw_wino.  Process-global, atomic.  Returns FEMASR_OK. */
 int femasr_debug_wino_form(int c128);

@@ -262,13 +262,13 @@ def test_conv_up2_winograd_second_input(cuda_device, cin, cout, shape, nres):
 
 @pytest.fixture
 def wino_form():
-    """femasr_debug_wino_form(...) for the duration of a test; the default (x128 blocks where Cout % 128 == 0) is restored afterwards."""
+    """femasr_debug_wino_form(...) for the duration of a test; afterwards the environment decides again (default: the x64 form)."""
     lib = _lib.load()
 
     def set_(c128):
         _lib.check(lib.femasr_debug_wino_form(1 if c128 else 0))
     yield set_
-    _lib.check(lib.femasr_debug_wino_form(1))
+    _lib.check(lib.femasr_debug_wino_form(-1))
 
 
 @pytest.mark.parametrize('cin,cout,shape,gn,fast,nres', [
@@ -279,10 +279,10 @@ def wino_form():
     (128, 512, (1, 16, 33), True, True, 1),       # four column blocks, hardware-SiLU staging
     (512, 256, (1, 72, 72), False, False, 0)])    # after_quant at the benchmarked size
 def test_conv_winograd_both_block_shapes(cuda_device, wino_form, cin, cout, shape, gn, fast, nres):
-    """Layers with Cout % 128 == 0 run the F(4x4,3x3) form as 16x16 pixels x 128 channels per block (kernels_wino_c128.hip:
-    v_mfma_f32_16x16x1_f32, 16-channel steps, its own weight layout); the 2 x 16x16 x 64 form of kernels_wino.hip is kept for
-    the other layers.  Both must give the same bits - outputs and the fused GroupNorm partial moments - and, with the exact SiLU,
-    the oracle's."""
+    """The second block shape of the F(4x4,3x3) form - 16x16 pixels x 128 channels per block for layers with Cout % 128 == 0
+    (kernels_wino_c128.hip: v_mfma_f32_16x16x1_f32, 16-channel steps, its own weight layout; opt-in, FEMASR_WINO_C128=1) - against
+    the default 2 x 16x16 x 64 form of kernels_wino.hip: the same bits - outputs and the fused GroupNorm partial moments - and, with
+    the exact SiLU, the oracle's."""
     import gpu_utils as G
     from oracle import oracle as orc
     b, h, w = shape
