@@ -87,17 +87,102 @@ struct VqCandParams {
     int D, n_e;
     const uint4 *cbp;
     const float *ee, *en;           // en[n_e], en[n_e + 1] = max ee, max en
-    unsigned short *cand, *cnt;
+    unsigned short *cand, *cnt;     // !FUSED: the candidate lists, handed to vq_exact_kernel through global memory
+    const float *cb;                // FUSED: the fp32 codebook and the outputs of the lookup
+    long long *idx;
+    float *zq;
 };
 
 __device__ __forceinline__ uint4 ld_code(const uint4 *cbp, int S, int ct, int s, int lane) { return cbp[((size_t)ct * S + s) * 64 + lane]; }
+
+// pass 2: lane = (row, candidate slot); the specified fp32 chain (ORC_KPERM order inside every 8 channels), first-min
+// over the row's candidates with ties to the smaller code, idx and z_q = z + (e[idx] - z).  |z|^2 (one chain, c ascending,
+// as femasr_row_sqsum) is accumulated alongside the first chain of the row.  The chains are latency-bound (each lane
+// streams its own two 2-KB rows): 32-float bursts = one 128-B line per operand, double-buffered.
+struct VqBurst {
+    float4 z[8], e[8];
+};
+__device__ __forceinline__ void vq_load_burst(VqBurst &b, const float *zr, const float *er, int c)
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        b.z[u] = ld4(zr + c + 4 * u);
+        b.e[u] = ld4(er + c + 4 * u);
+    }
+}
+__device__ __forceinline__ void vq_chain_burst(const VqBurst &b, float &acc, float &zacc)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 z0 = b.z[2 * g], z1 = b.z[2 * g + 1], e0 = b.e[2 * g], e1 = b.e[2 * g + 1];
+        acc = __builtin_fmaf(z0.x, e0.x, acc);
+        acc = __builtin_fmaf(z1.x, e1.x, acc);
+        acc = __builtin_fmaf(z0.y, e0.y, acc);
+        acc = __builtin_fmaf(z1.y, e1.y, acc);
+        acc = __builtin_fmaf(z0.z, e0.z, acc);
+        acc = __builtin_fmaf(z1.z, e1.z, acc);
+        acc = __builtin_fmaf(z0.w, e0.w, acc);
+        acc = __builtin_fmaf(z1.w, e1.w, acc);
+        zacc = __builtin_fmaf(z0.x, z0.x, zacc);
+        zacc = __builtin_fmaf(z0.y, z0.y, zacc);
+        zacc = __builtin_fmaf(z0.z, z0.z, zacc);
+        zacc = __builtin_fmaf(z0.w, z0.w, zacc);
+        zacc = __builtin_fmaf(z1.x, z1.x, zacc);
+        zacc = __builtin_fmaf(z1.y, z1.y, zacc);
+        zacc = __builtin_fmaf(z1.z, z1.z, zacc);
+        zacc = __builtin_fmaf(z1.w, z1.w, zacc);
+    }
+}
+// both chains of one (row, code) pair; D % 32 == 0.  (A double-buffered variant needs 128 burst registers and spilled
+// at any occupancy worth having; single bursts with 4+ waves per SIMD measured faster.)
+__device__ __forceinline__ void vq_chain(const float *zr, const float *er, int D, float &acc, float &zacc)
+{
+    for (int c = 0; c < D; c += 32) {
+        VqBurst b;
+        vq_load_burst(b, zr, er, c);
+        vq_chain_burst(b, acc, zacc);
+    }
+}
+
+// The same two chains with the row of z in LDS (fp32, 16-byte chunks xor-swizzled by the row: the 8 rows a wave reads together sit in
+// different banks) and the code's row streamed from L2 one 128-byte burst ahead.  D % 64 == 0.  Operation order = vq_chain's.
+__device__ __forceinline__ void vq_load_e(float4 (&e)[8], const float *er, int c)
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = ld4(er + c + 4 * u);
+}
+__device__ __forceinline__ void vq_chain_lds(const float *zrow, int sw, const float *er, int D, float &acc, float &zacc)
+{
+    float4 ea[8], eb[8];
+    vq_load_e(ea, er, 0);
+    for (int c = 0; c < D; c += 64) {
+        vq_load_e(eb, er, c + 32);
+        {
+            VqBurst b;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { b.z[u] = ld4(zrow + c + 4 * (u ^ sw)); b.e[u] = ea[u]; }
+            vq_chain_burst(b, acc, zacc);
+        }
+        if (c + 64 < D) vq_load_e(ea, er, c + 64);
+        {
+            VqBurst b;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { b.z[u] = ld4(zrow + c + 32 + 4 * (u ^ sw)); b.e[u] = eb[u]; }
+            vq_chain_burst(b, acc, zacc);
+        }
+    }
+}
 
 // pass 1.  Block = NW waves (2 per SIMD: one wave's bound arithmetic overlaps the other's MFMAs), 128 rows of z as a bf16
 // image in LDS (the MFMA B operand); wave w takes code-tile pairs w, w+NW, ..: per 16-deep k step 2 A fragments from global
 // (L2-resident packed codebook, 4-step register ring), 4 B fragments from LDS, 8 MFMAs.
 // Bound per row (see the header): every code's |d - zz - s| <= Erow, s = ee - 2 dot~, Erow = 2 VQ_EPS |z| |e|max + gz;
 // a code survives iff s <= min_j s_j + 2 Erow.
-template <int NW>
+// FUSED (round 4, the default): the block also runs the EXACT phase for its 128 rows - the lists never leave LDS, idx and z_q are written
+// here, ONE launch.  The bf16 image is dead after the search: its 128 KB take the fp32 rows of 64 rows at a time (re-read from L2 / MALL,
+// where this block's first read put them), lane = (row, candidate slot) walks the specified chains with z from LDS and the code's row
+// streamed from L2, and z_q = z + (e - z) is formed from the LDS copy.
+template <int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const VqCandParams p)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -271,64 +356,130 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
             }
     }
     __syncthreads();
-    // lists -> global: (M, VQ_CMAX) uint16, 8 B per thread
-    for (int i = t; i < VQ_R * (VQ_CMAX / 4); i += NW * 64) {
-        const int r = i / (VQ_CMAX / 4), q = i % (VQ_CMAX / 4);
-        if (row0 + r < p.M)
-            *reinterpret_cast<uint2 *>(p.cand + (size_t)(row0 + r) * VQ_CMAX + 4 * q) = *reinterpret_cast<const uint2 *>(s_code + r * VQ_CMAX + 4 * q);
+    if (!FUSED) {
+        // lists -> global: (M, VQ_CMAX) uint16, 8 B per thread
+        for (int i = t; i < VQ_R * (VQ_CMAX / 4); i += NW * 64) {
+            const int r = i / (VQ_CMAX / 4), q = i % (VQ_CMAX / 4);
+            if (row0 + r < p.M)
+                *reinterpret_cast<uint2 *>(p.cand + (size_t)(row0 + r) * VQ_CMAX + 4 * q) = *reinterpret_cast<const uint2 *>(s_code + r * VQ_CMAX + 4 * q);
+        }
+        if (t < VQ_R && row0 + t < p.M) {
+            const unsigned n = s_cnt[t];
+            p.cnt[row0 + t] = (unsigned short)(n > (unsigned)VQ_CMAX ? VQ_ALL : n);
+        }
+        return;
     }
-    if (t < VQ_R && row0 + t < p.M) {
-        const unsigned n = s_cnt[t];
-        p.cnt[row0 + t] = (unsigned short)(n > (unsigned)VQ_CMAX ? VQ_ALL : n);
-    }
-}
-
-// pass 2: lane = (row, candidate slot); the specified fp32 chain (ORC_KPERM order inside every 8 channels), first-min
-// over the row's candidates with ties to the smaller code, idx and z_q = z + (e[idx] - z).  |z|^2 (one chain, c ascending,
-// as femasr_row_sqsum) is accumulated alongside the first chain of the row.  The chains are latency-bound (each lane
-// streams its own two 2-KB rows): 32-float bursts = one 128-B line per operand, double-buffered.
-struct VqBurst {
-    float4 z[8], e[8];
-};
-__device__ __forceinline__ void vq_load_burst(VqBurst &b, const float *zr, const float *er, int c)
-{
+    // ---- exact phase: 512 lanes = 64 rows x 8 candidate slots, the block's rows in two halves
+    static_assert(!FUSED || NW == 8, "the fused exact phase maps 64 rows x 8 slots onto 8 waves");
+    float *zf = reinterpret_cast<float *>(smem_raw);            // [64][D] fp32 over the dead bf16 image (64 * D * 4 = 128 * D * 2 bytes)
+    const int D4 = D >> 2, LD4 = 31 - __builtin_clz(D4);
+    for (int half = 0; half < 2; ++half) {
+        const long long hrow0 = row0 + 64 * half;
+        if (hrow0 >= p.M) break;                                 // (block-uniform)
+        for (int i0 = t; i0 < 64 * D4; i0 += NW * 64 * 8) {      // 8 loads in flight per thread, consecutive lanes walk a row
+            float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        b.z[u] = ld4(zr + c + 4 * u);
-        b.e[u] = ld4(er + c + 4 * u);
-    }
-}
-__device__ __forceinline__ void vq_chain_burst(const VqBurst &b, float &acc, float &zacc)
-{
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * NW * 64, r = i >> LD4, c4 = i & (D4 - 1);
+                v[u] = float4{0.f, 0.f, 0.f, 0.f};
+                if (i < 64 * D4 && hrow0 + r < p.M) v[u] = ld4(p.z + (size_t)(hrow0 + r) * D + 4 * c4);
+            }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4 z0 = b.z[2 * g], z1 = b.z[2 * g + 1], e0 = b.e[2 * g], e1 = b.e[2 * g + 1];
-        acc = __builtin_fmaf(z0.x, e0.x, acc);
-        acc = __builtin_fmaf(z1.x, e1.x, acc);
-        acc = __builtin_fmaf(z0.y, e0.y, acc);
-        acc = __builtin_fmaf(z1.y, e1.y, acc);
-        acc = __builtin_fmaf(z0.z, e0.z, acc);
-        acc = __builtin_fmaf(z1.z, e1.z, acc);
-        acc = __builtin_fmaf(z0.w, e0.w, acc);
-        acc = __builtin_fmaf(z1.w, e1.w, acc);
-        zacc = __builtin_fmaf(z0.x, z0.x, zacc);
-        zacc = __builtin_fmaf(z0.y, z0.y, zacc);
-        zacc = __builtin_fmaf(z0.z, z0.z, zacc);
-        zacc = __builtin_fmaf(z0.w, z0.w, zacc);
-        zacc = __builtin_fmaf(z1.x, z1.x, zacc);
-        zacc = __builtin_fmaf(z1.y, z1.y, zacc);
-        zacc = __builtin_fmaf(z1.z, z1.z, zacc);
-        zacc = __builtin_fmaf(z1.w, z1.w, zacc);
-    }
-}
-// both chains of one (row, code) pair; D % 32 == 0.  (A double-buffered variant needs 128 burst registers and spilled
-// at any occupancy worth having; single bursts with 4+ waves per SIMD measured faster.)
-__device__ __forceinline__ void vq_chain(const float *zr, const float *er, int D, float &acc, float &zacc)
-{
-    for (int c = 0; c < D; c += 32) {
-        VqBurst b;
-        vq_load_burst(b, zr, er, c);
-        vq_chain_burst(b, acc, zacc);
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * NW * 64, r = i >> LD4, c4 = i & (D4 - 1);
+                if (i < 64 * D4) *reinterpret_cast<float4 *>(zf + r * D + 4 * (c4 ^ (r & 7))) = v[u];
+            }
+        }
+        __syncthreads();
+        const int rl = t >> 3, sl = t & 7;                       // row of the half, candidate slot; a wave = 8 rows
+        const long long row = hrow0 + rl;
+        const bool rok = row < p.M;
+        const float *zrow = zf + rl * D;
+        const unsigned ncnt = rok ? s_cnt[64 * half + rl] : 0u;
+        const bool all = ncnt > (unsigned)VQ_CMAX;
+        const int n = all ? 0 : (int)ncnt;
+        int nmax = n;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) nmax = max(nmax, __shfl_xor(nmax, sft, 64));
+        float zzr = 0.f, bd = INFINITY;
+        int bi = 0x7fffffff;
+        for (int base = 0; base < nmax; base += 8) {
+            const int k = base + sl;
+            const bool act = k < n;
+            int code = 0;
+            float acc = 0.f, zacc = 0.f;
+            if (act) {
+                code = (int)s_code[(64 * half + rl) * VQ_CMAX + k];
+                vq_chain_lds(zrow, rl & 7, p.cb + (size_t)code * D, D, acc, zacc);
+            }
+            if (base == 0) zzr = __shfl(zacc, lane & ~7, 64);        // slot 0 is active whenever the row has a candidate
+            const float d = (zzr + s_ee[code]) - 2.0f * acc;
+            if (act && (d < bd || (d == bd && code < bi))) { bd = d; bi = code; }
+        }
+        // rows marked "every code": the whole wave scans the codebook, 64 codes per step (constructed inputs only)
+        unsigned long long allmask = __ballot(all && sl == 0);
+        while (allmask) {
+            const int l = __builtin_ctzll(allmask);
+            allmask &= allmask - 1;
+            const int ra = (w * 64 + l) >> 3;
+            float wd = INFINITY;
+            int wi = 0x7fffffff;
+            for (int j0 = 0; j0 < p.n_e; j0 += 64) {
+                const int code = j0 + lane;
+                float acc = 0.f, zacc = 0.f;
+                vq_chain_lds(zf + ra * D, ra & 7, p.cb + (size_t)code * D, D, acc, zacc);
+                const float d = (zacc + s_ee[code]) - 2.0f * acc;
+                if (d < wd) { wd = d; wi = code; }                   // ascending codes per lane: strict < keeps the first
+            }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                const float od = __shfl_xor(wd, sft, 64);
+                const int oi = __shfl_xor(wi, sft, 64);
+                if (od < wd || (od == wd && oi < wi)) { wd = od; wi = oi; }
+            }
+            if ((lane & ~7) == l) { bd = wd; bi = wi; }              // all eight lanes of that row
+        }
+#pragma unroll
+        for (int sft = 4; sft >= 1; sft >>= 1) {
+            const float od = __shfl_xor(bd, sft, 64);
+            const int oi = __shfl_xor(bi, sft, 64);
+            if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+        }
+        bi = bi < 0 ? 0 : (bi >= p.n_e ? p.n_e - 1 : bi);       // rows with no finite distance keep the sentinel, as the single-pass path
+        if (rok && sl == 0) p.idx[row] = (long long)bi;
+        // z_q of this wave's 8 rows from the LDS copy of z, 4 rows at a time (all code rows requested before the first store)
+        for (int r0 = 0; r0 < 8; r0 += 4) {
+            float4 ev[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = __shfl(bi, (r0 + r) * 8, 64);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = lane * 4 + 256 * j;
+                    ev[r][j] = float4{0.f, 0.f, 0.f, 0.f};
+                    if (c < D) ev[r][j] = ld4(p.cb + (size_t)b * D + c);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = w * 8 + r0 + r;
+                const long long rr = hrow0 + lr;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c4 = lane + 64 * j;
+                    if (rr < p.M && 4 * c4 < D) {
+                        const float4 zv = ld4(zf + lr * D + 4 * (c4 ^ (lr & 7))), ef = ev[r][j];
+                        float4 q;
+                        q.x = zv.x + (ef.x - zv.x);
+                        q.y = zv.y + (ef.y - zv.y);
+                        q.z = zv.z + (ef.z - zv.z);
+                        q.w = zv.w + (ef.w - zv.w);
+                        *reinterpret_cast<float4 *>(p.zq + (size_t)rr * D + 4 * c4) = q;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                             // the next half overwrites zf
     }
 }
 
@@ -487,6 +638,24 @@ size_t femasr_vq_scratch_bytes(int64_t M, int n_e)
     return gemm > two ? gemm : two;
 }
 
+static int launch_candidates(hipStream_t s, const VqCandParams &p, bool fused)
+{
+    const int lds = (int)cand_lds_bytes(p.n_e, p.D);
+    int dev = 0;
+    FEMASR_CHECK_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << ((dev & 31) + (fused ? 32 : 0));       // (one mask: low half = the list-only form, high half = fused)
+    if (!(__atomic_load_n(&g_cand_attr_devs, __ATOMIC_ACQUIRE) & bit)) {
+        FEMASR_CHECK_HIP(hipFuncSetAttribute(fused ? (const void *)vq_candidates_kernel<VQ_NW, true> : (const void *)vq_candidates_kernel<VQ_NW, false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        __atomic_fetch_or(&g_cand_attr_devs, bit, __ATOMIC_RELEASE);
+    }
+    const dim3 grid((unsigned)((p.M + VQ_R - 1) / VQ_R)), block(VQ_NW * 64);
+    if (fused) hipLaunchKernelGGL((vq_candidates_kernel<VQ_NW, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((vq_candidates_kernel<VQ_NW, false>), grid, block, lds, s, p);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
 // pass 1 alone (tests: the exact argmin must be among the candidates).  cand (M, VQ_CMAX = 32) u16, cnt (M) u16 with
 // 0xFFFF = "every code".
 int femasr_vq_candidates(void *stream, const float *z, int64_t M, int D, const void *aux, const float *ee, int n_e,
@@ -494,27 +663,26 @@ int femasr_vq_candidates(void *stream, const float *z, int64_t M, int D, const v
 {
     FEMASR_REQUIRE(z && aux && ee && cand && cnt && M > 0, "vq_candidates: bad args");
     FEMASR_REQUIRE(femasr_vq_twopass_ok(n_e, D), "vq_candidates: shape (n_e=%d, e_dim=%d) not supported", n_e, D);
-    hipStream_t s = (hipStream_t)stream;
     const float *en = (const float *)((const char *)aux + (size_t)n_e * D * 2);
-    const int lds = (int)cand_lds_bytes(n_e, D);
-    int dev = 0;
-    FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    if (!(__atomic_load_n(&g_cand_attr_devs, __ATOMIC_ACQUIRE) >> (dev & 63) & 1ull)) {
-        FEMASR_CHECK_HIP(hipFuncSetAttribute((const void *)vq_candidates_kernel<VQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        __atomic_fetch_or(&g_cand_attr_devs, 1ull << (dev & 63), __ATOMIC_RELEASE);
-    }
-    VqCandParams p{z, (long long)M, D, n_e, (const uint4 *)aux, ee, en, cand, cnt};
-    hipLaunchKernelGGL(vq_candidates_kernel<VQ_NW>, dim3((unsigned)((M + VQ_R - 1) / VQ_R)), dim3(VQ_NW * 64), lds, s, p);
-    FEMASR_CHECK_HIP(hipGetLastError());
-    return FEMASR_OK;
+    VqCandParams p{z, (long long)M, D, n_e, (const uint4 *)aux, ee, en, cand, cnt, nullptr, nullptr, nullptr};
+    return launch_candidates((hipStream_t)stream, p, false);
 }
 
+// The lookup.  Default: ONE launch (candidate search + exact phase in the same block, FUSED above); FEMASR_VQ_FUSED=0 keeps the round-2
+// form - the candidate lists through global memory to vq_exact_kernel - for A/B.  Same results bit for bit.
 int femasr_vq_twopass(void *stream, const float *z, int64_t M, int D, const float *cb, const void *aux, const float *ee, int n_e,
                       int64_t *idx, float *zq, void *scratch)
 {
     FEMASR_REQUIRE(z && cb && aux && ee && idx && zq && scratch && M > 0, "vq_twopass: bad args");
     FEMASR_REQUIRE(M < (1ll << 31) - 256, "vq: too many rows");
+    FEMASR_REQUIRE(femasr_vq_twopass_ok(n_e, D), "vq_twopass: shape (n_e=%d, e_dim=%d) not supported", n_e, D);
     hipStream_t s = (hipStream_t)stream;
+    static const bool fused = [] { const char *e = getenv("FEMASR_VQ_FUSED"); return !(e && atoi(e) == 0); }();      // (thread-safe one-time init)
+    const float *en = (const float *)((const char *)aux + (size_t)n_e * D * 2);
+    if (fused) {
+        VqCandParams p{z, (long long)M, D, n_e, (const uint4 *)aux, ee, en, nullptr, nullptr, cb, (long long *)idx, zq};
+        return launch_candidates(s, p, true);
+    }
     const size_t m64 = (size_t)((M + 63) / 64) * 64;
     uint16_t *cand = (uint16_t *)scratch;
     uint16_t *cnt = cand + m64 * VQ_CMAX;
