@@ -139,21 +139,23 @@ class PowerWatch:
     at ~2 Hz when the files are not there.  Round 4 found the MFMA kernels of this network within 2-6 % of the 1400 W package limit
     (profiles/r04_k_power_clock.txt): the clock the step runs at is set by power, so the line carries both."""
 
-    def __init__(self, pci_bus_id=None):
+    def __init__(self, pci=None):
+        """pci = (domain, bus, device) of the GPU (torch.cuda.get_device_properties): /sys/class/drm lists EVERY card of the host, also
+        inside a one-GPU container, so the card is matched by its PCI address; without a match nothing is read from sysfs."""
         import glob
         self.dir, self.samples, self._stop, self._thr = None, [], False, None
         for d in sorted(glob.glob('/sys/class/drm/card*/device')):
             hw = sorted(glob.glob(os.path.join(d, 'hwmon', 'hwmon*')))
-            if not hw:
+            if not hw or pci is None:
                 continue
-            if pci_bus_id is not None:
-                try:
-                    if int(os.path.basename(os.path.realpath(d)).split(':')[1], 16) != int(pci_bus_id):
-                        continue
-                except (ValueError, IndexError):
-                    pass
+            try:
+                dom, bus, devfn = os.path.basename(os.path.realpath(d)).split(':')
+                if (int(dom, 16), int(bus, 16), int(devfn.split('.')[0], 16)) != tuple(int(v) for v in pci):
+                    continue
+            except (ValueError, IndexError):
+                continue
             for h in hw:
-                if any(os.path.exists(os.path.join(h, f)) for f in ('power1_average', 'power1_input')):
+                if any(os.path.exists(os.path.join(h, f)) for f in ('power1_input', 'power1_average')):
                     self.dir = h
                     break
             if self.dir:
@@ -169,9 +171,9 @@ class PowerWatch:
 
     def _sample(self):
         if self.dir:
-            p = self._read('power1_average')
+            p = self._read('power1_input')            # (MI300-class: the socket's current power, label PPT; older parts: power1_average)
             if p is None:
-                p = self._read('power1_input')
+                p = self._read('power1_average')
             f = self._read('freq1_input')
             return (p / 1e6 if p else None, f / 1e6 if f else None)
         import re
@@ -366,7 +368,8 @@ def main():
     clk_before = clock_probe()
     watch = None
     if rank == 0 and not dry:
-        watch = PowerWatch(getattr(torch.cuda.get_device_properties(dev), 'pci_bus_id', None) if world > 1 else None)
+        pr = torch.cuda.get_device_properties(dev)
+        watch = PowerWatch((pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id) if hasattr(pr, 'pci_bus_id') else None)
         if watch.dir:                      # file reads on a host thread: safe inside the timed region (rocm-smi is sampled in its own loop below)
             watch.start()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if not dry else None

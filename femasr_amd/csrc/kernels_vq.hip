@@ -145,8 +145,9 @@ __device__ __forceinline__ void vq_chain(const float *zr, const float *er, int D
 }
 
 // The same two chains with the row of z in LDS (fp32, 16-byte chunks xor-swizzled by the row: the 8 rows a wave reads together sit in
-// different banks) and the code's row streamed from L2 THREE 128-byte bursts ahead (each lane walks its own 2-KB row: the stream is bound
-// by latency, 2 waves per SIMD; one burst ahead measured 138 us for the phase at M = 82 944).  D % 32 == 0.  Operation order = vq_chain's.
+// different banks) and the code's row streamed from L2 one 128-byte burst ahead.  D % 64 == 0.  Operation order = vq_chain's.
+// (Three bursts ahead - 128 registers of code rows per lane - measured SLOWER: 336 against 311 us for the whole lookup at M = 82 944; every
+// lane walks its own 2-KB row, 16 bytes per request and line: the phase is bound by the texture addresser's line rate, not by latency.)
 __device__ __forceinline__ void vq_load_e(float4 (&e)[8], const float *er, int c)
 {
 #pragma unroll
@@ -154,22 +155,22 @@ __device__ __forceinline__ void vq_load_e(float4 (&e)[8], const float *er, int c
 }
 __device__ __forceinline__ void vq_chain_lds(const float *zrow, int sw, const float *er, int D, float &acc, float &zacc)
 {
-    float4 e[4][8];
-    const int nb = D >> 5;
+    float4 ea[8], eb[8];
+    vq_load_e(ea, er, 0);
+    for (int c = 0; c < D; c += 64) {
+        vq_load_e(eb, er, c + 32);
+        {
+            VqBurst b;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (i < nb) vq_load_e(e[i], er, 32 * i);
-    for (int b0 = 0; b0 < nb; b0 += 4) {
+            for (int u = 0; u < 8; ++u) { b.z[u] = ld4(zrow + c + 4 * (u ^ sw)); b.e[u] = ea[u]; }
+            vq_chain_burst(b, acc, zacc);
+        }
+        if (c + 64 < D) vq_load_e(ea, er, c + 64);
+        {
+            VqBurst b;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int bb = b0 + u;
-            if (bb < nb) {
-                if (bb + 3 < nb) vq_load_e(e[(u + 3) & 3], er, 32 * (bb + 3));
-                VqBurst b;
-#pragma unroll
-                for (int v = 0; v < 8; ++v) { b.z[v] = ld4(zrow + 32 * bb + 4 * (v ^ sw)); b.e[v] = e[u][v]; }
-                vq_chain_burst(b, acc, zacc);
-            }
+            for (int u = 0; u < 8; ++u) { b.z[u] = ld4(zrow + c + 32 + 4 * (u ^ sw)); b.e[u] = eb[u]; }
+            vq_chain_burst(b, acc, zacc);
         }
     }
 }
