@@ -324,8 +324,8 @@ int femasr_mlp_fused(void *stream, const float *x, int64_t M, int C, int hidden,
 int femasr_debug_wino_limits(int log2_total, int log2_image);
 /* Test / measurement hook of the F(4x4,3x3) convs' block shape.  c128 = 0 (the default): every layer runs as 2 x 16x16 pixels x 64
  * output channels per block (kernels_wino.hip); c128 > 0: layers with Cout % 128 == 0 run as 16x16 pixels x 128 channels per block
- * (kernels_wino_c128.hip: half the staging / transform work per MFMA, twice the weight-fragment traffic; measured 23 % fewer cycles
- * and the same time - it reaches the 1400 W package limit and the clock drops); c128 < 0: what the environment says
+ * (kernels_wino_c128.hip: half the staging / transform work per MFMA, twice the weight-fragment traffic; measured 7 % fewer cycles
+ * and 3 % more time - it reaches the 1400 W package limit and the clock drops); c128 < 0: what the environment says
  * (FEMASR_WINO_C128=1 selects the x128 form).  The two forms produce the same bits and have different packed-weight layouts
  * (femasr_repack_oihw_wino follows the setting): weights packed under one setting must be launched under the same one - set it
  * before femasr_finalize_weights / femasr_repack_oihw_wino.  Process-global, atomic.  Returns FEMASR_OK. */
