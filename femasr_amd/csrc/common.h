@@ -63,6 +63,7 @@ size_t femasr_wino_limit_image();
 bool femasr_conv_wino_shape_ok(const femasr_conv_args *a);
 int femasr_conv_wino_gn_tiles(int H, int W);      // fused GroupNorm partials of a Winograd conv: one per 16x16-pixel sub-block
 int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out);
+bool femasr_wino_c128_shape(int Cin, int Cout);      // kernels_wino_c128.hip: this layer runs (and its weights are packed) in the 16x16 x 128 block shape
 int femasr_conv_wino_variant_count();
 const char *femasr_conv_wino_variant_name(int v);
 // nn.Upsample(x2) + 3x3 conv in the 25-product Winograd-type form (kernels_wino_up2.hip); GroupNorm partials per 16x16 OUTPUT sub-block

@@ -82,6 +82,7 @@ struct WSpec {
     void *split = nullptr;  // bf16x3 hi/lo fragments (decoder-side 3x3 convs only), owned
     float *up2w = nullptr;  // phase matrices of a nearest-x2 conv (femasr_repack_oihw_up2), owned
     float *wino = nullptr;  // Winograd-domain weights (decoder-side 3x3 convs of single-codebook networks), owned
+    bool wino_c128 = false; // ... packed in the layout of the 16x16-pixel x 128-channel block shape (femasr_debug_wino_form at pack time)
     bool up2 = false;       // the conv behind nn.Upsample(x2) of an up / decoder block
     bool set = false;
     size_t numel() const { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i]; return n; }
@@ -403,6 +404,11 @@ struct Ctx {
         if (wino_on) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) wino_w = h->specs[it->second].wino;
+            if (wino_w && !o.up2 && h->specs[it->second].wino_c128 != femasr_wino_c128_shape(a.Cin, a.Cout)) {
+                // femasr_debug_wino_form changed between femasr_finalize_weights and this forward: the two block shapes read different layouts
+                rc = femasr_set_error(FEMASR_ERR_WEIGHT, "conv %s: its Winograd weights were packed under another femasr_debug_wino_form setting - finalize the weights again", prefix.c_str());
+                return y;
+            }
         }
         if (o.in_add && !(wino_on && o.up2)) {
             rc = femasr_set_error(FEMASR_ERR_INVALID, "conv %s: a second input was scheduled for a conv that does not run in the x2 Winograd-type form", prefix.c_str());
@@ -935,6 +941,7 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
         rc = w.up2 ? femasr_repack_oihw_wino_up2(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.wino)
                    : femasr_repack_oihw_wino(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.wino);
         if (rc) return rc;
+        w.wino_c128 = !w.up2 && femasr_wino_c128_shape((int)w.shape[1], (int)w.shape[0]);      // (the layout femasr_repack_oihw_wino just chose)
     }
     if (w.kind == W_CONV && dec_side && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {
         const size_t nb = femasr_packed_weight_bf16x3_bytes((int)w.shape[0], (int)w.shape[1], 3, 3);

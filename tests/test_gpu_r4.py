@@ -306,3 +306,18 @@ def test_conv_winograd_both_block_shapes(cuda_device, wino_form, cin, cout, shap
     if not fast:
         ref = orc.conv2d(xin, wt, bias, 3, 1, 1, res1=r1, res2=r2, wino=True)
         assert np.array_equal(y128, ref), f'x128 blocks vs oracle: max-abs {np.abs(y128 - ref).max():.3e}'
+
+
+def test_wino_form_change_after_finalize_is_refused(cuda_device, wino_form):
+    """The two Winograd block shapes read different packed-weight layouts: a handle whose weights were packed under one setting must not
+    run under the other - the forward fails loudly instead of convolving with mis-laid weights."""
+    import gpu_utils as G
+    from femasr_amd._lib import FemasrError
+    net = G.build_net('x4', synth_weights('x4', 2, 'trained'), cuda_device)
+    x = torch.from_numpy(synth.synth_input(5, (1, 3, 32, 48))).to(cuda_device)
+    ref = net.test(x)
+    wino_form(True)
+    with pytest.raises(FemasrError, match='femasr_debug_wino_form'):
+        net.test(x)
+    wino_form(False)
+    assert torch.equal(net.test(x), ref)
