@@ -737,6 +737,8 @@ typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void clock_probe_kernel(int groups, float a, float b, unsigned long long *ticks)
 {
     probe_f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    a += (float)(threadIdx.x & 31) * 0.03125f;        // operands differ from lane to lane (tools/power_probe.py reads the package power under this loop)
+    b += (float)((threadIdx.x >> 5) & 1) * 0.25f;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < groups; ++i) {
         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
