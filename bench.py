@@ -136,8 +136,8 @@ class DryNet:
 class PowerWatch:
     """Package power and engine clock of one GPU while steps run: the amdgpu hwmon files (power1_average / power1_input in uW,
     freq1_input in Hz, power1_cap) read by a host thread at ~25 Hz - no GPU work, no effect on the timed region; `rocm-smi` polled
-    at ~2 Hz when the files are not there.  Round 4 found the MFMA kernels of this network within 2-6 % of the 1400 W package limit
-    (profiles/r04_k_power_clock.txt): the clock the step runs at is set by power, so the line carries both."""
+    at ~2 Hz when the files are not there.  Round 4 found the MFMA kernels of this network within 1-6 % of the 1400 W package limit
+    (profiles/r04_k_power_clock.txt): a step time is not interpretable without the clock it ran at, so the line carries both."""
 
     def __init__(self, pci=None):
         """pci = (domain, bus, device) of the GPU (torch.cuda.get_device_properties): /sys/class/drm lists EVERY card of the host, also
@@ -434,8 +434,9 @@ def main():
             power['sampled_in'] = 'about 3 s of extra steps right after the timed region (rocm-smi is too slow to poll inside it)'
     if power:
         power.setdefault('sampled_in', 'the timed steps')
-        power['note'] = ('package power and engine clock while the steps run.  The fp32 MFMA kernels of this network draw 1.3-1.4 kW at 50-80 % '
-                         'MFMA issue: the 1400 W package limit, not the issue slots, sets the clock (DESIGN.md 5, "the power limit")')
+        power['note'] = ('package power and engine clock while the steps run.  Stand-alone, the fp32 MFMA kernels of this network draw 1.3-1.4 kW '
+                         '(a pure MFMA stream: 0.72 kW at 98 % of the peak) - within 1-6 % of the 1400 W package limit; a kernel that moves '
+                         'more bytes per MFMA is clocked down (DESIGN.md 5, "last experiment")')
         res['power'] = power
     if args.workload == 'tile2048' and not dry:
         # where the last step went on every rank: batched test() calls / the RCCL all-gather / the paste of all ranks' tiles
