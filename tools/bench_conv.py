@@ -65,6 +65,7 @@ def main():
     ap.add_argument('--k1', action='store_true', help='1x1 conv / nn.Linear (fp32 igemm path)')
     ap.add_argument('--gelu', action='store_true')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--power', action='store_true', help='sample package power / engine clock (amdgpu hwmon) while the timed loop runs: use a few thousand iterations')
     a_ = ap.parse_args()
     b, h, w, cin, cout = a_.dims
     if os.environ.get('FEMASR_SO'):          # debug builds (tools/build_debug.sh)
@@ -136,12 +137,21 @@ def main():
     for _ in range(2):
         _lib.check(lib.femasr_conv2d(None, ctypes.byref(args)))
     torch.cuda.synchronize()
+    watch = None
+    if a_.power:
+        import bench
+        pr = torch.cuda.get_device_properties(0)
+        watch = bench.PowerWatch((pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+        watch.start()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a_.iters):
         _lib.check(lib.femasr_conv2d(None, ctypes.byref(args)))
     e1.record()
     torch.cuda.synchronize()
+    if watch:
+        pw = watch.stop()
+        print('  power:', {k: v for k, v in (pw or {}).items() if k in ('package_w_mean', 'package_w_max', 'sclk_mhz_median', 'samples')})
     ms = e0.elapsed_time(e1) / a_.iters
     fl = 2.0 * b * ho * wo * cout * ks * ks * cin
     if tt:
