@@ -595,7 +595,7 @@ size_t cand_lds_bytes(int n_e, int D)
     return (size_t)VQ_R * D * 2 + (size_t)n_e * 4 + (size_t)VQ_NW * VQ_R * 4 + VQ_R * 8 + (size_t)VQ_R * VQ_CMAX * 2;
 }
 
-unsigned long long g_cand_attr_devs = 0ull;
+unsigned long long g_cand_attr_devs[2] = {0ull, 0ull};      // [list-only | one-launch] instantiation: bit = device
 
 int exact_slots()
 {
@@ -645,11 +645,12 @@ static int launch_candidates(hipStream_t s, const VqCandParams &p, bool fused)
     const int lds = (int)cand_lds_bytes(p.n_e, p.D);
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
-    const unsigned long long bit = 1ull << ((dev & 31) + (fused ? 32 : 0));       // (one mask: low half = the list-only form, high half = fused)
-    if (!(__atomic_load_n(&g_cand_attr_devs, __ATOMIC_ACQUIRE) & bit)) {
+    const unsigned long long bit = 1ull << (dev & 63);
+    unsigned long long *mask = &g_cand_attr_devs[fused ? 1 : 0];
+    if (!(__atomic_load_n(mask, __ATOMIC_ACQUIRE) & bit)) {
         FEMASR_CHECK_HIP(hipFuncSetAttribute(fused ? (const void *)vq_candidates_kernel<VQ_NW, true> : (const void *)vq_candidates_kernel<VQ_NW, false>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        __atomic_fetch_or(&g_cand_attr_devs, bit, __ATOMIC_RELEASE);
+        __atomic_fetch_or(mask, bit, __ATOMIC_RELEASE);
     }
     const dim3 grid((unsigned)((p.M + VQ_R - 1) / VQ_R)), block(VQ_NW * 64);
     if (fused) hipLaunchKernelGGL((vq_candidates_kernel<VQ_NW, true>), grid, block, lds, s, p);
