@@ -266,16 +266,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
             ar[u][1] = ld_code(p.cbp, S, 2 * w + 1, u, lane);
         }
     }
-    // B fragments (the bf16 image of z) one k step ahead of the MFMAs that use them, two register sets alternating (they depend on the k step
-    // only, not on the code pair, so the stream runs through the pair loop): with one set every pair of MFMAs waited for its own ds_read
-    // (round-2 form: 20 % of the bf16 peak)
-    uint4 bq[2][4];
-    auto ldB = [&](uint4 (&b)[4], int s) {
-        const int chunk = (2 * s + h) ^ (c31 & SWM);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) b[rt] = zt[(rt * 32 + c31) * CH + chunk];
-    };
-    ldB(bq[0], 0);
+    // (Round 4: the B fragments requested one k step ahead of their MFMAs, two register sets - the ds_read latency then hides behind 8 MFMAs
+    // instead of being waited for before every second one - measured SLOWER: 200 against 173 us for the search at M = 82 944.  The search is
+    // not bound by that latency; two waves per SIMD already cover it, and the extra 16 registers cost more elsewhere.)
     for (int pp = w; pp < npairs; pp += NW) {
         f32x16 acc[2][4];
 #pragma unroll
@@ -289,11 +282,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
             for (int u = 0; u < 4; ++u) {
                 const int s = s0 + u;
                 const uint4 a0 = ar[u][0], a1 = ar[u][1];
-                ldB(bq[(u + 1) & 1], s + 1 < S ? s + 1 : 0);          // (S % 4 == 0: the set of a step is a compile-time choice)
-                __builtin_amdgcn_sched_barrier(0);                    // requested BEFORE this step's MFMAs, not behind them
+                const int chunk = (2 * s + h) ^ (c31 & SWM);
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
-                    const uint4 b = bq[u & 1][rt];
+                    const uint4 b = zt[(rt * 32 + c31) * CH + chunk];
                     acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b),
                                                                         acc[0][rt], 0, 0, 0);
                     acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b),
