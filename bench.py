@@ -362,10 +362,10 @@ def main():
         sync()
         return round(float(ticks.double().mean().item()) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 3)
 
-    for _ in range(args.warmup):
+    clk_before = clock_probe()       # ahead of the warm-up: the timed steps follow the warm-up steps directly (with the probe between them the
+    for _ in range(args.warmup):     # first timed step ran 4 ms slow - the chip leaves the probe's pure-MFMA loop in another power state)
         step()
     fence()
-    clk_before = clock_probe()
     watch = None
     if rank == 0 and not dry:
         pr = torch.cuda.get_device_properties(dev)
@@ -419,7 +419,7 @@ def main():
                                                        if step_ms else None),
                          'step_ms_min_max': [round(min(step_ms), 2), round(max(step_ms), 2)] if step_ms else None,
                          'mfma_clock_ghz_before_after': [clk_before, clk_after],
-                         'clock_note': ('clock the chip sustains under back-to-back fp32 MFMAs (femasr_clock_probe), probed right before and '
+                         'clock_note': ('clock the chip sustains under back-to-back fp32 MFMAs (femasr_clock_probe), probed before the warm-up steps and '
                                         'right after the timed steps: the hot kernels are clock-bound, so box-to-box / thermal differences '
                                         'show here')},
     }
