@@ -324,155 +324,180 @@ typedef float att_f32x16 __attribute__((ext_vector_type(16)));
 //         bytes per half-wave), issued before the softmax so that its VALU work covers their latency; O leaves as 128-byte
 //         row segments.  LDS holds only the 225-entry bias table: no barriers beyond the one after its load.
 // ------------------------------------------------------------------------------------------
+// UNITS = (window, head) units a wave works through (consecutive unit numbers: the same window, the next head).  With 2 the Q / K rows of the
+// second unit are requested as soon as the first unit's S^T MFMAs have consumed their registers - in flight under its softmax and P V -
+// and half as many waves are launched.  Every unit is computed by the same instruction sequence either way: bit-identical.
+template <int UNITS>
 __global__ __launch_bounds__(64, 2) void window_attention_reg_kernel(const float *__restrict__ qkv, int B, int H, int W, int C,
                                                                      int heads, int shift, const float *__restrict__ table,
-                                                                     float *__restrict__ out)
+                                                                     float *__restrict__ out, int total)
 {
-    __shared__ float Ts[232];
+    __shared__ float Ts[UNITS][232];
     const int lane = threadIdx.x, c = lane & 31, hf = lane >> 5;
     const int nwx = W >> 3, nwy = H >> 3;
-    int bid = blockIdx.x;
-    const int h = bid % heads;
-    bid /= heads;
-    const int wx = bid % nwx;
-    bid /= nwx;
-    const int wy = bid % nwy;
-    const int n = bid / nwy;
-    for (int i = lane; i < 225; i += 64) Ts[i] = table[i * heads + h];      // one wave: its own LDS writes are ordered before its reads
-    // the shift mask is non-zero only in the last window row / column of the shifted frame (network_swinir.py:216-237): everywhere else
-    // every key shares its query's region and the reference adds 0.0 - which a wave-uniform test skips (same bits: s + 0.0 == s up to
-    // the sign of a zero, which neither the max nor the exponential sees)
-    const bool masked = shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
-
-    // token offsets of window positions: row part (8 window rows) + column part (8 window columns), roll folded in
-    auto rowtok = [&](int iy) { int y = wy * 8 + iy + shift; if (y >= H) y -= H; return y * W; };
-    auto coltok = [&](int ix) { int x = wx * 8 + ix + shift; if (x >= W) x -= W; return x; };
-    const size_t img = (size_t)n * H * W;
-    const float *qbase = qkv + img * 3 * C + h * ATT_HD;          // this sample / head: 32-bit element offsets from here on
-    float *obase = out + img * C + h * ATT_HD;
+    struct Unit { int h, wx, wy, n; };
+    auto unit_of = [&](int bid) {
+        Unit g;
+        g.h = bid % heads;
+        bid /= heads;
+        g.wx = bid % nwx;
+        bid /= nwx;
+        g.wy = bid % nwy;
+        g.n = bid / nwy;
+        return g;
+    };
+    Unit gs[UNITS];
+    bool has[UNITS];
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int bid = (int)blockIdx.x * UNITS + u;
+        has[u] = bid < total;                                     // (uniform)
+        gs[u] = unit_of(has[u] ? bid : total - 1);
+        for (int i = lane; i < 225; i += 64) Ts[u][i] = table[i * heads + gs[u].h];      // one wave: its own LDS writes are ordered before its reads
+    }
     const float scale = 0.17677669529663687f;   // (float)(32 ** -0.5)
+    // token offsets of window positions: row part (8 window rows) + column part (8 window columns), roll folded in
+    auto rowtok = [&](const Unit &g, int iy) { int y = g.wy * 8 + iy + shift; if (y >= H) y -= H; return y * W; };
+    auto coltok = [&](const Unit &g, int ix) { int x = g.wx * 8 + ix + shift; if (x >= W) x -= W; return x; };
+    auto qb = [&](const Unit &g) { return qkv + (size_t)g.n * H * W * 3 * C + g.h * ATT_HD; };      // this sample / head: 32-bit element offsets from here on
 
     // ---- operands of S^T: lane (c, hf) holds row (32*t + c) of K / Q, elements d = 2s + hf
     float ak[2][16], bq[2][16];
+    auto load_qk = [&](const Unit &g) {
+        const float *qbase = qb(g);
 #pragma unroll
-    for (int tI = 0; tI < 2; ++tI) {
-        const int w = 32 * tI + c;                     // window position 0..63 of this lane's row
-        const unsigned tok = (unsigned)(rowtok(w >> 3) + coltok(w & 7));
-        const float *kp = qbase + tok * (unsigned)(3 * C) + C, *qp = qbase + tok * (unsigned)(3 * C);
+        for (int tI = 0; tI < 2; ++tI) {
+            const int w = 32 * tI + c;                     // window position 0..63 of this lane's row
+            const unsigned tok = (unsigned)(rowtok(g, w >> 3) + coltok(g, w & 7));
+            const float *kp = qbase + tok * (unsigned)(3 * C) + C, *qp = qbase + tok * (unsigned)(3 * C);
 #pragma unroll
-        for (int d4 = 0; d4 < 8; ++d4) {
-            const float4 kv = ld4(kp + 4 * d4), qv = ld4(qp + 4 * d4);
-            ak[tI][2 * d4] = hf ? kv.y : kv.x;
-            ak[tI][2 * d4 + 1] = hf ? kv.w : kv.z;
-            bq[tI][2 * d4] = (hf ? qv.y : qv.x) * scale;
-            bq[tI][2 * d4 + 1] = (hf ? qv.w : qv.z) * scale;
+            for (int d4 = 0; d4 < 8; ++d4) {
+                const float4 kv = ld4(kp + 4 * d4), qv = ld4(qp + 4 * d4);
+                ak[tI][2 * d4] = hf ? kv.y : kv.x;
+                ak[tI][2 * d4 + 1] = hf ? kv.w : kv.z;
+                bq[tI][2 * d4] = (hf ? qv.y : qv.x) * scale;
+                bq[tI][2 * d4 + 1] = (hf ? qv.w : qv.z) * scale;
+            }
         }
-    }
-    att_f32x16 sc[2][2];      // [tj][ti]
+    };
+    load_qk(gs[0]);
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[tj][ti][r] = 0.f;
-#pragma unroll
-    for (int st = 0; st < 16; ++st)
+    for (int u = 0; u < UNITS; ++u) {
+        if (!has[u]) break;
+        const Unit g = gs[u];
+        const float *qbase = qb(g);
+        float *obase = out + (size_t)g.n * H * W * C + g.h * ATT_HD;
+        // the shift mask is non-zero only in the last window row / column of the shifted frame (network_swinir.py:216-237): everywhere else
+        // every key shares its query's region and the reference adds 0.0 - which a wave-uniform test skips (same bits: s + 0.0 == s up to
+        // the sign of a zero, which neither the max nor the exponential sees)
+        const bool masked = shift > 0 && (g.wy == nwy - 1 || g.wx == nwx - 1);
+        att_f32x16 sc[2][2];      // [tj][ti]
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) sc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[tj][st], bq[ti][st], sc[tj][ti], 0, 0, 0);
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[tj][ti][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 16; ++st)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) sc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[tj][st], bq[ti][st], sc[tj][ti], 0, 0, 0);
 
-    // ---- V operands of O = P V: step (tj, r) needs V[j(r,tj,hf)][d = c]; issued now, consumed after the softmax
-    float vf[2][16];
-    {
-        const float *vb = qbase + 2 * C + c;
-        unsigned cto[4];          // per-lane element offset of the 4 window columns this half touches
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cto[e] = (unsigned)coltok(e + 4 * hf) * (unsigned)(3 * C);
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(rowtok((r >> 2) + 4 * tj)) * (unsigned)(3 * C);   // uniform
-                vf[tj][r] = vb[ro + cto[r & 3]];
-            }
-    }
-    // ---- softmax per query row (this lane: rows i = 32*ti + c, its half of the keys)
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int i = 32 * ti + c, iy = i >> 3, ix = i & 7;
-        const int tb = (iy + 7) * 15 + ix + 7 - 4 * hf;          // bias index of key (jy, jx) is tb - 15*jy - (jx - 4*hf)
-        unsigned rowdiff = 0, coldiff = 0;                         // bit jy / bit (jx - 4*hf): key in another mask region
-        if (masked) {
-            const int ysi = wy * 8 + iy, xsi = wx * 8 + ix;
-            const int ryi = ysi < H - 8 ? 0 : (ysi < H - shift ? 1 : 2), rxi = xsi < W - 8 ? 0 : (xsi < W - shift ? 1 : 2);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int ysj = wy * 8 + q, xsj = wx * 8 + q;
-                const int ryj = ysj < H - 8 ? 0 : (ysj < H - shift ? 1 : 2), rxj = xsj < W - 8 ? 0 : (xsj < W - shift ? 1 : 2);
-                rowdiff |= (ryj != ryi ? 1u : 0u) << q;
-                coldiff |= (rxj != rxi ? 1u : 0u) << q;
-            }
-            coldiff >>= 4 * hf;
-        }
-        float m = -INFINITY;
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jy = (r >> 2) + 4 * tj, jxl = r & 3;
-                float a1 = sc[tj][ti][r] + Ts[tb - 15 * jy - jxl];
-                if (masked) a1 = a1 + ((((rowdiff >> jy) | (coldiff >> jxl)) & 1u) ? -100.0f : 0.0f);
-                sc[tj][ti][r] = a1;
-                m = a1 > m ? a1 : m;
-            }
+        // ---- V operands of O = P V: step (tj, r) needs V[j(r,tj,hf)][d = c]; issued now, consumed after the softmax
+        float vf[2][16];
         {
-            const float mo = __shfl_xor(m, 32, 64);
-            m = mo > m ? mo : m;
+            const float *vb = qbase + 2 * C + c;
+            unsigned cto[4];          // per-lane element offset of the 4 window columns this half touches
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cto[e] = (unsigned)coltok(g, e + 4 * hf) * (unsigned)(3 * C);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(rowtok(g, (r >> 2) + 4 * tj)) * (unsigned)(3 * C);   // uniform
+                    vf[tj][r] = vb[ro + cto[r & 3]];
+                }
         }
-        float part = 0.f;
+        if (u + 1 < UNITS && has[u + 1 < UNITS ? u + 1 : u]) load_qk(gs[u + 1 < UNITS ? u + 1 : u]);      // (the operand registers are free again)
+        // ---- softmax per query row (this lane: rows i = 32*ti + c, its half of the keys)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+        for (int ti = 0; ti < 2; ++ti) {
+            const int i = 32 * ti + c, iy = i >> 3, ix = i & 7;
+            const int tb = (iy + 7) * 15 + ix + 7 - 4 * hf;          // bias index of key (jy, jx) is tb - 15*jy - (jx - 4*hf)
+            unsigned rowdiff = 0, coldiff = 0;                         // bit jy / bit (jx - 4*hf): key in another mask region
+            if (masked) {
+                const int ysi = g.wy * 8 + iy, xsi = g.wx * 8 + ix;
+                const int ryi = ysi < H - 8 ? 0 : (ysi < H - shift ? 1 : 2), rxi = xsi < W - 8 ? 0 : (xsi < W - shift ? 1 : 2);
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {      // the exponential two keys at a time on the packed ALU (bit-identical per element); the sum stays one chain
-                const det_f32x2 e = det_expf2(det_f32x2{sc[tj][ti][r] - m, sc[tj][ti][r + 1] - m});
-                sc[tj][ti][r] = e[0];
-                sc[tj][ti][r + 1] = e[1];
-                part = part + e[0];
-                part = part + e[1];
+                for (int q = 0; q < 8; ++q) {
+                    const int ysj = g.wy * 8 + q, xsj = g.wx * 8 + q;
+                    const int ryj = ysj < H - 8 ? 0 : (ysj < H - shift ? 1 : 2), rxj = xsj < W - 8 ? 0 : (xsj < W - shift ? 1 : 2);
+                    rowdiff |= (ryj != ryi ? 1u : 0u) << q;
+                    coldiff |= (rxj != rxi ? 1u : 0u) << q;
+                }
+                coldiff >>= 4 * hf;
             }
-        const float other = __shfl_xor(part, 32, 64);
-        const float rinv = 1.0f / (hf ? other + part : part + other);          // half 0 + half 1; one IEEE division per row
+            float m = -INFINITY;
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) sc[tj][ti] = sc[tj][ti] * rinv;          // (vector form: v_pk_mul_f32 on register pairs)
-    }
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jy = (r >> 2) + 4 * tj, jxl = r & 3;
+                    float a1 = sc[tj][ti][r] + Ts[u][tb - 15 * jy - jxl];
+                    if (masked) a1 = a1 + ((((rowdiff >> jy) | (coldiff >> jxl)) & 1u) ? -100.0f : 0.0f);
+                    sc[tj][ti][r] = a1;
+                    m = a1 > m ? a1 : m;
+                }
+            {
+                const float mo = __shfl_xor(m, 32, 64);
+                m = mo > m ? mo : m;
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {      // the exponential two keys at a time on the packed ALU (bit-identical per element); the sum stays one chain
+                    const det_f32x2 e = det_expf2(det_f32x2{sc[tj][ti][r] - m, sc[tj][ti][r + 1] - m});
+                    sc[tj][ti][r] = e[0];
+                    sc[tj][ti][r + 1] = e[1];
+                    part = part + e[0];
+                    part = part + e[1];
+                }
+            const float other = __shfl_xor(part, 32, 64);
+            const float rinv = 1.0f / (hf ? other + part : part + other);          // half 0 + half 1; one IEEE division per row
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) sc[tj][ti] = sc[tj][ti] * rinv;          // (vector form: v_pk_mul_f32 on register pairs)
+        }
 
-    // ---- O = P V: A = probabilities (accumulator registers of S^T), B = V
-    att_f32x16 oc[2];
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oc[ti][r] = 0.f;
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) oc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[tj][ti][r], vf[tj][r], oc[ti], 0, 0, 0);
-
-    // ---- store: oc[ti][r] = O[i = 32*ti + (r&3) + 8(r>>2) + 4*hf][d = c]
-    {
-        float *ob = obase + c;
-        unsigned cto[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cto[e] = (unsigned)coltok(e + 4 * hf) * (unsigned)C;
+        // ---- O = P V: A = probabilities (accumulator registers of S^T), B = V
+        att_f32x16 oc[2];
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(rowtok((r >> 2) + 4 * ti)) * (unsigned)C;
-                ob[ro + cto[r & 3]] = oc[ti][r];
-            }
+            for (int r = 0; r < 16; ++r) oc[ti][r] = 0.f;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) oc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[tj][ti][r], vf[tj][r], oc[ti], 0, 0, 0);
+
+        // ---- store: oc[ti][r] = O[i = 32*ti + (r&3) + 8(r>>2) + 4*hf][d = c]
+        {
+            float *ob = obase + c;
+            unsigned cto[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cto[e] = (unsigned)coltok(g, e + 4 * hf) * (unsigned)C;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(rowtok(g, (r >> 2) + 4 * ti)) * (unsigned)C;
+                    ob[ro + cto[r & 3]] = oc[ti][r];
+                }
+        }
     }
 }
 
@@ -855,9 +880,15 @@ int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W,
     FEMASR_REQUIRE(heads > 0 && heads <= 8 && C == heads * ATT_HD, "window_attention: head_dim must be 32, at most 8 heads (C=%d heads=%d)", C, heads);
     FEMASR_REQUIRE(shift >= 0 && shift < 8, "window_attention: bad shift %d", shift);
     FEMASR_REQUIRE((size_t)H * W * 3 * C < ((size_t)1 << 30), "window_attention: image too large for 32-bit offsets");
-    const unsigned grid = (unsigned)((size_t)B * (H / 8) * (W / 8) * heads);
-    hipLaunchKernelGGL(window_attention_reg_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads, shift, table,
-                       out);
+    const size_t total = (size_t)B * (H / 8) * (W / 8) * heads;
+    FEMASR_REQUIRE(total < ((size_t)1 << 31), "window_attention: too many (window, head) units");
+    static const int units = [] { const char *e = getenv("FEMASR_ATT_UNITS"); return (e && atoi(e) == 1) ? 1 : 2; }();      // (A/B switch; same bits)
+    if (units == 2)
+        hipLaunchKernelGGL(window_attention_reg_kernel<2>, dim3((unsigned)((total + 1) / 2)), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads,
+                           shift, table, out, (int)total);
+    else
+        hipLaunchKernelGGL(window_attention_reg_kernel<1>, dim3((unsigned)total), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads, shift, table,
+                           out, (int)total);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }
