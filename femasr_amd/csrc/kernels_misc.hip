@@ -326,7 +326,8 @@ typedef float att_f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------
 // UNITS = (window, head) units a wave works through (consecutive unit numbers: the same window, the next head).  With 2 the Q / K rows of the
 // second unit are requested as soon as the first unit's S^T MFMAs have consumed their registers - in flight under its softmax and P V -
-// and half as many waves are launched.  Every unit is computed by the same instruction sequence either way: bit-identical.
+// and half as many waves are launched.  Every unit is computed by the same instruction sequence either way: bit-identical.  Measured in
+// round 4: 2 is 4-5 % slower than 1 (the launcher's comment); 1 is the default.
 template <int UNITS>
 __global__ __launch_bounds__(64, 2) void window_attention_reg_kernel(const float *__restrict__ qkv, int B, int H, int W, int C,
                                                                      int heads, int shift, const float *__restrict__ table,
@@ -882,7 +883,9 @@ int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W,
     FEMASR_REQUIRE((size_t)H * W * 3 * C < ((size_t)1 << 30), "window_attention: image too large for 32-bit offsets");
     const size_t total = (size_t)B * (H / 8) * (W / 8) * heads;
     FEMASR_REQUIRE(total < ((size_t)1 << 31), "window_attention: too many (window, head) units");
-    static const int units = [] { const char *e = getenv("FEMASR_ATT_UNITS"); return (e && atoi(e) == 1) ? 1 : 2; }();      // (A/B switch; same bits)
+    // one unit per wave is the default: two (FEMASR_ATT_UNITS=2: half the waves, the second unit's Q / K rows in flight under the first one's
+    // softmax, 256 registers) measured 4-5 % SLOWER - 133 against 127 us at B = 16 (profiles/r04_p_attention_units.txt); same bits
+    static const int units = [] { const char *e = getenv("FEMASR_ATT_UNITS"); return (e && atoi(e) == 2) ? 2 : 1; }();
     if (units == 2)
         hipLaunchKernelGGL(window_attention_reg_kernel<2>, dim3((unsigned)((total + 1) / 2)), dim3(64), 0, (hipStream_t)stream, qkv, B, H, W, C, heads,
                            shift, table, out, (int)total);
