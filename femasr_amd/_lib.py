@@ -38,10 +38,11 @@ class ConvArgs(ctypes.Structure):
         ('act', ctypes.c_int32),
         ('res1', vp), ('res2', vp), ('out', vp),
         ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32),
-        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp), ('w_wino', vp), ('fast_act', ctypes.c_int32), ('in_add', vp),
+        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp), ('w_wino', vp), ('fast_act', ctypes.c_int32), ('in_add', vp), ('w_bf16s', vp),
     ]
 
 
+ABI_VERSION = 101      # femasr_version(): femasr_conv_args ends with w_bf16s
 PRO_NONE, PRO_GN_SILU, PRO_LN = 0, 1, 2
 ACT_NONE, ACT_GELU = 0, 1
 
@@ -100,6 +101,10 @@ SIGNATURES = {
     'femasr_packed_weight_bf16x3_bytes': (szt, [c_int, c_int, c_int, c_int]),
     'femasr_repack_oihw_bf16x3': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'femasr_set_decoder_math': (c_int, [vp, c_int]),
+    'femasr_set_linear_math': (c_int, [vp, c_int]),
+    'femasr_packed_weight_bf16s_bytes': (szt, [c_int, c_int]),
+    'femasr_repack_k1_bf16s': (c_int, [vp, vp, c_int, c_int, vp]),
+    'femasr_debug_mfma_bf16': (c_int, [vp, vp, vp, vp, c_int, vp]),
     'femasr_image_u8_to_f32': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_image_f32_to_u8': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_clock_probe': (c_int, [vp, c_int, vp]),
@@ -124,6 +129,10 @@ def load():
             f'{SO_PATH} not found: the HIP extension is not built. Run `python femasr_amd/csrc/build.py` '
             '(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback.')
     lib = ctypes.CDLL(SO_PATH)
+    lib.femasr_version.restype = c_int
+    if lib.femasr_version() != ABI_VERSION:
+        raise FemasrError(f'{SO_PATH} reports ABI version {lib.femasr_version()}, this binding is written for {ABI_VERSION} '
+                          '(femasr_conv_args layout): rebuild with `python femasr_amd/csrc/build.py --force`')
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported
         fn.restype = res

@@ -193,6 +193,11 @@ class FeMaSRNet(nn.Module):
         # 'fp32_direct': every conv in the direct form - bit-identical to OracleNet(winograd=False)
         # 'bf16x3': the convs behind the lookup on the bf16 matrix cores with a 3-term hi/lo split (within the 1e-3 bound)
         self.decoder_math = ignore_kwargs.get('decoder_math', 'fp32')       # (an extension key of this build in `network_g`)
+        # arithmetic of the 1x1 convs / nn.Linear layers (Swin qkv / proj / fc1 / fc2, before_quant):
+        # 'bf16_split' (default): fp32-grade product on the bf16 matrix pipe - operands split exactly into three bf16 terms, six partial
+        #   products, fp32 accumulation; ~3x closer to fp64 than the fp32 chain, bit-identical to OracleNet() (csrc/kernels_gemm_bf16.hip)
+        # 'fp32': one fp32 fmaf chain per output on the fp32 MFMA - bit-identical to OracleNet(linear_math='fp32')
+        self.linear_math = ignore_kwargs.get('linear_math', 'bf16_split')
         # True: each (shape, mode) class is captured once into a hipGraph (torch.cuda.CUDAGraph around femasr_forward, which
         # is capture-safe: no allocation / synchronisation inside) and replayed; inputs are copied into the graph's static
         # buffer and the outputs are copies of its static outputs.  Only pays when the ~330 launches are host-bound (tiny
@@ -268,12 +273,15 @@ class FeMaSRNet(nn.Module):
                 _lib.check(lib.femasr_finalize_weights(self._handle))
             self._version_sum = self._param_stamp()
             self._weights_dirty = False
-        if self._streams_set != (self._handle.value, self.num_streams, self.decoder_math):
+        if self._streams_set != (self._handle.value, self.num_streams, self.decoder_math, self.linear_math):
             if self.decoder_math not in ('fp32', 'bf16x3', 'fp32_direct', 'fp32_strict'):
                 raise ValueError(f"decoder_math must be 'fp32', 'fp32_strict', 'fp32_direct' or 'bf16x3', got {self.decoder_math!r}")
+            if self.linear_math not in ('fp32', 'bf16_split'):
+                raise ValueError(f"linear_math must be 'bf16_split' or 'fp32', got {self.linear_math!r}")
+            _lib.check(lib.femasr_set_linear_math(self._handle, {'fp32': 0, 'bf16_split': 1}[self.linear_math]))
             _lib.check(lib.femasr_set_streams(self._handle, int(self.num_streams)))
             _lib.check(lib.femasr_set_decoder_math(self._handle, {'fp32': 0, 'bf16x3': 1, 'fp32_direct': 2, 'fp32_strict': 3}[self.decoder_math]))
-            self._streams_set = (self._handle.value, self.num_streams, self.decoder_math)
+            self._streams_set = (self._handle.value, self.num_streams, self.decoder_math, self.linear_math)
         return lib, self._handle
 
     def _param_stamp(self):
@@ -348,7 +356,7 @@ class FeMaSRNet(nn.Module):
                                              ctypes.byref(qh), ctypes.byref(qw)))
         sizes = [b * qh[k] * qw[k] for k in range(nq.value)]
         if self.use_graph:
-            key = (b, hh, ww, pad_mode, self.num_streams, self.decoder_math, x.device.index)
+            key = (b, hh, ww, pad_mode, self.num_streams, self.decoder_math, self.linear_math, x.device.index)
             ent = self._graphs.get(key)
             if ent is None:
                 if len(self._graphs) > 8:

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['kernels_conv.hip', 'kernels_gemm.hip', 'kernels_mlp.hip', 'kernels_vq.hip', 'kernels_wino.hip', 'kernels_wino_c128.hip', 'kernels_wino_up2.hip', 'kernels_conv_bf16.hip', 'kernels_misc.hip', 'model.hip']
+SOURCES = ['kernels_conv.hip', 'kernels_gemm.hip', 'kernels_gemm_bf16.hip', 'kernels_mlp.hip', 'kernels_vq.hip', 'kernels_wino.hip', 'kernels_wino_c128.hip', 'kernels_wino_up2.hip', 'kernels_conv_bf16.hip', 'kernels_misc.hip', 'model.hip']
 HEADERS = ['common.h', 'conv_common.h', 'wino_common.h', 'detmath.h', '../../include/femasr_hip.h']
 SO = os.path.join(HERE, 'libfemasr_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',

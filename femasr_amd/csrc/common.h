@@ -51,6 +51,12 @@ int femasr_gemm_variant_count();
 const char *femasr_gemm_variant_name(int v);
 int femasr_repack_k1(hipStream_t s, const float *in, int O, int I, float *out);
 
+// 1x1 convs / nn.Linear as an fp32-grade product on the bf16 matrix pipe (kernels_gemm_bf16.hip)
+bool femasr_gemm_bf16s_shape_ok(const femasr_conv_args *a);
+int femasr_gemm_bf16s_launch(hipStream_t s, const femasr_conv_args *a, const void *w_bf16s, int *variant_out, double *flops_out);
+int femasr_gemm_bf16s_variant_count();
+const char *femasr_gemm_bf16s_variant_name(int v);
+
 // the Swin MLP in one kernel (kernels_mlp.hip): fc1 + exact GELU + fc2 + residual, hidden activation on chip
 bool femasr_mlp_fused_shape_ok(int C, int hidden);
 int femasr_mlp_fused_launch(hipStream_t s, const float *x, long long M, const float *w1p, const float *b1, const float *w2p, const float *b2,

@@ -1039,7 +1039,12 @@ int femasr_clock_probe(void *stream, int mfmas_per_wave, unsigned long long *tic
 
 int femasr_conv2d(void *stream, const femasr_conv_args *a)
 {
-    FEMASR_REQUIRE(!a || !a->in_add || (a->w_wino && a->up2), "conv2d: in_add is only taken by the x2 Winograd-type form (up2 = 1 with w_wino)");
+    FEMASR_REQUIRE(!a || !a->in_add || (a->w_wino && a->up2 && !a->w_bf16x3 && !a->w_bf16s),
+                   "conv2d: in_add is only taken by the x2 Winograd-type form (up2 = 1 with w_wino, no w_bf16x3 / w_bf16s)");
+    if (a && a->w_bf16s) {
+        FEMASR_REQUIRE(femasr_gemm_bf16s_shape_ok(a), "conv2d: w_bf16s given but the layer is not a 1x1 stride-1 layer with Cin %% 64 == 0 and no prologue");
+        return femasr_gemm_bf16s_launch((hipStream_t)stream, a, a->w_bf16s, nullptr, nullptr);
+    }
     if (a && a->w_bf16x3) {
         FEMASR_REQUIRE(femasr_conv_bf16x3_eligible(a), "conv2d: w_bf16x3 given but the layer is not eligible for the bf16x3 path");
         return femasr_conv_bf16x3_launch((hipStream_t)stream, a, nullptr, nullptr);

@@ -80,6 +80,7 @@ struct WSpec {
     int ndim;
     float *dev = nullptr;   // repacked, owned
     void *split = nullptr;  // bf16x3 hi/lo fragments (decoder-side 3x3 convs only), owned
+    void *lin3 = nullptr;   // three bf16 planes of a 1x1 / linear weight (femasr_repack_k1_bf16s), owned
     float *up2w = nullptr;  // phase matrices of a nearest-x2 conv (femasr_repack_oihw_up2), owned
     float *wino = nullptr;  // Winograd-domain weights (decoder-side 3x3 convs of single-codebook networks), owned
     bool wino_c128 = false; // ... packed in the layout of the 16x16-pixel x 128-channel block shape (femasr_debug_wino_form at pack time)
@@ -166,6 +167,7 @@ struct femasr_handle {
     // sub-batch streams (femasr_set_streams): independent samples run on separate streams so that
     // one sub-batch's kernels fill the tail / HBM-bound phases of the other's
     int decoder_math = 0;   // femasr_set_decoder_math
+    int linear_math = 1;    // femasr_set_linear_math: 1 = fp32-grade product on the bf16 matrix pipe, 0 = fp32 MFMA chain
     int nsub = 1;
     std::vector<hipStream_t> sub_streams;
     std::vector<hipEvent_t> sub_done;
@@ -420,7 +422,15 @@ struct Ctx {
             rc = femasr_set_error(FEMASR_ERR_WEIGHT, "conv %s: planned in the Winograd form but its weights were not packed for it", prefix.c_str());
             return y;
         }
-        if (lowp_on) {
+        const void *lin3 = nullptr;
+        if (h->linear_math == 1 && femasr_gemm_bf16s_shape_ok(&a)) {
+            auto it = h->index.find(prefix + ".weight");
+            if (it != h->index.end()) lin3 = h->specs[it->second].lin3;
+        }
+        if (lin3) {
+            r = femasr_gemm_bf16s_launch(s(), &a, lin3, &variant, &flops);
+            variant += femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count() + femasr_conv_wino_variant_count() + 1;
+        } else if (lowp_on) {
             a.w_bf16x3 = split;
             r = femasr_conv_bf16x3_launch(s(), &a, &variant, &flops);
             variant += femasr_conv_variant_count();
@@ -826,7 +836,7 @@ int check_ready(const femasr_handle *h)
 extern "C" {
 
 const char *femasr_last_error(void) { return g_err; }
-int femasr_version(void) { return 100; }
+int femasr_version(void) { return 101; }
 
 int femasr_create(const femasr_config *cfg, femasr_handle **out)
 {
@@ -855,13 +865,15 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
     if (!guard.ok) { delete h; return femasr_set_error(FEMASR_ERR_HIP, "hipSetDevice(%d) failed", cfg->device); }
     const int rc = build_specs(h);
     if (rc) { delete h; return rc; }
-    const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count() + femasr_conv_wino_variant_count() + 1;
+    const int nslots = SLOT_SMALL_COUNT + femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count() + femasr_conv_wino_variant_count() + 1 +
+                       femasr_gemm_bf16s_variant_count();
     h->acc_ms.assign(nslots, 0.0); h->acc_flops.assign(nslots, 0.0); h->acc_bytes.assign(nslots, 0.0); h->acc_n.assign(nslots, 0);
     for (int i = 0; i < SLOT_SMALL_COUNT; ++i) h->slot_names.push_back(kSmallNames[i]);
     for (int i = 0; i < femasr_conv_variant_count(); ++i) h->slot_names.push_back(femasr_conv_variant_name(i));
     for (int i = 0; i < femasr_conv_bf16x3_variant_count(); ++i) h->slot_names.push_back(femasr_conv_bf16x3_variant_name(i));
     for (int i = 0; i < femasr_conv_wino_variant_count(); ++i) h->slot_names.push_back(femasr_conv_wino_variant_name(i));
     h->slot_names.push_back(femasr_conv_wino_up2_variant_name());
+    for (int i = 0; i < femasr_gemm_bf16s_variant_count(); ++i) h->slot_names.push_back(femasr_gemm_bf16s_variant_name(i));
     *out = h;
     return FEMASR_OK;
 }
@@ -869,7 +881,7 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
 void femasr_destroy(femasr_handle *h)
 {
     if (!h) return;
-    for (auto &w : h->specs) { if (w.dev) (void)hipFree(w.dev); if (w.split) (void)hipFree(w.split); if (w.up2w) (void)hipFree(w.up2w); if (w.wino) (void)hipFree(w.wino); }
+    for (auto &w : h->specs) { if (w.dev) (void)hipFree(w.dev); if (w.split) (void)hipFree(w.split); if (w.up2w) (void)hipFree(w.up2w); if (w.wino) (void)hipFree(w.wino); if (w.lin3) (void)hipFree(w.lin3); }
     for (int q = 0; q < FEMASR_MAX_CODEBOOKS; ++q) {
         if (h->cbT[q]) (void)hipFree(h->cbT[q]);
         if (h->ee[q]) (void)hipFree(h->ee[q]);
@@ -927,6 +939,12 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
         // feed the codebook lookup either
         const std::string pre = "multiscale_encoder.blocks.";
         if (h->cfg.lq_stage && k.rfind(pre, 0) == 0 && atoi(k.c_str() + pre.size()) > h->encode_depth) dec_side = true;
+    }
+    if ((w.kind == W_LINEAR || (w.kind == W_CONV && w.shape[2] == 1 && w.shape[3] == 1)) && (w.shape[1] % 64) == 0) {
+        // 1x1 convs / nn.Linear: the three bf16 planes for the fp32-grade product on the bf16 matrix pipe (kernels_gemm_bf16.hip)
+        if (!w.lin3) FEMASR_CHECK_HIP(hipMalloc(&w.lin3, femasr_packed_weight_bf16s_bytes((int)w.shape[0], (int)w.shape[1])));
+        rc = femasr_repack_k1_bf16s(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.lin3);
+        if (rc) return rc;
     }
     if (w.kind == W_CONV && w.up2 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {
         if (!w.up2w) FEMASR_CHECK_HIP(hipMalloc((void **)&w.up2w, femasr_up2_weight_floats((int)w.shape[0], (int)w.shape[1]) * sizeof(float)));
@@ -1169,6 +1187,14 @@ int femasr_set_decoder_math(femasr_handle *h, int mode)
     FEMASR_REQUIRE(h && mode >= 0 && mode <= 3, "set_decoder_math: mode must be 0 (fp32), 1 (bf16x3), 2 (fp32, direct convs only) or 3 (fp32, exact SiLU)");
     if (h->decoder_math != mode) h->plans.clear();
     h->decoder_math = mode;
+    return FEMASR_OK;
+}
+
+int femasr_set_linear_math(femasr_handle *h, int mode)
+{
+    FEMASR_REQUIRE(h && (mode == 0 || mode == 1), "set_linear_math: mode must be 0 (fp32 MFMA chain) or 1 (bf16 three-term split)");
+    if (h->linear_math != mode) h->plans.clear();
+    h->linear_math = mode;
     return FEMASR_OK;
 }
 

@@ -59,6 +59,7 @@ typedef struct {
 } femasr_config;
 
 const char *femasr_last_error(void);
+/* 100 * major + minor.  101: femasr_conv_args ends with w_bf16s (a caller built against 100 passes a shorter struct: rebuild). */
 int femasr_version(void);
 
 /* ---- model handle ------------------------------------------------------------------ */
@@ -179,6 +180,12 @@ typedef struct {
                              element while staging).  Only the x2 Winograd-type form takes it (up2 = 1 with w_wino; anything else refuses):
                              FeMaSRNet's decoder adds the encoder's skip feature to a stage's input (`x = x + enc_feats[i]`,
                              femasr_arch.py:361-362) right in front of that stage's x2 conv, so the sum never makes a pass of its own. */
+    const void *w_bf16s;  /* optional (struct version 101): femasr_repack_k1_bf16s weights.  When non-NULL the layer - a 1x1 stride-1 conv /
+                             nn.Linear with Cin % 64 == 0, no prologue (network_swinir.py:19-21,105-107,121,143; femasr_arch.py:298) - runs on
+                             the bf16 matrix pipe as an fp32-GRADE product: both operands split exactly into three bf16 terms, the six
+                             partial products of relative size >= 2^-16 accumulated in fp32 (two accumulators), ~3x closer to the fp64
+                             result than the fp32 fmaf chain and bit-identical to oracle/femasr_oracle.c orc_linear_bf16s, which restates
+                             the instruction's accumulation arithmetic from hardware probes (kernels_gemm_bf16.hip).  `w` is not read. */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 
@@ -267,6 +274,19 @@ int femasr_repack_oihw_wino(void *stream, const float *in, int O, int I, float *
 size_t femasr_wino_up2_weight_floats(int O, int I);
 int femasr_repack_oihw_wino_up2(void *stream, const float *w_oihw, int O, int I, float *out);
 int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *out);
+
+/* (out, in) fp32 -> femasr_conv_args.w_bf16s: the three bf16 planes of every weight (w = w1 + w2 + w3 exactly), packed
+ * [Cin/16][ceil(Cout/32)][plane][lane][8 bf16] - the MFMA B fragments of one 16-channel step, 1 KiB per (column tile, plane). */
+size_t femasr_packed_weight_bf16s_bytes(int O, int I);
+int femasr_repack_k1_bf16s(void *stream, const float *w_oi, int O, int I, void *out);
+/* Arithmetic of the network's 1x1 convs / nn.Linear layers (the Swin qkv / proj / fc1 / fc2 and before_quant):
+ * 1 (default, 'bf16_split'): the fp32-grade product on the bf16 matrix pipe described at femasr_conv_args.w_bf16s;
+ * 0 ('fp32'): one fp32 fmaf chain per output on the fp32 MFMA (kernels_gemm.hip), bit-identical to OracleNet(linear_math='fp32'). */
+int femasr_set_linear_math(femasr_handle *h, int mode);
+/* Test hook behind that arithmetic: n independent v_mfma_f32_32x32x16_bf16 evaluations, case i = 16 products a[i][s] * b[i][s]
+ * (bf16 bit patterns; k slot s = 8 * (lane / 32) + element) plus the fp32 accumulator input c[i] -> d[i].  tests/test_gpu_r5.py runs
+ * constructed cases through it and compares them bit for bit with the oracle's restatement (orc_mfma_dot8). */
+int femasr_debug_mfma_bf16(void *stream, const uint16_t *a, const uint16_t *b, const float *c, int n, float *d);
 
 /* Split-bf16 (hi/lo) fragment-major weights for the opt-in bf16x3 conv path (3x3 convs behind the VQ lookup). */
 size_t femasr_packed_weight_bf16x3_bytes(int O, int I, int kh, int kw);

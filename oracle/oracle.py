@@ -38,6 +38,9 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 def lib():
     global _lib
     if _lib is None:
+        # libgomp reads OMP_NUM_THREADS when it is loaded: one thread per PHYSICAL core unless the caller chose (on SMT hosts
+        # - this dev container, the GPU box - the default of one thread per logical CPU runs the integer-heavy loops slower)
+        os.environ.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 2) // 2)))
         build()
         L = ctypes.CDLL(_SO)
         i, i64, f, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -53,10 +56,15 @@ def lib():
         L.orc_codebook_gather.argtypes = [vp, i64, i, vp, vp]
         L.orc_conv3x3_winograd.argtypes = [vp, i, i, i, i, vp, vp, i, vp, vp, vp]
         L.orc_conv_up2_winograd.argtypes = [vp, i, i, i, i, vp, vp, i, vp, vp, vp]
+        L.orc_linear_bf16s.argtypes = [vp, i64, i, vp, vp, i, i, vp, vp, vp, i]
+        L.orc_mfma_dot8_v8.argtypes = [vp, vp, vp, vp]
+        L.orc_split3_eval.argtypes = [vp, i64, vp, vp, vp]
+        L.orc_mfma_dot8.argtypes = [f, vp, vp]
         for fn in ('orc_math_eval', 'orc_pad_nchw_to_nhwc', 'orc_crop_nhwc_to_nchw', 'orc_conv2d', 'orc_conv3x3_winograd', 'orc_conv_up2_winograd',
                    'orc_gn_coeffs', 'orc_scale_shift_silu', 'orc_layernorm', 'orc_window_attention',
-                   'orc_vq', 'orc_codebook_gather'):
+                   'orc_vq', 'orc_codebook_gather', 'orc_linear_bf16s', 'orc_split3_eval', 'orc_mfma_dot8_v8'):
             getattr(L, fn).restype = None
+        L.orc_mfma_dot8.restype = f
         _lib = L
     return _lib
 
@@ -162,10 +170,58 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, act=0, res1=None, r
     return out
 
 
-def linear(x_tokens, w_io, bias, act=0, res=None):
-    """x: (..., Cin) -> (..., Cout); w_io is [in][out]."""
+def split_ok(cin, ksz=1, stride=1, pad=0, up2=False):
+    """The 1x1 / Linear shapes csrc/kernels_gemm_bf16.hip takes in linear_math 'bf16_split' (femasr_gemm_bf16s_shape_ok)."""
+    return ksz == 1 and stride == 1 and pad == 0 and not up2 and cin % 64 == 0
+
+
+def mfma_dot8(d, a_bits, b_bits):
+    """One 8-product group of v_mfma_f32_*_bf16 (orc_mfma_dot8): a, b = 8 bf16 bit patterns (uint16), d = the accumulator."""
+    a = np.ascontiguousarray(a_bits, np.uint16)
+    b = np.ascontiguousarray(b_bits, np.uint16)
+    assert a.size == 8 and b.size == 8
+    return np.float32(lib().orc_mfma_dot8(np.float32(d), _p(a), _p(b)))
+
+
+def split3(x):
+    """x = x1 + x2 + x3, three bf16 values (orc_split3): returns the three uint16 bit-pattern arrays."""
+    x = _c(x)
+    p = [np.empty(x.shape, np.uint16) for _ in range(3)]
+    lib().orc_split3_eval(_p(x), x.size, _p(p[0]), _p(p[1]), _p(p[2]))
+    return p
+
+
+def mfma_dot8_v8(d8, a_bits, b_bits_kmajor):
+    """The 8-column AVX2 form of mfma_dot8 (orc_dot8_v8): d8 (8,), a (8,) shared by the lanes, b (8 k, 8 lanes)."""
+    d = _c(d8).reshape(8)
+    a = np.ascontiguousarray(a_bits, np.uint16).reshape(8)
+    b = np.ascontiguousarray(b_bits_kmajor, np.uint16).reshape(8, 8)
+    out = np.empty(8, np.float32)
+    lib().orc_mfma_dot8_v8(_p(d), _p(a), _p(b), _p(out))
+    return out
+
+
+def linear_bf16s(x_rows, w_oi, bias, act=0, res1=None, res2=None, scalar=False):
+    """The 1x1 / Linear layers in the split-bf16 arithmetic (orc_linear_bf16s): x (rows, Cin), w_oi (Cout, Cin) = torch's layout."""
+    x = _c(x_rows)
+    rows, cin = x.shape
+    w = _c(w_oi)
+    cout = w.shape[0]
+    assert w.shape[1] == cin and cin % 16 == 0
+    out = np.empty((rows, cout), np.float32)
+    res1 = None if res1 is None else _c(res1).reshape(rows, cout)
+    res2 = None if res2 is None else _c(res2).reshape(rows, cout)
+    lib().orc_linear_bf16s(_p(x), rows, cin, _p(w), _p(_c(bias)), cout, act, _p(res1), _p(res2), _p(out), int(scalar))
+    return out
+
+
+def linear(x_tokens, w_io, bias, act=0, res=None, split=False):
+    """x: (..., Cin) -> (..., Cout); w_io is [in][out].  split: the bf16-pipe arithmetic (linear_bf16s) where the shape allows."""
     shp = x_tokens.shape
     rows = int(np.prod(shp[:-1]))
+    if split and split_ok(shp[-1]):
+        y = linear_bf16s(_c(x_tokens).reshape(rows, shp[-1]), _c(np.asarray(w_io).reshape(shp[-1], -1).T), bias, act, res)
+        return y.reshape(shp[:-1] + (y.shape[-1],))
     y = conv2d(_c(x_tokens).reshape(1, rows, 1, shp[-1]), w_io, bias, 1, act=act,
                res1=None if res is None else _c(res).reshape(1, rows, 1, -1))
     return y.reshape(shp[:-1] + (w_io.shape[-1],))
@@ -268,8 +324,12 @@ class OracleNet:
     """Reference forward restated on the C ops.  `sd` = {key: ndarray} with the reference key names."""
 
     def __init__(self, sd, codebook_params=((32, 1024, 512),), gt_resolution=256, LQ_stage=False,
-                 scale_factor=4, use_quantize=True, use_residual=True, winograd=True):
+                 scale_factor=4, use_quantize=True, use_residual=True, winograd=True, linear_math='bf16_split'):
         self.sd = {k: np.asarray(v) for k, v in sd.items()}
+        # arithmetic of the 1x1 / Linear layers: 'bf16_split' (the kernels' default since round 5: kernels_gemm_bf16.hip) or
+        # 'fp32' (one fmaf chain per output on the fp32 MFMA: kernels_gemm.hip)
+        assert linear_math in ('fp32', 'bf16_split')
+        self.lin_split = linear_math == 'bf16_split'
         # the kernels' default exact-fp32 mode: 3x3 convs behind the codebook lookup of a single-codebook network run in
         # the Winograd F(4x4,3x3) form (model.hip Ctx::conv `wino`); winograd=False = decoder_math 'fp32_direct'
         self.wino = bool(winograd) and len(codebook_params) == 1
@@ -336,15 +396,15 @@ class OracleNet:
         c = x.shape[-1]
         t = layernorm(x, self.sd[prefix + '.norm1.weight'], self.sd[prefix + '.norm1.bias'])
         wq, bq = self._lin_w(prefix + '.attn.qkv')
-        qkv = linear(t, wq, bq)
+        qkv = linear(t, wq, bq, split=self.lin_split)
         att = window_attention(qkv, b, h, w, c, 8, shift, self.sd[prefix + '.attn.relative_position_bias_table'])
         wp, bp = self._lin_w(prefix + '.attn.proj')
-        x = linear(att, wp, bp, res=x)
+        x = linear(att, wp, bp, res=x, split=self.lin_split)
         t = layernorm(x, self.sd[prefix + '.norm2.weight'], self.sd[prefix + '.norm2.bias'])
         w1, b1 = self._lin_w(prefix + '.mlp.fc1')
-        hdn = linear(t, w1, b1, act=1)
+        hdn = linear(t, w1, b1, act=1, split=self.lin_split)
         w2, b2 = self._lin_w(prefix + '.mlp.fc2')
-        return linear(hdn, w2, b2, res=x)
+        return linear(hdn, w2, b2, res=x, split=self.lin_split)
 
     def _swin_layers(self, x, prefix):
         # femasr_arch.py:114-132 + network_swinir.py:442-482 (tokens (B,HW,C) == NHWC)
@@ -405,7 +465,11 @@ class OracleNet:
             cur_res = self.gt_res // 2 ** self.max_depth * 2 ** i
             if cur_res in self.cb_scales:        # quantise at this scale (femasr_arch.py:332-359)
                 zin = feats[i] if prev_dec is None else np.concatenate((feats[i], prev_dec), axis=-1)
-                z = self._conv(zin, f'before_quant_group.{qi}', 1, 1, 0)
+                if self.lin_split and split_ok(zin.shape[-1]):      # 1x1 conv == Linear over the pixels
+                    wq_, bq_ = self._conv_w(f'before_quant_group.{qi}')
+                    z = linear(zin, wq_.reshape(zin.shape[-1], -1), bq_, split=True)
+                else:
+                    z = self._conv(zin, f'before_quant_group.{qi}', 1, 1, 0)
                 if qi == 0:
                     self._probe('z', z)
                 b, h, w, d = z.shape

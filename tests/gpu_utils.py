@@ -41,10 +41,16 @@ def lib_weight_layout(w_khwc):
 
 
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
-           res1=None, res2=None, bf16x3=False, gn_part=False, wino=False, fast_act=False, in_add=None):
-    """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout)."""
+           res1=None, res2=None, bf16x3=False, gn_part=False, wino=False, fast_act=False, in_add=None, bf16s=False):
+    """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout).
+    bf16s: the 1x1 / Linear layer on the bf16 matrix pipe (femasr_conv_args.w_bf16s, three-term split)."""
     lib = _lib.load()
     cout = np.asarray(w_khwc).shape[-1]
+    wlin3 = None
+    if bf16s:
+        w_oi = dev(np.ascontiguousarray(np.asarray(w_khwc).reshape(-1, cout).T))
+        wlin3 = torch.empty(int(lib.femasr_packed_weight_bf16s_bytes(cout, w_oi.shape[1])), dtype=torch.uint8, device='cuda')
+        _lib.check(lib.femasr_repack_k1_bf16s(None, _lib.ptr(w_oi), cout, w_oi.shape[1], _lib.ptr(wlin3)))
     wsplit = None
     if bf16x3:      # opt-in split-bf16 path: weights repacked on the GPU from OIHW
         w_oihw = dev(np.ascontiguousarray(np.asarray(w_khwc).transpose(3, 2, 0, 1)))
@@ -89,6 +95,7 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     a.w_up2 = None if wup2 is None else wup2.data_ptr()
     a.w_wino = None if wwino is None else wwino.data_ptr()
     a.fast_act = int(bool(fast_act))
+    a.w_bf16s = None if wlin3 is None else wlin3.data_ptr()
     tadd = None if in_add is None else dev(in_add)
     a.in_add = None if tadd is None else tadd.data_ptr()
     part = None
@@ -204,7 +211,7 @@ def vq_candidates(z_rows, codebook):
     return cand.cpu().numpy().view('uint16'), cnt.cpu().numpy().view('uint16')
 
 
-def build_net(cfg_name, weights, device='cuda', decoder_math='fp32_strict'):
+def build_net(cfg_name, weights, device='cuda', decoder_math='fp32_strict', linear_math='bf16_split'):
     """decoder_math defaults to 'fp32_strict' HERE (the tests' bit-exact comparisons with the oracle): the product default
     'fp32' runs the SiLU of the Winograd convs on the hardware exp2 / rcp units and is compared with a tolerance instead
     (test_gpu_network.py::test_default_mode_vs_oracle_and_reference)."""
@@ -214,4 +221,5 @@ def build_net(cfg_name, weights, device='cuda', decoder_math='fp32_strict'):
     missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=False)
     assert not missing.unexpected_keys
     net.decoder_math = decoder_math
+    net.linear_math = linear_math
     return net.to(device).eval()

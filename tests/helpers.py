@@ -41,10 +41,14 @@ def synth_weights(cfg_name, seed, codebook):
     return out
 
 
-def oracle_net(cfg_name, weights):
+def oracle_net(cfg_name, weights, linear_math='bf16_split'):
+    """linear_math: arithmetic of the 1x1 / Linear layers - 'bf16_split' = the product default (FeMaSRNet.linear_math),
+    'fp32' = the fp32 fmaf chain (FeMaSRNet(linear_math='fp32')); the CPU-only golden tests run their large cases in 'fp32'
+    (the restated matrix-instruction arithmetic costs ~30x the fmaf chain on a CPU)."""
     from oracle import oracle as orc
     cfg = CONFIGS[cfg_name] if isinstance(cfg_name, str) else cfg_name
-    return orc.OracleNet(weights, codebook_params=cfg['codebook_params'], LQ_stage=cfg['LQ_stage'], scale_factor=cfg.get('scale_factor', 4))
+    return orc.OracleNet(weights, codebook_params=cfg['codebook_params'], LQ_stage=cfg['LQ_stage'], scale_factor=cfg.get('scale_factor', 4),
+                         linear_math=linear_math)
 
 
 def golden_cfg(g):

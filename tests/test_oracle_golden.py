@@ -12,17 +12,19 @@ from helpers import (cfg_name_of, check_indices_near_tie, load_golden, oracle_ne
 TOL = 1e-3
 
 
-def _run(name):
+def _run(name, linear_math='bf16_split'):
     g = load_golden(name)
     cn = cfg_name_of(g)
-    net = oracle_net(cn, synth_weights(cn, int(g['seed']), str(g['codebook'])))
+    net = oracle_net(cn, synth_weights(cn, int(g['seed']), str(g['codebook'])), linear_math)
     x = synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))
     return g, net, x
 
 
+@pytest.mark.parametrize('linear_math', ['bf16_split', 'fp32'])
 @pytest.mark.parametrize('name', ['x4_small_init', 'x4_small_trained', 'x2_small_trained'])
-def test_test_path_matches_reference(name):
-    g, net, x = _run(name)
+def test_test_path_matches_reference(name, linear_math):
+    """Both arithmetics of the 1x1 / Linear layers against the reference: the product default and the fp32 chain."""
+    g, net, x = _run(name, linear_math)
     net.probes = {}
     y, idx = net.test(x, return_indices=True)
     assert y.shape == tuple(g['out_shape'])
@@ -44,7 +46,7 @@ def test_hq_forward_matches_reference():
 
 
 def test_test_tile_matches_reference():
-    g, net, x = _run('x4_tiled_trained')
+    g, net, x = _run('x4_tiled_trained', 'fp32')
     y = net.test_tile(x, int(g['kw_tile_size']), int(g['kw_tile_pad']))
     assert y.shape == tuple(g['out_shape'])
     assert np.abs(y - g['output']).max() < TOL
@@ -59,7 +61,7 @@ def test_decode_indices_matches_reference():
 
 def test_full_tile_128_matches_reference():
     """One full-size x4 tile (128x128 -> 512x512, 964 GFLOP): ~12 s of CPU."""
-    g, net, x = _run('x4_tile128_trained')
+    g, net, x = _run('x4_tile128_trained', 'fp32')        # (the GPU suite checks the default arithmetic on this tile: tests/test_gpu_network.py)
     y, idx = net.test(x, return_indices=True)
     st = int(g['out_stride'])
     assert np.abs(y[:, :, ::st, ::st] - g['output']).max() < TOL
@@ -74,11 +76,11 @@ def test_direct_form_oracle_matches_reference(name):
     same reference goldens, and the two restatements against each other: identical VQ indices, outputs within fp32 rounding."""
     from oracle import oracle as orc
     from helpers import CONFIGS
-    g, net, x = _run(name)
+    g, net, x = _run(name, 'fp32')
     cn = cfg_name_of(g)
     cfg = CONFIGS[cn]
     direct = orc.OracleNet(synth_weights(cn, int(g['seed']), str(g['codebook'])), codebook_params=cfg['codebook_params'],
-                           LQ_stage=cfg['LQ_stage'], scale_factor=cfg.get('scale_factor', 4), winograd=False)
+                           LQ_stage=cfg['LQ_stage'], scale_factor=cfg.get('scale_factor', 4), winograd=False, linear_math='fp32')
     yd, idd = direct.test(x, return_indices=True)
     yw, idw = net.test(x, return_indices=True)
     assert np.abs(yd - g['output']).max() < TOL

@@ -39,10 +39,11 @@ def check_all_indices(idx_maps, g):
     return bad, acc
 
 
+@pytest.mark.parametrize('linear_math', ['bf16_split', 'fp32'])
 @pytest.mark.parametrize('name', NET_CASES)
-def test_oracle_matches_reference(name):
+def test_oracle_matches_reference(name, linear_math):
     g, cfg, w, x = _setup(name)
-    net = oracle_net(cfg, w)
+    net = oracle_net(cfg, w, linear_math)
     y, idx = net.test(x, return_indices=True) if str(g['mode']) == 'test' else net.forward(x)
     assert y.shape == g['output'].shape
     bad, acc = check_all_indices(_idx_maps(idx), g)
@@ -77,7 +78,7 @@ def test_cli_arithmetic_on_testset_png(name):
     w = weights_from_arch(cfg, int(g['seed']), 'trained')
     rgb = np.asarray(Image.open(io.BytesIO(g['png'].tobytes())).convert('RGB'))
     x = orc.image_u8_to_f32(rgb)
-    y, idx = oracle_net(cfg, w).test(x, return_indices=True)
+    y, idx = oracle_net(cfg, w, 'fp32' if name == 'png_comic1' else 'bf16_split').test(x, return_indices=True)
     assert np.abs(y[:, :, ::4, ::4] - g['output_f32_stride4']).max() < TOL
     bad, _ = check_indices_near_tie(idx, g)
     assert bad == 0
