@@ -44,6 +44,7 @@ def test_tiled_testset_image_first_tile_matches_reference():
     from PIL import Image
     from oracle import oracle as orc
     from helpers import weights_from_arch
+    from oracle.near_tie import NEAR_TIE_ULP
     g = load_golden('png_OST_120_tiled')
     cfg = dict(codebook_params=[[32, 1024, 512]], LQ_stage=True, scale_factor=4)
     net = oracle_net(cfg, weights_from_arch(cfg, int(g['seed']), 'trained'), 'fp32')
@@ -60,7 +61,7 @@ def test_tiled_testset_image_first_tile_matches_reference():
     mask = np.zeros((keep, keep), bool)
     for r in np.nonzero(got != ref)[0]:
         gp = near.get(int(r), {}).get(int(got[r]), 1e9)
-        assert gp <= 4.0, f'token {r}: index {got[r]} vs reference {ref[r]}: {gp} ulp apart in the reference, not a near tie'
+        assert gp <= NEAR_TIE_ULP, f'token {r}: index {got[r]} vs reference {ref[r]}: {gp} ulp apart in the reference, not a near tie'
         cy, cx = 8 * (int(r) // hw[1]), 8 * (int(r) % hw[1])
         mask[max(cy - 128, 0):cy + 136, max(cx - 128, 0):cx + 136] = True
     assert mask.mean() < 0.10
