@@ -447,7 +447,7 @@ class FeMaSRNet(nn.Module):
         s = self.scale_factor
         tiles = tiling.enumerate_tiles(height, width, tile_size, tile_pad)
         classes = tiling.shape_classes(tiles)
-        mine = tiling.partition(classes, rank, world_size)
+        mine = tiling.partition(classes, rank, world_size, s)
         # `time_split = True`: record where the call's time goes (events on the current stream; read back in `last_split_ms`
         # = {'compute', 'gather', 'paste', 'tiles_owned'} after a synchronize) - bench.py --workload tile2048 reports it per rank
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (getattr(self, 'time_split', False) and input.is_cuda) else None
@@ -488,7 +488,7 @@ class FeMaSRNet(nn.Module):
             return None
         output = input.new_zeros((batch, channel, height * s, width * s))
         for r, res in enumerate(per_rank):
-            owned = tiling.partition(classes, r, world_size)
+            owned = tiling.partition(classes, r, world_size, s)
             for hw, tl in owned.items():
                 if tl:
                     self._paste_tiles(output, res[hw], tl, batch, s)

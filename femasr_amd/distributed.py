@@ -60,7 +60,7 @@ class TileGather:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.classes, self.batch, self.channel, self.scale = classes, batch, channel, scale
-        self.owned = [tiling.partition(classes, r, self.world) for r in range(self.world)]
+        self.owned = tiling.assign(classes, self.world, scale)
         self.sizes = [sum(_class_numel(hw, len(tl), batch, channel, scale) for hw, tl in o.items()) for o in self.owned]
         self.cap = max(max(self.sizes), 1)
         self.send = torch.empty(self.cap, dtype=dtype, device=device)
@@ -128,7 +128,10 @@ class TileExchange:
         self._tg = None
 
     def _get(self, classes, batch, channel, scale, dtype, device):
-        key = (tuple((hw, tuple(t.index for t in tl)) for hw, tl in classes.items()), batch, channel, scale, dtype, str(device))
+        # (world size and rank are part of the key: after destroy_process_group + a new init in the same process - or a freed group's
+        # id() coming back - a TileGather built for another world would hand stale sizes to the collective)
+        key = (tuple((hw, tuple(t.index for t in tl)) for hw, tl in classes.items()), batch, channel, scale, dtype, str(device),
+               dist.get_world_size(self.group), dist.get_rank(self.group))
         if key != self._key:
             self._tg = None                 # one geometry at a time keeps the footprint bounded
             self._tg = TileGather(classes, batch, channel, scale, dtype, device, self.group)
@@ -152,6 +155,15 @@ class TileExchange:
 _exchanges = {}
 
 
+def _exchange_for(group):
+    """The cached TileExchange of a process group; entries of groups that no longer exist (or whose id() was re-used for a group of
+    another size / rank) are dropped."""
+    sig = (id(group), dist.get_world_size(group), dist.get_rank(group))
+    for k in [k for k in _exchanges if k[0] == sig[0] and k != sig]:
+        del _exchanges[k]
+    return _exchanges.setdefault(sig, TileExchange(group))
+
+
 def gather_tiles(results, classes, batch, channel, scale, group=None):
     """All-gather every rank's upscaled tiles with ONE `all_gather_into_tensor` on persistent buffers (functional form of
     TileExchange; the tiles are copied into the send slab unless they already live there).
@@ -159,8 +171,7 @@ def gather_tiles(results, classes, batch, channel, scale, group=None):
     results: {(h,w): tensor (n_owned*batch, channel, h*s, w*s)} of THIS rank.
     Returns a list (one entry per rank) of dicts with the same structure (views into the receive buffer,
     valid until the next call with the same geometry)."""
-    ex = _exchanges.setdefault(id(group), TileExchange(group))
-    return ex(results, classes, batch, channel, scale)
+    return _exchange_for(group)(results, classes, batch, channel, scale)
 
 
 def test_tile_parallel(net, x, tile_size=240, tile_pad=16, group=None, root_only=False):
@@ -168,7 +179,7 @@ def test_tile_parallel(net, x, tile_size=240, tile_pad=16, group=None, root_only
     rank 0 pastes it (the others return None): one canvas write per job instead of one per rank."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return net.test_tile(x, tile_size, tile_pad)
-    ex = _exchanges.setdefault(id(group), TileExchange(group))
+    ex = _exchange_for(group)
     rank = dist.get_rank(group)
     return net.test_tile(x, tile_size, tile_pad, rank=rank, world_size=dist.get_world_size(group), gather=ex,
                          paste=(rank == 0 or not root_only))

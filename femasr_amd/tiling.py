@@ -13,7 +13,7 @@ What is new here (the reference runs tiles one at a time on one device):
 tiles are grouped by input-window shape ("shape class") so each class runs as
 ONE batched `test()` call — legal because every op in the network is
 per-sample (GroupNorm/LayerNorm/attention), verified bit-identical in
-SURVEY 8c — and each class is split in contiguous equal blocks over ranks.
+SURVEY 8c — and the tiles are spread over the ranks by work (padded pixels), longest-processing-time first (`assign`).
 """
 import math
 from collections import OrderedDict
@@ -78,13 +78,51 @@ def rank_slice(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def partition(classes: Dict[Tuple[int, int], List[Tile]], rank: int, world: int):
-    """Per-class tile lists owned by `rank`."""
-    out = OrderedDict()
-    for hw, tl in classes.items():
-        lo, hi = rank_slice(len(tl), rank, world)
-        out[hw] = tl[lo:hi]
+CALL_OVERHEAD_PX = 3 * 144 * 144 // 4      # fixed cost of one more batched test() call, in padded pixels (~0.75 of a 128x128 tile)
+
+
+def tile_cost(hw: Tuple[int, int], scale: int = 4) -> int:
+    """Work of one `test()` call on a window of this shape: the pixels it runs on after test()'s mirror pad."""
+    hp, wp = padded_hw(hw[0], hw[1], scale)
+    return hp * wp
+
+
+def assign(classes: Dict[Tuple[int, int], List[Tile]], world: int, scale: int = 4) -> List["OrderedDict[Tuple[int, int], List[Tile]]"]:
+    """Balanced ownership of all ranks: classes in order of descending per-tile cost (ties: first appearance), every tile to the
+    rank with the least work so far (ties: the lowest rank) - the longest-processing-time rule over (class, padded pixels).
+    A rank's tiles of one class are consecutive in the class's row-major list, in rank order, so they still run as batched calls
+    and paste in the reference's order.  Deterministic: every rank computes the same table.  (Round 4 split every class on its
+    own and gave each remainder to the lowest ranks: 15/10/../6 tiles at 240/16 on 8 ranks, a 5.9x bound before a byte moves.)"""
+    load = [0] * world
+    counts = {hw: [0] * world for hw in classes}
+    order = sorted(classes, key=lambda hw: -tile_cost(hw, scale))          # (stable: equal costs keep first-appearance order)
+    for hw in order:
+        c = tile_cost(hw, scale)
+        for _ in classes[hw]:
+            # a rank's FIRST tile of a class opens one more batched call: CALL_OVERHEAD_PX of latency-bound launches (measured: a
+            # 128x128 tile takes 7.7 ms alone and 4.5 ms inside a batch of 16, DESIGN.md 6) - so a class is not scattered needlessly
+            r = min(range(world), key=lambda k: (load[k] + c + (0 if counts[hw][k] else CALL_OVERHEAD_PX), k))
+            load[r] += c + (0 if counts[hw][r] else CALL_OVERHEAD_PX)
+            counts[hw][r] += 1
+    out = [OrderedDict() for _ in range(world)]
+    for hw, tl in classes.items():                                        # class order = first appearance (the reference's order)
+        lo = 0
+        for r in range(world):
+            out[r][hw] = tl[lo:lo + counts[hw][r]]
+            lo += counts[hw][r]
     return out
+
+
+def partition(classes: Dict[Tuple[int, int], List[Tile]], rank: int, world: int, scale: int = 4):
+    """Per-class tile lists owned by `rank` (see `assign`)."""
+    return assign(classes, world, scale)[rank]
+
+
+def balance_bound(classes: Dict[Tuple[int, int], List[Tile]], world: int, scale: int = 4) -> float:
+    """Total work / the busiest rank's work: the speed-up the partition allows at `world` ranks before communication."""
+    own = assign(classes, world, scale)
+    per = [sum(tile_cost(hw, scale) * len(tl) for hw, tl in o.items()) for o in own]
+    return sum(per) / max(max(per), 1)
 
 
 def padded_hw(h: int, w: int, scale: int) -> Tuple[int, int]:
