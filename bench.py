@@ -41,6 +41,16 @@ PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: bf16 MFMA dense peak (the 5 PF headline includes 2:1 sparsity)
 TILE_GFLOP = 964.47                  # algorithmic GFLOP per x4 128^2 tile (SURVEY 8d / BASELINE.md 3)
 X4_CFG = dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512]], LQ_stage=True, scale_factor=4)
+# the other single-GPU BASELINE configs as first-class workloads: same JSON schema, their own roofline and CPU sample
+WORKLOADS = {
+    'x2b32': dict(cfg=dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512]], LQ_stage=True, scale_factor=2), batch=32, hw=256, fn='test', out_hw=512,
+                  gflop=1075.05, tile='256x256->512x512', metric='SR output megapixels/sec at x2 (256->512)',
+                  text='BASELINE config 4: x2 SR FeMaSRNet.test (scale_factor=2 encoder head: 3->128 in_conv, ONE stride-2 stage), batch {B} of 256x256 LR tiles -> 512x512 '
+                       '(padded 288->576 inside)'),
+    'hq8': dict(cfg=dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512]], LQ_stage=False), batch=8, hw=512, fn='forward', out_hw=512,
+                gflop=544.21, tile='512x512->512x512', metric='autoencoded megapixels/sec (HQ pretrain stage, 512x512)',
+                text='BASELINE config 5: HQ autoencode FeMaSRNet.forward (encode -> VQ -> decode, no LR encoder / Swin stage, no pad), batch {B} of 512x512 images'),
+}
 
 
 def rocprof_kernel_name(bench_name):
@@ -97,6 +107,49 @@ def pmc_record(pmc, kname):
         return None
     return {'fetch_bytes_corrected': sum(r['fetch_bytes_corrected'] * r['launches'] for r in rs) / n,
             'write_bytes': sum(r['write_bytes'] * r['launches'] for r in rs) / n, 'launches': n}
+
+
+def measure_traffic(args, timeout_s=150):
+    """HBM traffic per launch of every kernel, measured on THIS box in THIS run: two `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE
+    need separate passes: TCC counter slots, MI355X_MICROARCH.md) over two serialized steps of the same workload, launched from here
+    after the timed region.  Returns {kernel name: {'fetch_bytes_corrected', 'write_bytes', 'launches'}} (the format of
+    profiles/pmc_traffic.json; FETCH_SIZE doubled per the guide's gfx950 correction) or None when rocprofv3 is missing / fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if not exe:
+        return None
+    data = {}
+    with tempfile.TemporaryDirectory(dir='/tmp') as d:
+        cmd = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--streams', '1', '--no-cpu-baseline', '--no-profile',
+               '--no-bf16x3-leg', '--no-measure-traffic', '--workload', args.workload, '--decoder-math', args.decoder_math,
+               '--linear-math', args.linear_math, '--batch', str(args.batch)]
+        env = dict(os.environ, TMPDIR='/tmp')
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(d, ctr)
+            try:
+                r = subprocess.run([exe, '--pmc', ctr, '--kernel-trace', '-d', out, '-o', ctr.lower(), '--'] + cmd, cwd='/tmp', env=env,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except Exception:
+                return None
+            dbs = glob.glob(os.path.join(out, '**', '*.db'), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            cur = sqlite3.connect(dbs[0]).cursor()
+            try:
+                rows = list(cur.execute('select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name'))
+            except Exception:
+                return None
+            for name, c, n, val in rows:
+                name = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+                data.setdefault(name, {})[c] = (n, val)
+    recs = {}
+    for name, dd in data.items():
+        if 'FETCH_SIZE' in dd and 'WRITE_SIZE' in dd:          # (KiB per dispatch)
+            recs[name] = {'fetch_bytes_corrected': 2 * dd['FETCH_SIZE'][1] * 1024, 'write_bytes': dd['WRITE_SIZE'][1] * 1024, 'launches': dd['FETCH_SIZE'][0]}
+    return recs or None
 
 
 def _free_port():
@@ -237,8 +290,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', choices=['tiles16', 'tile2048'], default='tiles16')
-    ap.add_argument('--batch', type=int, default=16, help='128x128 LR tiles per GPU per step (tiles16) / per batched test() call (tile2048)')
+    ap.add_argument('--workload', choices=['tiles16', 'tile2048', 'x2b32', 'hq8'], default='tiles16')
+    ap.add_argument('--batch', type=int, default=None, help='128x128 LR tiles per GPU per step (tiles16) / per batched test() call (tile2048)')
     ap.add_argument('--image', type=int, default=2048, help='tile2048: LR image side')
     ap.add_argument('--streams', type=int, default=3, help='sub-batch streams inside one forward (femasr_set_streams)')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra serialized steps (streams=1) for the roofline object')
@@ -259,6 +312,9 @@ def main():
     ap.add_argument('--no-bf16x3-leg', '--no-exact-leg', dest='no_second_leg', action='store_true',
                     help='skip the extra timing of the other decoder-math mode')
     ap.add_argument('--no-profile', action='store_true', help='do not record per-kernel HIP events')
+    ap.add_argument('--no-measure-traffic', action='store_true',
+                    help='do not run the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; ~20 s each) that make roofline.traffic a number of THIS run; '
+                         'the line then carries the figure of profiles/pmc_traffic.json, stamped as such')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -285,7 +341,10 @@ def main():
         if not dry:
             torch.cuda.synchronize(dev)
 
-    net = build_network(dict(X4_CFG))
+    wl = WORKLOADS.get(args.workload)
+    if args.batch is None:
+        args.batch = wl['batch'] if wl else 16
+    net = build_network(dict(wl['cfg'] if wl else X4_CFG))
     if dry:
         net = DryNet(net).net
     else:
@@ -325,6 +384,16 @@ def main():
         scaling = 'weak'
         workload = (f'x4 SR FeMaSRNet.test, batch {B} of 128x128 LR tiles per GPU -> 512x512 (padded 144->576 inside, reference '
                     'geometry), synthetic random weights (seed 0; codebook drawn at the scale of z), inputs resident in HBM')
+        units_per_step = B * world
+    elif wl:
+        x = torch.from_numpy(synth.synth_input(1000 + rank, (B, 3, wl['hw'], wl['hw']))).to(dev)
+        do_gather = False
+
+        def step():
+            return net.test(x) if wl['fn'] == 'test' else net(x)[0]
+        out_mpix = world * B * wl['out_hw'] * wl['out_hw'] / 1e6
+        scaling = 'weak'
+        workload = wl['text'].format(B=B) + ' per GPU, synthetic random weights (seed 0; codebook drawn at the scale of z), inputs resident in HBM'
         units_per_step = B * world
     else:
         S = args.image
@@ -398,9 +467,10 @@ def main():
     assert torch.isfinite(y).all()
     step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)] if step_ev else []
 
+    unit_gflop = wl['gflop'] if wl else TILE_GFLOP          # algorithmic GFLOP of one unit
     value = out_mpix * args.steps / dt
     res = {
-        'metric': 'SR output megapixels/sec at x4 (128->512)', 'value': round(value, 4), 'unit': 'MPix/s',
+        'metric': wl['metric'] if wl else 'SR output megapixels/sec at x4 (128->512)', 'value': round(value, 4), 'unit': 'MPix/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
         'dtype': (('f32' if args.linear_math == 'fp32' else
@@ -409,14 +479,14 @@ def main():
                   if args.decoder_math in ('fp32', 'fp32_strict', 'fp32_direct') else 'f32 + bf16x3 split (secondary mode, not the bench of record)'),
         'data': 'synthetic' if not dry else 'dry-net stand-in on CPU (launch-path check, NOT a measurement)',
         'config': {'workload': workload, 'workload_name': args.workload,
-                   'global_batch': units_per_step, 'tile': '128x128->512x512', 'parallelism': f'tile-parallel x{world}',
+                   'global_batch': units_per_step, 'tile': wl['tile'] if wl else '128x128->512x512', 'parallelism': f'tile-parallel x{world}',
                    'backend': ('RCCL (torch.distributed nccl)' if backend == 'nccl' else backend) if use_pg else 'none (single process)',
                    'gather': bool(do_gather), 'streams': args.streams, 'decoder_math': args.decoder_math, 'linear_math': args.linear_math,
                    'decoder_math_note': ("product default: all fp32; the SiLU of the Winograd convs' GroupNorm prologue on the hardware exp2 / rcp units - "
                                          "VQ indices exact, image within 1e-5 of 'fp32_strict' (the mode that is bit-identical to the CPU oracle, timed as a secondary leg)"
                                          if args.decoder_math == 'fp32' else None),
-                   'algorithmic_gflop_per_tile': TILE_GFLOP,
-                   'end_to_end_algorithmic_tflops': None if dry else round(TILE_GFLOP * units_per_step * args.steps / dt / 1e3, 2),
+                   'algorithmic_gflop_per_tile': unit_gflop,
+                   'end_to_end_algorithmic_tflops': None if dry else round(unit_gflop * units_per_step * args.steps / dt / 1e3, 2),
                    'flops_note': ('algorithmic = the layer DEFINITIONS (964.47 GFLOP per tile, direct form); the default fp32 mode ISSUES far '
                                   'fewer (behind the VQ lookup: Winograd F(4x4,3x3) 36/144, nearest-x2 convs in the 25-product form 25/144; phase-filter x2 convs elsewhere: 4/9) - the issued figure and '
                                   'the physical MFMA fraction are in `roofline`')},
@@ -458,18 +528,19 @@ def main():
 
     # ---------------------------------------------------------------- rank-0 extras (not part of the timed region)
     if rank == 0 and not dry:
-        x16 = x if args.workload == 'tiles16' else torch.from_numpy(synth.synth_input(1000, (B, 3, 128, 128))).to(dev)
+        x16 = x if (args.workload == 'tiles16' or wl) else torch.from_numpy(synth.synth_input(1000, (B, 3, 128, 128))).to(dev)
+        run16 = (lambda t: net(t)[0]) if (wl and wl['fn'] == 'forward') else net.test          # the unit forward of this workload
         # Per-kernel roofline: HIP events around every launch on the launch stream.  With >1 sub-batch streams kernels
         # of different streams overlap and a per-kernel duration is not separable, so the events are recorded in extra
         # SERIALIZED steps (streams=1) run right after the timed region.
         if not args.no_profile and args.profile_steps > 0:
             net.num_streams = 1
-            net.test(x16)
+            run16(x16)
             sync()
             net.enable_profile(True)
             tp0 = time.perf_counter()
             for _ in range(args.profile_steps):
-                net.test(x16)
+                run16(x16)
             sync()
             prof_ms_per_step = (time.perf_counter() - tp0) / args.profile_steps * 1e3
             prof = net.profile()
@@ -477,7 +548,13 @@ def main():
             net.num_streams = args.streams
             convs = merge_wino_slots({k: v for k, v in prof.items() if k.startswith('conv')})      # the MFMA kernels
             psteps = args.profile_steps
-            pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
+            pmc_live = None
+            if world == 1 and not args.no_measure_traffic:
+                try:
+                    pmc_live = measure_traffic(args)
+                except Exception:
+                    pmc_live = None
+            pmc = pmc_live or (json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {})
 
             def issued_share(name):      # MFMA flops issued / algorithmic flops of the layer definition
                 if name.startswith('conv3x3_wino_up2'):
@@ -521,8 +598,12 @@ def main():
                 elif share == 4.0 / 9.0:
                     out['form'] = 'nearest-x2 folded into four 2x2-tap phase filters: 4 multiplies per output where the definition has 9'
                 if rec:
-                    out['traffic_source'] = ('GB per launch, rocprofv3 --pmc FETCH_SIZE (doubled per MI355X_MICROARCH.md HBM section) + WRITE_SIZE '
-                                             'passes of this command on the BUILD box (profiles/pmc_traffic.json); not re-measured in this run')
+                    out['traffic_source'] = (('GB per launch MEASURED IN THIS RUN on this box: two rocprofv3 --pmc passes (FETCH_SIZE, doubled per '
+                                              'MI355X_MICROARCH.md HBM section, and WRITE_SIZE) over two serialized steps of this workload, launched by bench.py '
+                                              'after the timed region') if pmc_live else
+                                             ('GB per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes on the BUILD box, commit-stamped there); NOT '
+                                              're-measured in this run: rocprofv3 missing / failed or --no-measure-traffic'))
+                    out['traffic_measured_live'] = bool(pmc_live)
                 return out
             dom = max(convs, key=lambda k: convs[k][0])
             res['roofline'] = roof(dom)
@@ -596,7 +677,7 @@ def main():
             net.decoder_math = args.decoder_math
             net.linear_math = args.linear_math
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(net, x16, y if args.workload == 'tiles16' else None, B)
+            res['cpu_baseline'] = cpu_baseline(net, x16, y if (args.workload == 'tiles16' or wl) else None, B, wl)
             res['vq_index_match'] = res['cpu_baseline'].pop('vq_index_match')      # the metric's second half (BASELINE.json), top level
     if rank == 0:
         try:        # RCCL's banner goes through C stdio: flush it first so that the JSON line is the LAST line on stdout
@@ -613,7 +694,7 @@ def main():
         sys.exit(3)
 
 
-def cpu_baseline(net, x16, y_gpu, B):
+def cpu_baseline(net, x16, y_gpu, B, wl=None):
     """The same path on this box's host cores, on ONE of the step's tiles (bounded sample): (a) the stock-torch CPU
     restatement (oracle/torch_ref.py: ATen/oneDNN ops, i.e. the reference's own arithmetic library; bit-identical to
     the reference goldens), all physical cores, 1 warm-up + median of 3; (b) the C oracle (scalar fmaf chains, the
@@ -626,45 +707,50 @@ def cpu_baseline(net, x16, y_gpu, B):
     xs = x16[:1].cpu()
     cores = physical_cores()
     prev = torch.get_num_threads()
-    tnet = TorchRefNet(sd, LQ_stage=True, scale_factor=4)
+    kw = {k: v for k, v in (wl['cfg'] if wl else X4_CFG).items() if k != 'type'}
+    fwd = bool(wl and wl['fn'] == 'forward')
+    unit_px = (wl['out_hw'] if wl else 512) ** 2
+    unit_text = (f"{wl['tile']}, {wl['gflop']} GFLOP" if wl else f'x4 128x128->512x512, {TILE_GFLOP} GFLOP')
+    tnet = TorchRefNet(sd, **kw)
+    tnet_run = (lambda t: tnet.forward(t)[0]) if fwd else tnet.test
     # the best thread count for one 128x128 tile is not "all cores" on a 2-socket box (small convs): probe a few settings
     # (1 warm-up + 1 timed run each), then 1 warm-up + median of 3 at the fastest
     probe = {}
     for nt in sorted({cores, max(cores // 2, 1), max(cores // 4, 1), min(cores, 16)}, reverse=True):
         torch.set_num_threads(nt)
-        tnet.test(xs)
+        tnet_run(xs)
         t1 = time.perf_counter()
-        tnet.test(xs)
+        tnet_run(xs)
         probe[nt] = time.perf_counter() - t1
     best = min(probe, key=probe.get)
     torch.set_num_threads(best)
-    tnet.test(xs)
+    tnet_run(xs)
     ts = []
     for _ in range(3):
         t1 = time.perf_counter()
-        yt = tnet.test(xs)
+        yt = tnet_run(xs)
         ts.append(time.perf_counter() - t1)
     torch.set_num_threads(prev)
     tt = sorted(ts)[1]
     # BASELINE.json's metric names "VQ index bit-match": the index map of this tile in the reference's arithmetic (stock torch
     # ops: femasr_arch.py:35-38,58-66) against the HIP path's, each difference classified with the reference-side distances
     tnet.keep_vq_dist = True
-    _, it = tnet.test(xs, return_indices=True)
+    _, it = tnet.forward(xs) if fwd else tnet.test(xs, return_indices=True)
     tnet.keep_vq_dist = False
-    vq = vq_index_report(net, xs, it.numpy().reshape(-1), tnet.vq_dist[0].numpy())
+    vq = vq_index_report(net, xs, it.numpy().reshape(-1), tnet.vq_dist[0].numpy(), forward=fwd)
     onet = orc.OracleNet({k: v for k, v in sd.items() if not k.endswith(('relative_position_index', 'attn_mask'))},
-                         LQ_stage=True, scale_factor=4, linear_math=net.linear_math)
+                         linear_math=net.linear_math, **kw)
     t1 = time.perf_counter()
-    yo = onet.test(xs.numpy())
+    yo = onet.forward(xs.numpy())[0] if fwd else onet.test(xs.numpy())
     tc = time.perf_counter() - t1
     out = {
-        'value': round(512 * 512 / 1e6 / tt, 5), 'unit': 'MPix/s', 'cores': best, 'kind': 'port',
+        'value': round(unit_px / 1e6 / tt, 5), 'unit': 'MPix/s', 'cores': best, 'kind': 'port',
         'impl': 'stock torch CPU (ATen/oneDNN/MKL fp32, the arithmetic library the reference itself runs on); module restated in '
                 'oracle/torch_ref.py from the reference semantics, bit-identical to the reference-recorded goldens',
         'cpu': cpu_model_name(), 'physical_cores': cores, 'torch_threads': best,
         'thread_probe_s': {str(k): round(v, 2) for k, v in probe.items()},
-        'sample': f'1 of the {B} tiles of one step (x4 128x128->512x512, {TILE_GFLOP} GFLOP): fastest of the probed thread counts, 1 warm-up + median of 3 = {tt:.2f} s',
-        'c_oracle': {'value': round(512 * 512 / 1e6 / tc, 5), 'unit': 'MPix/s', 'cores': os.cpu_count(), 'kind': 'port',
+        'sample': f'1 of the {B} units of one step ({unit_text}): fastest of the probed thread counts, 1 warm-up + median of 3 = {tt:.2f} s',
+        'c_oracle': {'value': round(unit_px / 1e6 / tc, 5), 'unit': 'MPix/s', 'cores': os.cpu_count(), 'kind': 'port',
                      'sample': (f'the same tile through oracle/femasr_oracle.c (C, OpenMP: the bit-exact checker - fp32 fmaf chains, and for the 1x1 / Linear '
                                 f"layers in linear_math='bf16_split' the restated matrix-instruction arithmetic, ~30x the work of a chain) in {tc:.1f} s")},
     }
@@ -674,13 +760,15 @@ def cpu_baseline(net, x16, y_gpu, B):
         out['max_abs_torch_cpu_vs_gpu'] = float(np.abs(yt.numpy() - yg).max())
         out['c_oracle']['max_abs_vs_gpu'] = float(np.abs(yo - yg).max())
     try:
+        if wl:
+            raise RuntimeError('measured on the tiles16 workload only')
         out['host_throughput'] = cpu_host_throughput(sd, xs.numpy(), cores, best)
     except Exception as e:                                  # a reported extra, never a reason to lose the bench line
         out['host_throughput'] = {'error': f'{type(e).__name__}: {e}'[:200]}
     return out
 
 
-def vq_index_report(net, xs_cpu, idx_ref, dist_ref, rule_ulp=None):
+def vq_index_report(net, xs_cpu, idx_ref, dist_ref, rule_ulp=None, forward=False):
     """The HIP path's VQ index map of one tile against the reference arithmetic's (`idx_ref`, `dist_ref` = the (tokens, n_e)
     fp32 distance matrix torch computed on the CPU).  A differing token is 'within the rule' when, in the REFERENCE's own
     distances, the code the HIP path picked is within `rule_ulp` ulp of the reference's minimum (hard part 1: encoder
@@ -690,7 +778,10 @@ def vq_index_report(net, xs_cpu, idx_ref, dist_ref, rule_ulp=None):
     from oracle.near_tie import NEAR_TIE_ULP, histogram      # the one rule of tests/, tools/parity_report.py and this line
     rule_ulp = NEAR_TIE_ULP if rule_ulp is None else rule_ulp
     dev = next(net.parameters()).device
-    _, ig = net.test_with_indices(xs_cpu.to(dev))
+    if forward:
+        ig = net(xs_cpu.to(dev))[3][0]
+    else:
+        _, ig = net.test_with_indices(xs_cpu.to(dev))
     torch.cuda.synchronize()
     ig = ig.cpu().numpy().reshape(-1)
     assert ig.shape == idx_ref.shape, (ig.shape, idx_ref.shape)
