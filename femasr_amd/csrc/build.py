@@ -45,6 +45,14 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+    if jobs and os.environ.get('FEMASR_SKIP_SCRATCH_CHECK') != '1':
+        # gate: no kernel of the default schedule may (newly) use scratch memory - kernel_meta.py reads the code objects' metadata
+        sys.path.insert(0, HERE)
+        import kernel_meta
+        _, bad = kernel_meta.check()
+        if bad:
+            raise RuntimeError('kernels of the default schedule use (more) scratch memory:\n' + kernel_meta.table(bad) +
+                               '(fix the spill, or list the instantiation in kernel_meta.py with the reason)')
     return SO
 
 
