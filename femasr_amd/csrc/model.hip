@@ -89,6 +89,25 @@ struct WSpec {
     size_t numel() const { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i]; return n; }
 };
 
+// Is the conv with this state-dict key BEHIND every codebook lookup of the network (so that it cannot move a VQ index and may run in a
+// cheaper algebraic form)?  One codebook: the whole decoder side, and the LQ encoder's up-blocks (they only make skip features).
+// Several codebooks (femasr_arch.py:277-300,330-367): the decoder feeds the later lookups through before_quant_group[q > 0], so only what
+// follows the LAST lookup qualifies: after_quant_group[last], decoder_group[i >= stage of the last lookup], out_conv.  A static rule of
+// the layer (decode_indices runs decoder_group[0..] of such a network in the direct form too; the oracle applies the same rule).
+bool behind_every_lookup(const femasr_config &cfg, int encode_depth, int last_quant_stage, const std::string &k)
+{
+    const bool dec = k.rfind("decoder_group.", 0) == 0, aq = k.rfind("after_quant_group.", 0) == 0, oc = k.rfind("out_conv", 0) == 0;
+    if (cfg.n_codebooks == 1) {
+        if (dec || aq || oc) return true;
+        const std::string pre = "multiscale_encoder.blocks.";
+        return cfg.lq_stage && k.rfind(pre, 0) == 0 && atoi(k.c_str() + pre.size()) > encode_depth;
+    }
+    if (oc) return true;
+    if (aq) return atoi(k.c_str() + 18) == cfg.n_codebooks - 1;
+    if (dec) return atoi(k.c_str() + 14) >= last_quant_stage;
+    return false;
+}
+
 struct T {          // NHWC activation view
     float *p = nullptr;
     int B = 0, H = 0, W = 0, C = 0;
@@ -151,6 +170,7 @@ struct ProfRec { int slot; hipEvent_t e0, e1; double flops, bytes; };
 struct femasr_handle {
     femasr_config cfg;
     int scale = 1, max_depth = 0, encode_depth = 0;
+    int last_quant_stage = 0;       // decoder stage of the last codebook lookup (behind_every_lookup)
     std::vector<WSpec> specs;
     std::map<std::string, int> index;
     float *cbT[FEMASR_MAX_CODEBOOKS] = {nullptr, nullptr, nullptr}, *ee[FEMASR_MAX_CODEBOOKS] = {nullptr, nullptr, nullptr};
@@ -369,17 +389,18 @@ struct Ctx {
         a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
         a.in_add = o.in_add;
         const void *split = nullptr;
-        // (several codebooks: the decoder feeds later lookups through before_quant_group[q > 0], so NO conv is 'behind' every
-        // lookup - the inexact bf16x3 form, like the Winograd form below, is only taken by single-codebook networks)
-        if (o.lowp && h->decoder_math == 1 && h->cfg.n_codebooks == 1) {
+        // (several codebooks: the decoder feeds the later lookups through before_quant_group[q > 0]: only the convs that follow the LAST
+        // lookup may take the bf16x3 / Winograd forms - behind_every_lookup)
+        const bool behind = o.lowp && behind_every_lookup(h->cfg, h->encode_depth, h->last_quant_stage, prefix);
+        if (behind && h->decoder_math == 1) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) split = h->specs[it->second].split;
         }
         const bool lowp_on = split != nullptr && cout > 4 && femasr_conv_bf16x3_shape_ok(&a);      // out_conv: exact VALU kernel in both modes
-        // exact-fp32 mode: convs behind the codebook lookup of a single-codebook network run in the Winograd F(4x4,3x3) form
+        // exact-fp32 mode: convs behind every codebook lookup run in the Winograd F(4x4,3x3) form
         // (they cannot move a VQ index; oracle: OracleNet.wino).  decoder_math 2 = 'fp32_direct' keeps the direct form; 0 runs the
         // SiLU of their GroupNorm prologue on the hardware exp2 / rcp units, 3 = 'fp32_strict' keeps it IEEE-exact (== oracle).
-        const bool wino_on = !lowp_on && o.lowp && (h->decoder_math == 0 || h->decoder_math == 3) && h->cfg.n_codebooks == 1 &&
+        const bool wino_on = !lowp_on && behind && (h->decoder_math == 0 || h->decoder_math == 3) &&
                              (o.up2 ? femasr_conv_wino_up2_shape_ok(&a) : femasr_conv_wino_shape_ok(&a));
         const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
                                    : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
@@ -576,12 +597,13 @@ struct Ctx {
 
     // Will the x2 conv of a decoder stage with this input run in the Winograd-type form (the same test conv() makes)?  Then the skip
     // feature of that stage is added by ITS staging (in_add) instead of by the previous stage's last epilogue (a second residual operand).
-    bool up2_wino_ok(int B, int H, int W, int Cin, int Cout) const
+    bool up2_wino_ok(const std::string &prefix, int B, int H, int W, int Cin, int Cout) const
     {
+        if (!behind_every_lookup(h->cfg, h->encode_depth, h->last_quant_stage, prefix)) return false;
         femasr_conv_args a{};
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ksz = 3; a.stride = 1; a.pad = 1; a.up2 = 1;
         a.prologue = FEMASR_PRO_NONE; a.act = FEMASR_ACT_NONE; a.Ho = 2 * H; a.Wo = 2 * W;
-        return (h->decoder_math == 0 || h->decoder_math == 3) && h->cfg.n_codebooks == 1 && femasr_conv_wino_up2_shape_ok(&a);
+        return (h->decoder_math == 0 || h->decoder_math == 3) && femasr_conv_wino_up2_shape_ok(&a);
     }
 
     T up_block(const T &x, const std::string &p, int cout, const float *res2_last, bool lowp = false, const float *in_add = nullptr)   // Upsample x2 -> conv -> RB -> RB
@@ -718,7 +740,7 @@ int run_tail(Ctx &c, T x, std::vector<T> &feats, bool fuse_skip, bool with_encod
         // two-residual epilogue was the slowest instantiation of the F(4x4) kernel); otherwise folded into this block's last epilogue
         const bool next_skip = with_encoder && fuse_skip && i + 1 < h->max_depth && !quant_at(h, i + 1, nullptr);
         const int cout_i = channels_at(r * 2);
-        const bool skip_by_next = next_skip && c.up2_wino_ok(x.B, 2 * x.H, 2 * x.W, cout_i, channels_at(r * 4));
+        const bool skip_by_next = next_skip && c.up2_wino_ok("decoder_group." + std::to_string(i + 1) + ".block.1", x.B, 2 * x.H, 2 * x.W, cout_i, channels_at(r * 4));
         const float *skip = (next_skip && !skip_by_next) ? feats[i + 1].p : nullptr;
         T y = c.up_block(x, "decoder_group." + std::to_string(i) + ".block", cout_i, skip, true, pending_add.p);
         c.release(x);
@@ -854,6 +876,7 @@ int femasr_create(const femasr_config *cfg, femasr_handle **out)
     h->scale = cfg->lq_stage ? cfg->scale_factor : 1;
     if (!(h->scale == 1 || h->scale == 2 || h->scale == 4)) { delete h; return femasr_set_error(FEMASR_ERR_INVALID, "create: scale_factor %d unsupported", h->scale); }
     h->max_depth = ilog2(cfg->gt_resolution / cfg->codebook_scale[0]);
+    h->last_quant_stage = ilog2(cfg->codebook_scale[cfg->n_codebooks - 1] / cfg->codebook_scale[0]);      // (rows in ascending scale order)
     h->encode_depth = ilog2(cfg->gt_resolution / h->scale / cfg->codebook_scale[0]);
     if (h->max_depth < 1 || h->max_depth > 3) { delete h; return femasr_set_error(FEMASR_ERR_INVALID, "create: max_depth %d unsupported", h->max_depth); }
     for (int q = 1; q < cfg->n_codebooks; ++q) {
@@ -934,12 +957,8 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
     else
         FEMASR_CHECK_HIP(hipMemcpyAsync(w.dev, dev_ptr, n * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
     if (rc) return rc;
-    bool dec_side = k.rfind("decoder_group.", 0) == 0 || k.rfind("after_quant_group.", 0) == 0 || k.rfind("out_conv.", 0) == 0;
-    {   // the encoder's two up-blocks only produce the decoder's skip features (femasr_arch.py:314,361-362): they do not
-        // feed the codebook lookup either
-        const std::string pre = "multiscale_encoder.blocks.";
-        if (h->cfg.lq_stage && k.rfind(pre, 0) == 0 && atoi(k.c_str() + pre.size()) > h->encode_depth) dec_side = true;
-    }
+    // (the encoder's two up-blocks only produce the decoder's skip features, femasr_arch.py:314,361-362: one-codebook networks count them)
+    const bool dec_side = behind_every_lookup(h->cfg, h->encode_depth, h->last_quant_stage, k);
     if ((w.kind == W_LINEAR || (w.kind == W_CONV && w.shape[2] == 1 && w.shape[3] == 1)) && (w.shape[1] % 64) == 0) {
         // 1x1 convs / nn.Linear: the three bf16 planes for the fp32-grade product on the bf16 matrix pipe (kernels_gemm_bf16.hip)
         if (!w.lin3) FEMASR_CHECK_HIP(hipMalloc(&w.lin3, femasr_packed_weight_bf16s_bytes((int)w.shape[0], (int)w.shape[1])));
@@ -951,7 +970,7 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
         rc = femasr_repack_oihw_up2(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.up2w);
         if (rc) return rc;
     }
-    if (w.kind == W_CONV && dec_side && h->cfg.n_codebooks == 1 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0 &&
+    if (w.kind == W_CONV && dec_side && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0 &&
         (w.shape[0] % 64) == 0) {
         // Winograd-domain weights: F(4x4,3x3) for the plain convs, the 25-component form for the convs behind nn.Upsample(x2)
         const size_t nf = w.up2 ? femasr_wino_up2_weight_floats((int)w.shape[0], (int)w.shape[1]) : femasr_wino_weight_floats((int)w.shape[0], (int)w.shape[1]);

@@ -332,7 +332,8 @@ class OracleNet:
         self.lin_split = linear_math == 'bf16_split'
         # the kernels' default exact-fp32 mode: 3x3 convs behind the codebook lookup of a single-codebook network run in
         # the Winograd F(4x4,3x3) form (model.hip Ctx::conv `wino`); winograd=False = decoder_math 'fp32_direct'
-        self.wino = bool(winograd) and len(codebook_params) == 1
+        self.wino = bool(winograd)
+        self.single = len(codebook_params) == 1
         self.cb_scales = [int(c[0]) for c in codebook_params]
         self.LQ_stage = bool(LQ_stage)
         self.scale_factor = int(scale_factor) if LQ_stage else 1
@@ -341,6 +342,9 @@ class OracleNet:
         self.use_quantize = use_quantize
         self.use_residual = use_residual
         self.max_depth = int(math.log2(self.gt_res // self.codebook_scale))
+        # decoder stage of the LAST lookup: with several codebooks only after_quant_group[last], decoder_group[i >= that stage] and out_conv
+        # are behind every lookup (model.hip behind_every_lookup); with one codebook the whole decoder side and the LQ up-blocks are
+        self.last_quant_stage = int(math.log2(max(self.cb_scales) // self.codebook_scale))
         self.encode_depth = int(math.log2(self.gt_res // self.scale_factor // self.codebook_scale))
         self.probes = None
         self._wcache = {}
@@ -438,9 +442,9 @@ class OracleNet:
             bi += 1
             for _ in range(2):
                 cin = x.shape[-1]
-                x = self._conv(x, f'{p}.blocks.{bi}.1', 3, 1, 1, up2=True, dec=True)
-                x = self._resblock(x, f'{p}.blocks.{bi}.2', dec=True, from_up2=cin)       # the LQ up-blocks only make the decoder's skip features
-                x = self._resblock(x, f'{p}.blocks.{bi}.3', dec=True, from_wino=True)
+                x = self._conv(x, f'{p}.blocks.{bi}.1', 3, 1, 1, up2=True, dec=self.single)
+                x = self._resblock(x, f'{p}.blocks.{bi}.2', dec=self.single, from_up2=cin)       # the LQ up-blocks only make the decoder's skip features
+                x = self._resblock(x, f'{p}.blocks.{bi}.3', dec=self.single, from_wino=True)
                 self._probe(f'enc_block{bi}', x)
                 outs.append(x)
                 bi += 1
@@ -449,9 +453,10 @@ class OracleNet:
     def _decoder_block(self, x, i, res2=None):
         p = f'decoder_group.{i}.block'
         cin = x.shape[-1]
-        x = self._conv(x, p + '.1', 3, 1, 1, up2=True, dec=True)
-        x = self._resblock(x, p + '.2', dec=True, from_up2=cin)
-        return self._resblock(x, p + '.3', res2=res2, dec=True, from_wino=True)
+        dec = self.single or i >= self.last_quant_stage
+        x = self._conv(x, p + '.1', 3, 1, 1, up2=True, dec=dec)
+        x = self._resblock(x, p + '.2', dec=dec, from_up2=cin)
+        return self._resblock(x, p + '.3', res2=res2, dec=dec, from_wino=True)
 
     def encode_and_decode(self, x_nhwc):
         """femasr_arch.py:311-374; returns (out NHWC, [indices (B,1,h,w) int64 per codebook])."""
@@ -485,7 +490,7 @@ class OracleNet:
                     ys = (np.arange(h) * prev_q.shape[1]) // h
                     xs = (np.arange(w) * prev_q.shape[2]) // w
                     ain = np.concatenate((zq, prev_q[:, ys][:, :, xs]), axis=-1)
-                x = self._conv(ain, f'after_quant_group.{qi}.conv', 3, dec=True)
+                x = self._conv(ain, f'after_quant_group.{qi}.conv', 3, dec=self.single or qi == len(self.cb_scales) - 1)
                 if qi == 0:
                     self._probe('after_quant', x)
                 prev_q = zq
@@ -547,7 +552,7 @@ class OracleNet:
         b, _, h, w = indices.shape
         cb = self.sd['quantize_group.0.embedding.weight']
         zq = codebook_gather(indices, cb).reshape(b, h, w, -1)
-        x = self._conv(zq, 'after_quant_group.0.conv', 3, dec=True)
+        x = self._conv(zq, 'after_quant_group.0.conv', 3, dec=self.single or len(self.cb_scales) == 1)
         for i in range(self.max_depth):
             x = self._decoder_block(x, i)
         wout, bout = self._conv_w('out_conv')

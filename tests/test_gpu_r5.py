@@ -154,3 +154,40 @@ def test_linear_math_switch_replans_and_differs(cuda_device):
     with pytest.raises(ValueError):
         net.linear_math = 'bf16'
         net.test(x)
+
+
+@pytest.mark.parametrize('name', ['x4mc_small_trained', 'hq2_small_trained'])
+def test_multi_codebook_nets_run_winograd_behind_the_last_lookup(cuda_device, name):
+    """Two-codebook networks (femasr_arch.py:277-300,330-367): the decoder feeds the second lookup, so only what FOLLOWS the last lookup
+    (after_quant_group[1], decoder_group[i >= its stage], out_conv) may leave the direct form - those layers now run in the Winograd forms
+    (round 4 ran every conv of such a network direct), the ones ahead of the last lookup still run direct; bit-identical to the oracle under
+    the same rule and within 1e-3 of the reference golden."""
+    from femasr_amd.archs import build_network
+    from helpers import golden_cfg, weights_from_arch
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    w = weights_from_arch(cfg, int(g['seed']), str(g['codebook']), str(g['variant']))
+    x = synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))
+    net = build_network(dict(type='FeMaSRNet', **cfg))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    net.decoder_math = 'fp32_strict'
+    net = net.cuda().eval()
+    xt = torch.from_numpy(x).cuda()
+    run = (lambda: net.test_with_all_indices(xt)) if str(g['mode']) == 'test' else (lambda: (lambda r: (r[0], r[3]))(net(xt)))
+    y, idx = run()
+    net.enable_profile(True)
+    run()
+    torch.cuda.synchronize()
+    prof = net.profile()
+    net.enable_profile(False)
+    wino = {k: v[1] for k, v in prof.items() if k.startswith('conv3x3_wino')}
+    direct = {k: v[1] for k, v in prof.items() if k.startswith('conv3x3_halo')}
+    assert sum(wino.values()) > 0 and sum(direct.values()) > 0, (wino, direct)
+    onet = oracle_net(cfg, w)
+    yo, io = onet.test(x, return_indices=True) if str(g['mode']) == 'test' else onet.forward(x)
+    io = io if isinstance(io, list) else [io]
+    for a, b in zip(idx, io):
+        assert np.array_equal(a.cpu().numpy(), b)
+    assert np.array_equal(y.cpu().numpy(), yo), float(np.abs(y.cpu().numpy() - yo).max())
+    assert float(np.abs(y.cpu().numpy() - g['output']).max()) < 1e-3
+    print(f'{name}: Winograd-form launches {wino}, direct-form launches {sum(direct.values())}')
