@@ -61,6 +61,9 @@ SIGNATURES = {
     'femasr_forward_shapes': (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                       ctypes.POINTER(c_int * MAX_CODEBOOKS), ctypes.POINTER(c_int * MAX_CODEBOOKS)]),
     'femasr_forward': (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, szt]),
+    'femasr_forward_u8': (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, szt]),
+    'femasr_pad_u8hwc_to_nhwc': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'femasr_crop_nhwc_to_u8hwc': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'femasr_decode_workspace_bytes': (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(szt)]),
     'femasr_decode_indices': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, vp, szt]),
     'femasr_profile_enable': (c_int, [vp, c_int]),

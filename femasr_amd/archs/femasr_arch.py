@@ -383,6 +383,33 @@ class FeMaSRNet(nn.Module):
         return out, idx
 
     @torch.no_grad()
+    def test_u8(self, img_u8, bgr=False):
+        """The CLI arithmetic of inference_femasr.py:50-67 on the device in ONE native call: uint8 (H,W,3) or (B,H,W,3) image(s) ->
+        uint8 (sH,sW,3) / (B,sH,sW,3); decode (`/255.`) is fused into the forward's mirror-pad kernel and tensor2img (clamp, x255,
+        round half to even) into its crop kernel (femasr_forward_u8) - the same bits as imgproc.u8_to_input -> test() ->
+        imgproc.output_to_u8, without the two fp32 NCHW images in between."""
+        if img_u8.device.type != 'cuda':
+            raise _lib.FemasrError('test_u8: tensor must be on the GPU (no CPU fallback)')
+        single = img_u8.dim() == 3
+        x = img_u8.unsqueeze(0) if single else img_u8
+        if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[3] != 3:
+            raise ValueError(f'expected uint8 (H,W,3) or (B,H,W,3), got {img_u8.dtype} {tuple(img_u8.shape)}')
+        lib, h = self._native(x.device)
+        x = x.contiguous()
+        b, hh, ww, _ = x.shape
+        oh, ow, nq = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        qh, qw = (ctypes.c_int * _lib.MAX_CODEBOOKS)(), (ctypes.c_int * _lib.MAX_CODEBOOKS)()
+        _lib.check(lib.femasr_forward_shapes(h, hh, ww, 1, ctypes.byref(oh), ctypes.byref(ow), ctypes.byref(nq), ctypes.byref(qh), ctypes.byref(qw)))
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.femasr_workspace_bytes(h, b, hh, ww, 1, ctypes.byref(nbytes)))
+        ws = self._workspace(nbytes.value, x.device)
+        out = torch.empty((b, oh.value, ow.value, 3), dtype=torch.uint8, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.femasr_forward_u8(h, ctypes.c_void_p(stream), _lib.ptr(x), b, hh, ww, int(bool(bgr)), 1, _lib.ptr(out), None,
+                                         _lib.ptr(ws), ws.numel()))
+        return out[0] if single else out
+
+    @torch.no_grad()
     def encode_and_decode(self, input, gt_indices=None, current_iter=None):
         """`gt_indices` (one (B,1,h,w) index map per codebook) only changes the LOSS in the reference - VectorQuantizer.forward
         computes z_q and the returned indices from its own argmin either way (femasr_arch.py:64-66,69-91,95,339-342) - so an

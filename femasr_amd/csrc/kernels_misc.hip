@@ -37,6 +37,41 @@ __global__ void pad_nchw_to_nhwc_kernel(const float *__restrict__ in, int B, int
     }
 }
 
+// femasr_forward_u8: the image decode arithmetic fused into the pad - uint8 HWC (B,H,W,3) -> (float)u8 / 255.0f (img2tensor + `/255.`,
+// img_util.py:9-35, inference_femasr.py:55) mirrored to NHWC (B,Hp,Wp,3); swap_rb = the cv2 BGR order
+__global__ void pad_u8hwc_to_nhwc_kernel(const unsigned char *__restrict__ in, int B, int H, int W, int swap_rb, int Hp, int Wp,
+                                         float *__restrict__ out, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        size_t r = i / 3;
+        const int x = (int)(r % Wp);
+        r /= Wp;
+        const int y = (int)(r % Hp);
+        const int n = (int)(r / Hp);
+        const int sy = y < H ? y : 2 * H - 1 - y, sx = x < W ? x : 2 * W - 1 - x;
+        out[i] = (float)in[(((size_t)n * H + sy) * W + sx) * 3 + (swap_rb ? 2 - c : c)] / 255.0f;
+    }
+}
+
+// ... and tensor2img (img_util.py:38-94) fused into the crop: NHWC (B,Hs,Ws,3) -> clamp [0,1], x255, round half to even -> uint8 HWC (B,Hc,Wc,3)
+__global__ void crop_nhwc_to_u8hwc_kernel(const float *__restrict__ in, int B, int Hs, int Ws, int Hc, int Wc, int swap_rb,
+                                          unsigned char *__restrict__ out, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        size_t r = i / 3;
+        const int x = (int)(r % Wc);
+        r /= Wc;
+        const int y = (int)(r % Hc);
+        const int n = (int)(r / Hc);
+        float v = in[(((size_t)n * Hs + y) * Ws + x) * 3 + (swap_rb ? 2 - c : c)];
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+        if (!(v == v)) v = 0.f;
+        out[i] = (unsigned char)rintf(v * 255.0f);
+    }
+}
+
 // one thread per output element of NCHW (B,C,Hc,Wc)
 __global__ void crop_nhwc_to_nchw_kernel(const float *__restrict__ in, int B, int Hs, int Ws, int C, int Hc, int Wc,
                                          float *__restrict__ out, size_t total)
@@ -787,6 +822,24 @@ int femasr_pad_nchw_to_nhwc(void *stream, const float *in, int B, int C, int H, 
     const size_t total = (size_t)B * Hp * Wp * C;
     hipLaunchKernelGGL(pad_nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, B, C, H, W,
                        Hp, Wp, out, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_pad_u8hwc_to_nhwc(void *stream, const uint8_t *in, int B, int H, int W, int swap_rb, int Hp, int Wp, float *out)
+{
+    FEMASR_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W && Hp <= 2 * H && Wp <= 2 * W, "pad_u8: bad args");
+    const size_t total = (size_t)B * Hp * Wp * 3;
+    hipLaunchKernelGGL(pad_u8hwc_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, B, H, W, swap_rb, Hp, Wp, out, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_crop_nhwc_to_u8hwc(void *stream, const float *in, int B, int Hs, int Ws, int Hc, int Wc, int swap_rb, uint8_t *out)
+{
+    FEMASR_REQUIRE(in && out && B > 0 && Hc > 0 && Wc > 0 && Hc <= Hs && Wc <= Ws, "crop_u8: bad args");
+    const size_t total = (size_t)B * Hc * Wc * 3;
+    hipLaunchKernelGGL(crop_nhwc_to_u8hwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, B, Hs, Ws, Hc, Wc, swap_rb, out, total);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

@@ -342,6 +342,8 @@ struct Ctx {
     Arena *arena;
     hipStream_t stream;
     int rc = 0;
+    // femasr_forward_u8: the first / last kernel of the forward read / write uint8 HWC images directly (bit 0: input, bit 1: output)
+    int io_u8 = 0, swap_rb = 0;
     bool dry() const { return arena->dry; }
     hipStream_t s() const { return stream; }
 
@@ -754,7 +756,8 @@ int run_tail(Ctx &c, T x, std::vector<T> &feats, bool fuse_skip, bool with_encod
     c.release(x);
     if (!c.rc && !c.dry()) {
         Scope sc(h, c.s(), c.dry(), SLOT_LAYOUT, 0.0, (double)img.B * 3.0 * crop_h * crop_w * 8.0);
-        const int r = femasr_crop_nhwc_to_nchw(c.s(), img.p, img.B, img.H, img.W, 3, crop_h, crop_w, out_nchw);
+        const int r = (c.io_u8 & 2) ? femasr_crop_nhwc_to_u8hwc(c.s(), img.p, img.B, img.H, img.W, crop_h, crop_w, c.swap_rb, (uint8_t *)out_nchw)
+                                    : femasr_crop_nhwc_to_nchw(c.s(), img.p, img.B, img.H, img.W, 3, crop_h, crop_w, out_nchw);
         if (r && !c.rc) c.rc = r;
     }
     c.release(img);
@@ -762,10 +765,11 @@ int run_tail(Ctx &c, T x, std::vector<T> &feats, bool fuse_skip, bool with_encod
 }
 
 int run_forward(femasr_handle *h, Arena *arena, hipStream_t stream, const float *in_nchw, int B, int H, int W, int pad_mode,
-                float *out_nchw, int64_t *const *idx_out)
+                float *out_nchw, int64_t *const *idx_out, int io_u8 = 0, int swap_rb = 0)
 {
     const femasr_config &cfg = h->cfg;
     Ctx c{h, arena, stream};
+    c.io_u8 = io_u8; c.swap_rb = swap_rb;
     Geometry g;
     int rc = plan_geometry(h, H, W, pad_mode, &g);
     if (rc) return rc;
@@ -777,7 +781,8 @@ int run_forward(femasr_handle *h, Arena *arena, hipStream_t stream, const float 
     T x0 = c.alloc_t(B, g.Hp, g.Wp, cfg.in_channel);
     if (!c.rc && !c.dry()) {
         Scope sc(h, c.s(), c.dry(), SLOT_LAYOUT, 0.0, (double)x0.numel() * 8.0);
-        const int r = femasr_pad_nchw_to_nhwc(c.s(), in_nchw, B, cfg.in_channel, H, W, g.Hp, g.Wp, x0.p);
+        const int r = (c.io_u8 & 1) ? femasr_pad_u8hwc_to_nhwc(c.s(), (const uint8_t *)in_nchw, B, H, W, c.swap_rb, g.Hp, g.Wp, x0.p)
+                                    : femasr_pad_nchw_to_nhwc(c.s(), in_nchw, B, cfg.in_channel, H, W, g.Hp, g.Wp, x0.p);
         if (r) c.rc = r;
     }
     const std::string enc = "multiscale_encoder";
@@ -1108,12 +1113,13 @@ int femasr_set_streams(femasr_handle *h, int n)
     return FEMASR_OK;
 }
 
-int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, int H, int W, int pad_mode,
-                   float *out_nchw, int64_t *indices, void *ws, size_t ws_bytes)
+static int forward_impl(femasr_handle *h, void *stream, const float *in_nchw, int B, int H, int W, int pad_mode,
+                        float *out_nchw, int64_t *indices, void *ws, size_t ws_bytes, int io_u8, int swap_rb)
 {
     int rc = check_ready(h);
     if (rc) return rc;
     FEMASR_REQUIRE(in_nchw && out_nchw && ws && B > 0 && H > 0 && W > 0, "forward: bad args");
+    FEMASR_REQUIRE(!io_u8 || h->cfg.in_channel == 3, "forward_u8: 3-channel images only");
     FEMASR_REQUIRE(((uintptr_t)ws & 255) == 0, "forward: workspace must be 256-byte aligned");
     DeviceGuard guard(h->cfg.device);
     FEMASR_REQUIRE(guard.ok, "forward: hipSetDevice(%d) failed", h->cfg.device);
@@ -1139,15 +1145,15 @@ int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, 
     if (S <= 1) {
         Arena a;
         a.reset(ws, ws_bytes, false);
-        return run_forward(h, &a, caller, in_nchw, B, H, W, pad_mode, out_nchw, indices ? qbase : nullptr);
+        return run_forward(h, &a, caller, in_nchw, B, H, W, pad_mode, out_nchw, indices ? qbase : nullptr, io_u8, swap_rb);
     }
     // fork: every sub-batch stream waits for the caller's stream; join: the caller's stream waits for all of them.
     // Only event dependencies are added — no host synchronisation.
     size_t total = 0;
     for (size_t n : *need) total += n;
     if (total > ws_bytes) return femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small for %d sub-batches", S);
-    const size_t in_stride = (size_t)h->cfg.in_channel * H * W;
-    const size_t out_stride = (size_t)3 * g.crop_h * g.crop_w;
+    const size_t in_stride = (size_t)h->cfg.in_channel * H * W * ((io_u8 & 1) ? 1 : 4);            // bytes per sample
+    const size_t out_stride = (size_t)3 * g.crop_h * g.crop_w * ((io_u8 & 2) ? 1 : 4);
     FEMASR_CHECK_HIP(hipEventRecord(h->ev_fork, caller));
     size_t off = 0;
     int forked = 0;
@@ -1162,8 +1168,8 @@ int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, 
         forked = i + 1;
         int64_t *qsub[FEMASR_MAX_CODEBOOKS];
         for (int q = 0; q < FEMASR_MAX_CODEBOOKS; ++q) qsub[q] = qbase[q] ? qbase[q] + lo * qstride[q] : nullptr;
-        rc = run_forward(h, &a, st, in_nchw + lo * in_stride, hi - lo, H, W, pad_mode, out_nchw + lo * out_stride,
-                         indices ? qsub : nullptr);
+        rc = run_forward(h, &a, st, (const float *)((const char *)in_nchw + lo * in_stride), hi - lo, H, W, pad_mode,
+                         (float *)((char *)out_nchw + lo * out_stride), indices ? qsub : nullptr, io_u8, swap_rb);
     }
     // join every stream that was forked - also on an error, so that nothing still runs on ws / out when the caller's
     // stream continues
@@ -1173,6 +1179,18 @@ int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, 
         }
     }
     return rc;
+}
+
+int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, int H, int W, int pad_mode,
+                   float *out_nchw, int64_t *indices, void *ws, size_t ws_bytes)
+{
+    return forward_impl(h, stream, in_nchw, B, H, W, pad_mode, out_nchw, indices, ws, ws_bytes, 0, 0);
+}
+
+int femasr_forward_u8(femasr_handle *h, void *stream, const uint8_t *in_hwc, int B, int H, int W, int swap_rb, int pad_mode,
+                      uint8_t *out_hwc, int64_t *indices, void *ws, size_t ws_bytes)
+{
+    return forward_impl(h, stream, (const float *)in_hwc, B, H, W, pad_mode, (float *)out_hwc, indices, ws, ws_bytes, 3, swap_rb ? 1 : 0);
 }
 
 int femasr_decode_workspace_bytes(const femasr_handle *hc, int B, int hq, int wq, size_t *bytes)

@@ -73,17 +73,20 @@ def main(argv=None):
     for path in paths:
         img_name = os.path.basename(path)
         rgb = np.array(Image.open(path).convert('RGB'))                   # cv2.imread + BGR2RGB == RGB
-        x = imgproc.u8_to_input(torch.from_numpy(rgb).to(dev))
-        h, w = x.shape[2:]
+        xu8 = torch.from_numpy(rgb).to(dev)
+        h, w = rgb.shape[:2]
         if h * w < args.max_size ** 2:
-            out = model.test(x)
-        elif world > 1:
-            out = fd.test_tile_parallel(model, x, args.tile_size, args.tile_pad)
+            # whole image: ONE native call, uint8 in -> uint8 out (decode fused into the pad kernel, tensor2img into the crop kernel)
+            u8 = model.test_u8(xu8) if rank == 0 else None
         else:
-            out = model.test_tile(x, args.tile_size, args.tile_pad)
+            x = imgproc.u8_to_input(xu8)
+            if world > 1:
+                out = fd.test_tile_parallel(model, x, args.tile_size, args.tile_pad)
+            else:
+                out = model.test_tile(x, args.tile_size, args.tile_pad)
+            u8 = imgproc.output_to_u8(out) if rank == 0 else None
         if rank == 0:
-            u8 = imgproc.output_to_u8(out).cpu().numpy()
-            Image.fromarray(u8, 'RGB').save(os.path.join(args.output, img_name))
+            Image.fromarray(u8.cpu().numpy(), 'RGB').save(os.path.join(args.output, img_name))
     if world > 1:
         torch.distributed.barrier()
 

@@ -101,6 +101,16 @@ int femasr_forward_shapes(const femasr_handle *h, int H, int W, int pad_mode, in
 int femasr_forward(femasr_handle *h, void *stream, const float *in_nchw, int B, int H, int W,
                    int pad_mode, float *out_nchw, int64_t *indices, void *ws, size_t ws_bytes);
 
+/* The same forward on uint8 images, the step either side of the path fused into its first and last kernel: in (B,H,W,3)
+ * uint8 HWC (swap_rb = 1: cv2's BGR) -> (float)u8 / 255.0f inside the mirror-pad kernel (img2tensor + `/255.`: basicsr/utils/img_util.py:9-35,
+ * inference_femasr.py:54-56); out (B,out_h,out_w,3) uint8 HWC = clamp [0,1], x255, round half to even inside the crop kernel (tensor2img,
+ * img_util.py:38-94, inference_femasr.py:64-67).  No fp32 NCHW image makes a pass of its own; same bits as femasr_image_u8_to_f32 ->
+ * femasr_forward -> femasr_image_f32_to_u8. */
+int femasr_forward_u8(femasr_handle *h, void *stream, const uint8_t *in_hwc, int B, int H, int W, int swap_rb, int pad_mode,
+                      uint8_t *out_hwc, int64_t *indices, void *ws, size_t ws_bytes);
+int femasr_pad_u8hwc_to_nhwc(void *stream, const uint8_t *in, int B, int H, int W, int swap_rb, int Hp, int Wp, float *out);
+int femasr_crop_nhwc_to_u8hwc(void *stream, const float *in, int B, int Hs, int Ws, int Hc, int Wc, int swap_rb, uint8_t *out);
+
 /* indices (B,1,h,w) int64 -> image NCHW (B,3,8h,8w).  Replaces FeMaSRNet.decode_indices
  * (femasr_arch.py:376-385) incl. VectorQuantizer.get_codebook_entry (:102-112). */
 int femasr_decode_workspace_bytes(const femasr_handle *h, int B, int hq, int wq, size_t *bytes);

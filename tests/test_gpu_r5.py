@@ -191,3 +191,41 @@ def test_multi_codebook_nets_run_winograd_behind_the_last_lookup(cuda_device, na
     assert np.array_equal(y.cpu().numpy(), yo), float(np.abs(y.cpu().numpy() - yo).max())
     assert float(np.abs(y.cpu().numpy() - g['output']).max()) < 1e-3
     print(f'{name}: Winograd-form launches {wino}, direct-form launches {sum(direct.values())}')
+
+
+def test_forward_u8_fused_pre_post(cuda_device):
+    """femasr_forward_u8 / FeMaSRNet.test_u8: uint8 HWC in -> uint8 HWC out in one native call (decode fused into the mirror-pad kernel,
+    tensor2img into the crop kernel) == imgproc.u8_to_input -> test() -> imgproc.output_to_u8 bit for bit, for RGB
+    and BGR, a batch, ragged sizes, and several sub-batch streams; the two stand-alone kernels against numpy."""
+    import gpu_utils as G
+    from femasr_amd import imgproc
+    net = G.build_net('x4', synth_weights('x4', 2, 'trained'), cuda_device, decoder_math='fp32')
+    rng = np.random.default_rng(0)
+    for (b, h, w, bgr, streams) in [(1, 24, 40, False, 1), (1, 33, 17, True, 1), (3, 20, 28, False, 2)]:
+        net.num_streams = streams
+        img = torch.from_numpy(rng.integers(0, 256, (b, h, w, 3), dtype=np.uint8)).to(cuda_device)
+        ref = torch.stack([imgproc.output_to_u8(net.test(imgproc.u8_to_input(img[i], bgr=bgr)), bgr=bgr) for i in range(b)])
+        got = net.test_u8(img, bgr=bgr)
+        assert got.dtype == torch.uint8 and tuple(got.shape) == (b, 4 * h, 4 * w, 3)
+        assert torch.equal(got, ref), int((got != ref).sum())
+        if b == 1:
+            assert torch.equal(net.test_u8(img[0], bgr=bgr), ref[0])
+    with pytest.raises(ValueError):
+        net.test_u8(torch.zeros((4, 4, 3), dtype=torch.float32, device=cuda_device))
+    # the kernels on their own
+    lib = _lib.load()
+    u = rng.integers(0, 256, (2, 5, 7, 3), dtype=np.uint8)
+    tu = torch.from_numpy(u).to(cuda_device)
+    out = torch.empty((2, 8, 8, 3), dtype=torch.float32, device=cuda_device)
+    _lib.check(lib.femasr_pad_u8hwc_to_nhwc(None, _lib.ptr(tu), 2, 5, 7, 1, 8, 8, _lib.ptr(out)))
+    ys = np.array([y if y < 5 else 9 - y for y in range(8)])
+    xs = np.array([x if x < 7 else 13 - x for x in range(8)])
+    want = (u[:, ys][:, :, xs][..., ::-1].astype(np.float32) / np.float32(255.0))
+    assert np.array_equal(out.cpu().numpy(), want)
+    f = (rng.standard_normal((2, 6, 9, 3)) * 0.6 + 0.5).astype(np.float32)
+    f[0, 0, 0] = [0.5 / 255, 1.5 / 255, 2.5 / 255]          # ties: round half to even
+    tf = torch.from_numpy(f).to(cuda_device)
+    o8 = torch.empty((2, 4, 5, 3), dtype=torch.uint8, device=cuda_device)
+    _lib.check(lib.femasr_crop_nhwc_to_u8hwc(None, _lib.ptr(tf), 2, 6, 9, 4, 5, 0, _lib.ptr(o8)))
+    want8 = np.round(np.clip(f[:, :4, :5], 0, 1) * np.float32(255.0)).astype(np.uint8)
+    assert np.array_equal(o8.cpu().numpy(), want8)
