@@ -229,3 +229,54 @@ def test_forward_u8_fused_pre_post(cuda_device):
     _lib.check(lib.femasr_crop_nhwc_to_u8hwc(None, _lib.ptr(tf), 2, 6, 9, 4, 5, 0, _lib.ptr(o8)))
     want8 = np.round(np.clip(f[:, :4, :5], 0, 1) * np.float32(255.0)).astype(np.uint8)
     assert np.array_equal(o8.cpu().numpy(), want8)
+
+
+def test_config4_x2_at_stated_batch_32(cuda_device):
+    """BASELINE config 4 at its stated batch (configs 4 / 5 had only run at B = 4 / 2 inside a test): x2, 32 tiles of 256x256 ->
+    512x512 in the product default mode, three sub-batch streams.  Determinism (two runs equal), batch invariance (a tile alone == the tile in
+    the batch, output and index map), and the fixture's own tile planted at position 17: indices == the reference's, output within 1e-3 of the
+    reference golden (`x2_tile256_trained`)."""
+    import gpu_utils as G
+    g = load_golden('x2_tile256_trained')
+    w = synth_weights('x2', int(g['seed']), str(g['codebook']))
+    net = G.build_net('x2', w, cuda_device, decoder_math='fp32')
+    net.num_streams = 3
+    x = synth.synth_input(40, (32, 3, 256, 256))
+    x[17] = synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))[0]
+    xt = torch.from_numpy(x).to(cuda_device)
+    y, idx = net.test_with_indices(xt)
+    assert y.shape == (32, 3, 512, 512) and idx.shape == (32, 1, 72, 72) and torch.isfinite(y).all()
+    y2, idx2 = net.test_with_indices(xt)
+    assert torch.equal(y, y2) and torch.equal(idx, idx2)
+    for k in (0, 17, 31):
+        y1, i1 = net.test_with_indices(xt[k:k + 1])
+        assert torch.equal(y1[0], y[k]) and torch.equal(i1[0], idx[k]), k
+    st = int(g['out_stride'])
+    nbad, _ = check_indices_near_tie(idx[17].cpu().numpy(), g)
+    assert nbad == 0
+    assert float(np.abs(y[17].cpu().numpy()[:, ::st, ::st] - g['output'][0]).max()) < 1e-3
+
+
+def test_config5_hq_at_stated_batch_8(cuda_device):
+    """BASELINE config 5 at its stated batch: HQ autoencode `forward` of 8 images of 512x512 (no pad, no Swin stage): determinism, batch
+    invariance, decode_indices(indices) == the forward's image up to the straight-through rounding, and the fixture's image planted at
+    position 5 against the reference golden (`hq_full512_trained`)."""
+    import gpu_utils as G
+    g = load_golden('hq_full512_trained')
+    w = synth_weights('hq', int(g['seed']), str(g['codebook']))
+    net = G.build_net('hq', w, cuda_device, decoder_math='fp32')
+    net.num_streams = 2
+    x = synth.synth_input(41, (8, 3, 512, 512))
+    x[5] = synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))[0]
+    xt = torch.from_numpy(x).to(cuda_device)
+    out, _, _, il = net(xt)
+    assert out.shape == (8, 3, 512, 512) and il[0].shape == (8, 1, 64, 64) and torch.isfinite(out).all()
+    out2, _, _, il2 = net(xt)
+    assert torch.equal(out, out2) and torch.equal(il[0], il2[0])
+    for k in (0, 5, 7):
+        o1, _, _, i1 = net(xt[k:k + 1])
+        assert torch.equal(o1[0], out[k]) and torch.equal(i1[0][0], il[0][k]), k
+    assert float((net.decode_indices(il[0]) - out).abs().max()) < 1e-5
+    st = int(g['out_stride'])
+    assert np.array_equal(il[0][5].cpu().numpy().reshape(-1), g['vq_indices'].reshape(-1))
+    assert float(np.abs(out[5].cpu().numpy()[:, ::st, ::st] - g['output'][0]).max()) < 1e-3
