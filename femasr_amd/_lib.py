@@ -115,6 +115,7 @@ SIGNATURES = {
     'femasr_conv_small_launch_blocks': (c_int, [c_int]),
     'femasr_debug_wino_limits': (c_int, [c_int, c_int]),
     'femasr_debug_wino_form': (c_int, [c_int]),
+    'femasr_debug_wino_mphase': (c_int, [c_int]),
     'femasr_clock_probe_entries': (c_int, []),
     'femasr_mlp_fused': (c_int, [vp, vp, c_i64, c_int, c_int, vp, vp, vp, vp, vp, vp]),
 }

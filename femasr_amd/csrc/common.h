@@ -67,6 +67,7 @@ const char *femasr_mlp_fused_variant_name();
 size_t femasr_wino_limit_total();       // element limits of the Winograd-form kernels (2^31 / 2^27 per image; femasr_debug_wino_limits)
 size_t femasr_wino_limit_image();
 bool femasr_conv_wino_shape_ok(const femasr_conv_args *a);
+bool femasr_wino_mphase_bf16();       // default-mode F(4x4) convs run their M phase on the bf16 matrix pipe (FEMASR_WINO_M / femasr_debug_wino_mphase)
 int femasr_conv_wino_gn_tiles(int H, int W);      // fused GroupNorm partials of a Winograd conv: one per 16x16-pixel sub-block
 int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out);
 bool femasr_wino_c128_shape(int Cin, int Cout);      // kernels_wino_c128.hip: this layer runs (and its weights are packed) in the 16x16 x 128 block shape

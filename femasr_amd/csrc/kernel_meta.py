@@ -98,6 +98,9 @@ def table(rows):
 # kernels ON the default schedule that still touch scratch, with the bytes per thread they may use (a regression gate: the build fails
 # when one grows or a new one appears).  All of it is epilogue / setup state, none inside a main loop (DESIGN.md 5 "scratch"):
 KNOWN_SCRATCH = {
+    'conv3x3_wino4_kernelILi1ELb1ELi1ELi1E': 24,   # ... with the M phase on the bf16 matrix pipe (MM = 1): prologue / output stage only, as above
+    'conv3x3_wino4_kernelILi1ELb1ELi0ELi1E': 8,
+    'conv3x3_wino4_kernelILi1ELb1ELi2ELi1E': 188,
     'conv3x3_wino4_kernelILi1ELb1ELi1E': 40,       # F(4x4) conv, GN prologue, one residual: 8 dword stores + loads per thread in the output stage
     'conv3x3_wino4_kernelILi1ELb0ELi1E': 24,       # the same, 'fp32_strict'
     'conv3x3_wino4_kernelILi0ELb0ELi1E': 40,       # (no prologue, one residual: C ABI only)

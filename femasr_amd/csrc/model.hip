@@ -459,7 +459,7 @@ struct Ctx {
             variant += femasr_conv_variant_count();
         } else if (wino_w) {
             a.w_wino = wino_w;
-            a.fast_act = h->decoder_math == 0 ? 1 : 0;
+            a.fast_act = h->decoder_math == 0 ? (femasr_wino_mphase_bf16() && !o.up2 ? 2 : 1) : 0;      // 2: + the M phase on the bf16 matrix pipe (kernels_wino.hip MM = 1)
             if (o.up2) {
                 r = femasr_conv_wino_up2_launch(s(), &a, &flops);
                 variant = femasr_conv_wino_variant_count();          // the slot behind the F(4x4,3x3) variants

@@ -185,7 +185,9 @@ typedef struct {
     int32_t fast_act;     /* Winograd convs with the GN+SiLU prologue only: 1 = SiLU through the hardware exp2 / rcp units
                              (v_exp_f32, v_rcp_f32: 1 ulp each) instead of the IEEE-exact polynomial + division - ~6x fewer
                              VALU instructions in the staging; output within ~1e-6 relative of the exact form (no longer
-                             bit-identical to the oracle).  0 = exact. */
+                             bit-identical to the oracle).  0 = exact.  2 (round 5) = 1 + the M phase of the F(4x4,3x3) form (not the x2 form) on the
+                             bf16 matrix pipe: V and U split exactly into three bf16 terms, six partial products (v_mfma_f32_32x32x8_bf16_1k),
+                             fp32 accumulation - fp32-grade, output within ~1e-6 relative of fast_act = 1. */
     const float *in_add;  /* optional second INPUT tensor of the same (B,H,W,Cin) shape: the conv reads in + in_add (one fp32 add per
                              element while staging).  Only the x2 Winograd-type form takes it (up2 = 1 with w_wino; anything else refuses):
                              FeMaSRNet's decoder adds the encoder's skip feature to a stage's input (`x = x + enc_feats[i]`,
@@ -360,6 +362,9 @@ int femasr_debug_wino_limits(int log2_total, int log2_image);
  * (femasr_repack_oihw_wino follows the setting): weights packed under one setting must be launched under the same one - set it
  * before femasr_finalize_weights / femasr_repack_oihw_wino.  Process-global, atomic.  Returns FEMASR_OK. */
 int femasr_debug_wino_form(int c128);
+/* Test / measurement hook: 1 = the F(4x4,3x3) convs of decoder math 0 ('fp32', the default) run their M phase on the bf16 matrix pipe
+ * (femasr_conv_args.fast_act = 2), 0 = on the fp32 MFMA, < 0 = what the environment says (FEMASR_WINO_M=bf16|fp32).  Process-global, atomic. */
+int femasr_debug_wino_mphase(int bf16);
 
 #ifdef __cplusplus
 }

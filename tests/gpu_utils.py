@@ -94,7 +94,7 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     a.w_bf16x3 = None if wsplit is None else wsplit.data_ptr()
     a.w_up2 = None if wup2 is None else wup2.data_ptr()
     a.w_wino = None if wwino is None else wwino.data_ptr()
-    a.fast_act = int(bool(fast_act))
+    a.fast_act = int(fast_act)      # 0 exact, 1 hardware SiLU, 2 = 1 + the F(4x4) M phase on the bf16 matrix pipe
     a.w_bf16s = None if wlin3 is None else wlin3.data_ptr()
     tadd = None if in_add is None else dev(in_add)
     a.in_add = None if tadd is None else tadd.data_ptr()

@@ -62,6 +62,7 @@ def main():
     ap.add_argument('--wino', action='store_true', help='Winograd F(4x4,3x3) form (fp32)')
     ap.add_argument('--gn-part', action='store_true')
     ap.add_argument('--fast-act', action='store_true', help='Winograd + --gn: SiLU on the hardware exp2 / rcp units (the model default)')
+    ap.add_argument('--bf16m', action='store_true', help='--wino --gn --fast-act + the M phase on the bf16 matrix pipe (fast_act = 2, round 5)')
     ap.add_argument('--k1', action='store_true', help='1x1 conv / nn.Linear (fp32 igemm path)')
     ap.add_argument('--gelu', action='store_true')
     ap.add_argument('--iters', type=int, default=10)
@@ -105,7 +106,7 @@ def main():
             ww = torch.empty(int(lib.femasr_wino_weight_floats(cout, cin)), device=dev)
             _lib.check(lib.femasr_repack_oihw_wino(None, _lib.ptr(w_oihw), cout, cin, _lib.ptr(ww)))
         args.w_wino = ww.data_ptr(); keep.append(ww)
-        args.fast_act = int(a_.fast_act)
+        args.fast_act = 2 if a_.bf16m else int(a_.fast_act)
     if not a_.fp32 and not a_.k1 and not a_.wino:
         ws = torch.empty(int(lib.femasr_packed_weight_bf16x3_bytes(cout, cin, 3, 3)), dtype=torch.uint8, device=dev)
         _lib.check(lib.femasr_repack_oihw_bf16x3(None, _lib.ptr(w_oihw), cout, cin, 3, 3, _lib.ptr(ws)))
