@@ -232,16 +232,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
         chunk(c + 1, ar[1], ar[0]);
     }
     GS_STAMP(te);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // no copy may still be writing LDS when the epilogue re-uses it
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
     // out = act((hi + lo) + bias) + res1 + res2, in that order.  Each 32 x 32 tile goes through a per-wave LDS scratch so that lane l
     // owns columns 4 (l & 7) .. +3 of tile rows (l >> 3) + 8 k: float4 loads / stores (the epilogue of kernels_gemm.hip).
+    // Bias (two column tiles) and the residual rows of the first tile are requested BEFORE the last barrier, the residuals of tile t + 1 before
+    // tile t is processed: one exposed round trip per block instead of one per tile (each tile waited for its own bias / residual loads:
+    // ~2.5 k of the 11 k epilogue cycles, profiles/r05_gemm_bf16s_ubench.txt).
+    // (first: every asm load / copy of the main loop has landed - the compiler does not know that the register sets of the surplus row loads
+    // are still being written and would reuse them for the addresses below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float *T = reinterpret_cast<float *>(smem_raw) + wave * TSCRATCH;
     const int trow = lane >> 3, tq = lane & 7;
     const float *ra = p.res1 ? p.res1 : p.res2, *rb = (p.res1 && p.res2) ? p.res2 : nullptr;
     const bool vec = (p.N & 3) == 0;
+    f32x4_t bpre[2] = {}, r1[2][4] = {}, r2[2][4] = {};
+    auto fetch_res = [&](int tl, f32x4_t (&d1)[4], f32x4_t (&d2)[4]) {
+        if (NRES == 0 || !vec) return;
+        const int rbase = m0 + (wm * 2 + (tl >> 1)) * 32, col = n0 + (wn * 2 + (tl & 1)) * 32 + 4 * tq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = rbase + trow + 8 * k;
+            const size_t o = (col < p.N && row < p.M) ? (size_t)row * p.N + col : 0;
+            d1[k] = *reinterpret_cast<const f32x4_t *>(ra + o);
+            if (NRES >= 2) d2[k] = *reinterpret_cast<const f32x4_t *>(rb + o);
+        }
+    };
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + (wn * 2 + j) * 32 + 4 * tq;
+            bpre[j] = *reinterpret_cast<const f32x4_t *>(p.bias + (col < p.N ? col : 0));
+        }
+    }
+    fetch_res(0, r1[0], r2[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (no copy is still writing LDS: vmcnt(0) above; the bias / residual requests stay in flight across the barrier)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) {
         const int i = tl >> 1, j = tl & 1;
@@ -249,20 +274,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
         if (vec) {
             const int col = cbase + 4 * tq;
             const bool cok = col < p.N;
-            f32x4_t r1[4], r2[4];
-            if (NRES >= 1) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int row = rbase + trow + 8 * k;
-                    const bool ok = cok && row < p.M;
-                    const size_t o = ok ? (size_t)row * p.N + col : 0;
-                    r1[k] = *reinterpret_cast<const f32x4_t *>(ra + o);
-                    if (NRES >= 2) r2[k] = *reinterpret_cast<const f32x4_t *>(rb + o);
-                }
-            }
+            if (tl + 1 < 4) fetch_res(tl + 1, r1[(tl + 1) & 1], r2[(tl + 1) & 1]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TPITCH + c31] = hi[i][j][r] + lo[i][j][r];
-            const f32x4_t b4 = *reinterpret_cast<const f32x4_t *>(p.bias + (cok ? col : 0));
+            const f32x4_t b4 = bpre[j];
             // (same wave wrote and reads the scratch: LDS ops of one wave complete in order)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -274,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (NRES >= 1) v[e] = v[e] + r1[k][e];
-                    if (NRES >= 2) v[e] = v[e] + r2[k][e];
+                    if (NRES >= 1) v[e] = v[e] + r1[tl & 1][k][e];
+                    if (NRES >= 2) v[e] = v[e] + r2[tl & 1][k][e];
                 }
                 const int row = rbase + trow + 8 * k;
                 if (cok && row < p.M && (!(GS_ABL & 16) || v[0] == 123.456f))
