@@ -24,7 +24,9 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, gate='fail'):
+    """gate: what the scratch-memory check (kernel_meta.py) does when a kernel of the default schedule newly uses scratch: 'fail' raises
+    (the developer's build), 'warn' prints the table (the driver's build check: a toolchain drift must not hide the library), 'off' skips it."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs, jobs = [], []
@@ -45,12 +47,18 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-    if jobs and os.environ.get('FEMASR_SKIP_SCRATCH_CHECK') != '1':
+    if jobs and gate != 'off' and os.environ.get('FEMASR_SKIP_SCRATCH_CHECK') != '1':
         # gate: no kernel of the default schedule may (newly) use scratch memory - kernel_meta.py reads the code objects' metadata
         sys.path.insert(0, HERE)
         import kernel_meta
-        _, bad = kernel_meta.check()
-        if bad:
+        try:
+            _, bad = kernel_meta.check()
+        except Exception as e:              # (llvm-readelf missing, another object layout: the gate is a check, not a dependency)
+            print(f'kernel_meta: scratch check skipped ({type(e).__name__}: {e})', flush=True)
+            bad = []
+        if bad and gate == 'warn':
+            print('WARNING: kernels of the default schedule use (more) scratch memory:\n' + kernel_meta.table(bad), flush=True)
+        elif bad:
             raise RuntimeError('kernels of the default schedule use (more) scratch memory:\n' + kernel_meta.table(bad) +
                                '(fix the spill, or list the instantiation in kernel_meta.py with the reason)')
     return SO

@@ -27,8 +27,9 @@ def run(name, r2):
     x = torch.from_numpy(synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))).cuda()
     st = int(g['out_stride']) if 'out_stride' in g else 1
     res = {}
-    for math in ('fp32_direct', 'fp32_strict', 'fp32', 'bf16x3'):
-        net.decoder_math = math
+    for math in ('fp32_direct', 'fp32_strict', 'fp32', 'bf16x3', 'fp32+fp32_linears'):
+        net.linear_math = 'fp32' if math.endswith('fp32_linears') else 'bf16_split'
+        net.decoder_math = math.split('+')[0]
         if str(g['mode']) == 'test':
             y, idx = net.test_with_all_indices(x)
         else:
@@ -37,7 +38,8 @@ def run(name, r2):
         res[math] = (float(np.abs(y - g['output']).max()), int((idx[0].cpu().numpy().reshape(-1) != g['vq_indices'].reshape(-1)).sum()), y)
     d = lambda a, b: float(np.abs(res[a][2] - res[b][2]).max())
     print(f'{name:22s} |out|max {float(np.abs(g["output"]).max()):8.3f}  vs reference: direct {res["fp32_direct"][0]:.2e} strict(F4x4) {res["fp32_strict"][0]:.2e} '
-          f'fp32(default) {res["fp32"][0]:.2e} bf16x3 {res["bf16x3"][0]:.2e} (idx mismatches {res["fp32"][1]});  '
+          f'fp32(default) {res["fp32"][0]:.2e} bf16x3 {res["bf16x3"][0]:.2e} default with fp32-chain linears {res["fp32+fp32_linears"][0]:.2e} '
+          f'(idx mismatches: default {res["fp32"][1]}, fp32-chain linears {res["fp32+fp32_linears"][1]});  '
           f'strict vs direct {d("fp32_strict", "fp32_direct"):.2e}  default vs strict {d("fp32", "fp32_strict"):.2e}  bf16x3 vs strict {d("bf16x3", "fp32_strict"):.2e}', flush=True)
 
 
