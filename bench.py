@@ -90,7 +90,7 @@ def merge_wino_slots(convs):
         kk = re.sub(r'^(conv3x3_wino4<.*),res=\d,', r'\1,res=*,', k)
         if kk in out:
             o = out[kk]
-            out[kk] = (o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3])
+            out[kk] = (o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3])
         else:
             out[kk] = tuple(v)
     return out
@@ -574,7 +574,7 @@ def main():
             def roof(name):
                 """`achieved` / `frac` are PHYSICAL: the flops the MFMA pipe executes per second and their share of the dense peak
                 (<= 1).  The layer definition's (algorithmic) flops over the same time are reported beside them."""
-                ms, n, fl, _ = convs[name]
+                ms, n, fl, alg_bytes = convs[name]
                 split = name.startswith('conv3x3_halo_bf16x3')
                 peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
                 alg = fl / (ms * 1e-3) / 1e12
@@ -583,6 +583,7 @@ def main():
                 out = {'bound': 'mfma', 'kernel': name, 'achieved': round(alg * share, 2), 'peak': peak, 'unit': 'TFLOP/s',
                        'frac': round(alg * share / peak, 4),
                        'traffic': round((rec['fetch_bytes_corrected'] + rec['write_bytes']) / 1e9, 4) if rec else None,
+                       'algorithmic_GB_per_launch': round(alg_bytes / n / 1e9, 4) if alg_bytes else None,
                        'launches': n, 'avg_launch_ms': round(ms / n, 4),
                        'issued_gflop_per_launch': round(fl * share / n / 1e9, 3), 'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3),
                        'issued_share_of_algorithmic': round(share, 4),
@@ -604,6 +605,10 @@ def main():
                                              ('GB per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes on the BUILD box, commit-stamped there); NOT '
                                               're-measured in this run: rocprofv3 missing / failed or --no-measure-traffic'))
                     out['traffic_measured_live'] = bool(pmc_live)
+                    if alg_bytes and out['traffic']:
+                        # (every operand once: input, residual, output, weights; the kernel reads its input once per 64-channel column block
+                        # and a 18x18 halo per 16x16 pixels - what of that misses L2 / the Infinity Cache shows up here)
+                        out['traffic_over_algorithmic'] = round(out['traffic'] / (alg_bytes / n / 1e9), 3)
                 return out
             dom = max(convs, key=lambda k: convs[k][0])
             res['roofline'] = roof(dom)

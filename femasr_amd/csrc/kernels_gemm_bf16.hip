@@ -164,25 +164,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
     }
     const int boff = (wn * 2) * 192 + lane;      // + ct*192 + plane*64
 
-    // one 16-deep step: 24 MFMAs on the fragments of A half (s & 1) and W stage (s & 3)
-    auto compute = [&](int s) {
+    // one 16-deep step: 24 MFMAs on the fragments of A half (s & 1) and W stage (s & 3).
+    // GS_ORDER (tools/ubench A/B, profiles/r05_gemm_bf16s_ubench.txt "step order"): 0 = the scheduler places the twelve fragment reads (it spreads
+    // them between the MFMAs, an `s_waitcnt lgkmcnt(0)` in front of every second one); 1 = all twelve as one burst right behind the barrier, the
+    // step's VALU work (split of the next A granule, copy / load addresses) while they are in flight, then the MFMAs back to back; 2 = 1 with the
+    // next barrier fenced behind the MFMAs.  Measured equal within noise (qkv 193.7 / 197.0 / 197.0 us, fc1 300.8 / 302.3 / 301.8): the partner wave
+    // of the SIMD already covers the LDS round trips - the exposed reads are not what holds the kernel at ~0.4 of the bf16 pipe.  0 stays.
+#ifndef GS_ORDER
+#define GS_ORDER 0
+#endif
+    bf16x8 fa[3][2], fb[3][2];
+    auto load_frags = [&](int s) {
         const uint4 *As = Al + (s & 1) * GS_A_HALF;
         const uint4 *Ws = Wl + (s & (GS_W_STAGES - 1)) * GS_W_STAGE + boff;
-        bf16x8 a[3][2], b[3][2];
+        constexpr int order[3] = {2, 0, 1};              // planes in the order the products need them: a3 b1, a1 b3, a2 b2, ...
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int q = 0; q < 3; ++q) {
+            const int pa = order[q], pb = q == 0 ? 0 : (q == 1 ? 2 : 1);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) a[pl][rt] = __builtin_bit_cast(bf16x8, As[pl * 256 + aoff[rt]]);
+            for (int rt = 0; rt < 2; ++rt) fa[pa][rt] = __builtin_bit_cast(bf16x8, As[pa * 256 + aoff[rt]]);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) b[pl][ct] = __builtin_bit_cast(bf16x8, Ws[ct * 192 + pl * 64]);
+            for (int ct = 0; ct < 2; ++ct) fb[pb][ct] = __builtin_bit_cast(bf16x8, Ws[ct * 192 + pb * 64]);
+        }
+    };
+    auto mfmas = [&]() {
         // lo += a3 b1, a1 b3, a2 b2, a2 b1, a1 b2 ; hi += a1 b1   (consecutive instructions on different accumulators)
 #define GS_TERM(ACC, PA, PB)                                                                                       \
     _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                              \
         _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                          \
-            if (GS_ABL & 8) ACC[rt][ct][0] += (float)a[PA][rt][0] * (float)b[PB][ct][0];                          \
-            else ACC[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][rt], b[PB][ct], ACC[rt][ct], 0, 0, 0);
+            if (GS_ABL & 8) ACC[rt][ct][0] += (float)fa[PA][rt][0] * (float)fb[PB][ct][0];                        \
+            else ACC[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][rt], fb[PB][ct], ACC[rt][ct], 0, 0, 0);
         GS_TERM(lo, 2, 0)
         GS_TERM(lo, 0, 2)
         GS_TERM(lo, 1, 1)
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
         GS_TERM(hi, 0, 0)
 #undef GS_TERM
     };
+    auto compute = [&](int s) { load_frags(s); mfmas(); };
 
 #ifndef GS_TT
 #define GS_TT 0
@@ -214,18 +226,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
         asm volatile("s_waitcnt vmcnt(14)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (GS_ORDER) { load_frags(2 * c); __builtin_amdgcn_sched_barrier(0); }
         issueW(2 * c + 3);
         splitA(cur[2], cur[3], 1);                       // second half of chunk c -> read by step 2c + 1
-        compute(2 * c);
+        if (GS_ORDER) { __builtin_amdgcn_sched_barrier(0); mfmas(); if (GS_ORDER == 2) __builtin_amdgcn_sched_barrier(0); } else compute(2 * c);
         // ---- step 2c + 1: W(2c + 1) landed
         asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (GS_ORDER) { load_frags(2 * c + 1); __builtin_amdgcn_sched_barrier(0); }
         issueW(2 * c + 4);
         loadA(c + 2, cur);                               // both items of chunk c are split: the set is free
         asm volatile("s_waitcnt vmcnt(10)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) :: "memory");      // rows of chunk c + 1
         splitA(nxt[0], nxt[1], 0);                       // first half of chunk c + 1 -> read by step 2c + 2
-        compute(2 * c + 1);
+        if (GS_ORDER) { __builtin_amdgcn_sched_barrier(0); mfmas(); if (GS_ORDER == 2) __builtin_amdgcn_sched_barrier(0); } else compute(2 * c + 1);
     };
     for (int c = 0; c < nch; c += 2) {                   // (K % 64 == 0 is required by the launcher: the register sets alternate statically)
         chunk(c, ar[0], ar[1]);

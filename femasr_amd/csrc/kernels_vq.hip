@@ -32,6 +32,7 @@
 
 namespace {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -192,7 +193,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
     const int D = p.D, CH = D >> 3, S = D >> 4, SWM = (CH < 16 ? CH : 16) - 1, LCH = 31 - __builtin_clz(CH);
     uint4 *zt = reinterpret_cast<uint4 *>(smem_raw);                               // [128][CH] 16-B chunks, XOR-swizzled
     float *s_ee = reinterpret_cast<float *>(smem_raw + (size_t)VQ_R * D * 2);
-    volatile float *s_min = s_ee + p.n_e;                                          // [NW][128] running min of s, read without barriers
+    // (an explicit LDS pointer: through a generic `volatile float *` the address space is not inferred and every access becomes a flat one
+    // with a 64-bit address)
+    typedef __attribute__((address_space(3))) volatile float lds_vfloat;
+    typedef __attribute__((address_space(3))) const volatile f32x4_t lds_vfloat4;
+    lds_vfloat *s_min = (lds_vfloat *)(s_ee + p.n_e);                                          // [128][NW] running min of s, read without barriers
     float *s_e2 = s_ee + p.n_e + NW * VQ_R;                                        // [128] |z~|^2, then 2 Erow
     unsigned *s_cnt = reinterpret_cast<unsigned *>(s_e2 + VQ_R);
     unsigned short *s_code = reinterpret_cast<unsigned short *>(s_cnt + VQ_R);     // [128][VQ_CMAX]
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             smin[rt] = fminf(smin[rt], __shfl_xor(smin[rt], 32, 64));
-            if (h == 0) s_min[w * VQ_R + rt * 32 + c31] = smin[rt];
+            if (h == 0) s_min[(rt * 32 + c31) * NW + w] = smin[rt];
         }
         // first round: wait for every wave's first minima (NW * 64 codes seen) before emitting anything -- without it each
         // wave emits against its own 64 codes only and the raw lists fill with entries the final threshold rejects
@@ -333,9 +338,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             const int row = rt * 32 + c31;
-            // other waves' minima: possibly stale, always valid upper bounds of the row minimum
+            // every wave's minimum of the row (its own included): possibly stale, always valid upper bounds of the row minimum.  One row = NW
+            // consecutive floats: one per-lane address and immediates (per-wave planes needed 28 wrapped addresses, which were hoisted out of
+            // the pair loop and spilled: 52 dwords of scratch per thread)
+            static_assert(NW % 4 == 0, "row minima are read four at a time");
 #pragma unroll
-            for (int o = 1; o < NW; ++o) smin[rt] = fminf(smin[rt], s_min[((w + o) % NW) * VQ_R + row]);
+            for (int o = 0; o < NW; o += 4) {
+                const f32x4_t m4 = *(lds_vfloat4 *)(s_min + row * NW + o);
+                smin[rt] = fminf(fminf(smin[rt], fminf(m4[0], m4[1])), fminf(m4[2], m4[3]));
+            }
             thr[rt] = smin[rt] + e2[rt];
         }
         // survivors of this pair: one bit per accumulator, one list reservation per (tile, row tile), codes only (an entry
@@ -376,12 +387,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
     }
     // ---- exact phase: 512 lanes = 64 rows x 8 candidate slots, the block's rows in two halves
     static_assert(!FUSED || NW == 8, "the fused exact phase maps 64 rows x 8 slots onto 8 waves");
+    // (the thread id as an opaque value from here on: with the plain one every swizzled row address of this phase is loop-invariant for
+    // the search above, gets hoisted over it and lands in scratch memory - 56 dwords per thread - because the search owns the registers)
+    int te = t;
+    asm volatile("" : "+v"(te));
+    const int lane_e = te & 63, w_e = __builtin_amdgcn_readfirstlane(te >> 6);
     float *zf = reinterpret_cast<float *>(smem_raw);            // [64][D] fp32 over the dead bf16 image (64 * D * 4 = 128 * D * 2 bytes)
     const int D4 = D >> 2, LD4 = 31 - __builtin_clz(D4);
     for (int half = 0; half < 2; ++half) {
         const long long hrow0 = row0 + 64 * half;
         if (hrow0 >= p.M) break;                                 // (block-uniform)
-        for (int i0 = t; i0 < 64 * D4; i0 += NW * 64 * 8) {      // 8 loads in flight per thread, consecutive lanes walk a row
+        for (int i0 = te; i0 < 64 * D4; i0 += NW * 64 * 8) {      // 8 loads in flight per thread, consecutive lanes walk a row
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
             }
         }
         __syncthreads();
-        const int rl = t >> 3, sl = t & 7;                       // row of the half, candidate slot; a wave = 8 rows
+        const int rl = te >> 3, sl = te & 7;                       // row of the half, candidate slot; a wave = 8 rows
         const long long row = hrow0 + rl;
         const bool rok = row < p.M;
         const float *zrow = zf + rl * D;
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
                 code = (int)s_code[(64 * half + rl) * VQ_CMAX + k];
                 vq_chain_lds(zrow, rl & 7, p.cb + (size_t)code * D, D, acc, zacc);
             }
-            if (base == 0) zzr = __shfl(zacc, lane & ~7, 64);        // slot 0 is active whenever the row has a candidate
+            if (base == 0) zzr = __shfl(zacc, lane_e & ~7, 64);        // slot 0 is active whenever the row has a candidate
             const float d = (zzr + s_ee[code]) - 2.0f * acc;
             if (act && (d < bd || (d == bd && code < bi))) { bd = d; bi = code; }
         }
@@ -426,15 +442,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
         while (allmask) {
             const int l = __builtin_ctzll(allmask);
             allmask &= allmask - 1;
-            const int ra = (w * 64 + l) >> 3;
+            const int ra = (w_e * 64 + l) >> 3;
             float wd = INFINITY;
             int wi = 0x7fffffff;
             for (int j0 = 0; j0 < p.n_e; j0 += 64) {
-                const int code = j0 + lane;
+                const int code = j0 + lane_e;
                 float acc = 0.f, zacc = 0.f;
                 vq_chain_lds(zf + ra * D, ra & 7, p.cb + (size_t)code * D, D, acc, zacc);
                 const float d = (zacc + s_ee[code]) - 2.0f * acc;
-                if (d < wd) { wd = d; wi = code; }                   // ascending codes per lane: strict < keeps the first
+                if (d < wd) { wd = d; wi = code; }                   // ascending codes per lane_e: strict < keeps the first
             }
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) {
@@ -442,7 +458,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
                 const int oi = __shfl_xor(wi, sft, 64);
                 if (od < wd || (od == wd && oi < wi)) { wd = od; wi = oi; }
             }
-            if ((lane & ~7) == l) { bd = wd; bi = wi; }              // all eight lanes of that row
+            if ((lane_e & ~7) == l) { bd = wd; bi = wi; }              // all eight lanes of that row
         }
 #pragma unroll
         for (int sft = 4; sft >= 1; sft >>= 1) {
@@ -460,18 +476,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
                 const int b = __shfl(bi, (r0 + r) * 8, 64);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int c = lane * 4 + 256 * j;
+                    const int c = lane_e * 4 + 256 * j;
                     ev[r][j] = float4{0.f, 0.f, 0.f, 0.f};
                     if (c < D) ev[r][j] = ld4(p.cb + (size_t)b * D + c);
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int lr = w * 8 + r0 + r;
+                const int lr = w_e * 8 + r0 + r;
                 const long long rr = hrow0 + lr;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int c4 = lane + 64 * j;
+                    const int c4 = lane_e + 64 * j;
                     if (rr < p.M && 4 * c4 < D) {
                         const float4 zv = ld4(zf + lr * D + 4 * (c4 ^ (lr & 7))), ef = ev[r][j];
                         float4 q;

@@ -29,6 +29,9 @@
 #define FEMASR_WTT_BUF g_wi_ttbuf
 #include "wino_common.h"
 #include <string.h>
+#ifndef FEMASR_WINO_EPI_FENCE
+#define FEMASR_WINO_EPI_FENCE 1
+#endif
 #ifndef FEMASR_WINO_M_DEFAULT
 #define FEMASR_WINO_M_DEFAULT 0      // the M phase of the default-mode F(4x4) convs: 0 fp32 MFMA, 1 bf16 matrix pipe (see MM below)
 #endif
@@ -458,8 +461,12 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
         // network's 20 launches): only the upper two tile rows of both now, the lower two behind the first pass, whose registers they take -
         // all 64 values next to the other column tile's accumulators made the allocator spill accumulator tiles INSIDE the main loop
         // (5.6 GB of scratch writes per launch, 2.46 ms instead of 1.5: profiles/r04_run3_pmc_summary_streams1.txt)
-        if (HAS1) fetch(fullc, rs_r1, r, r1, 0, HAS2 ? 8 : 16);
-        if (HAS2) fetch(fullc, rs_r2, r, r2, 0, 8);
+        // A block on the image border (!FULL, rare: H or W not a multiple of 16) fetches row by row where the values are used: its 32 masked
+        // per-pixel offsets next to 32 residuals in flight pushed the allocator over 256 registers (11 dwords of scratch in every variant)
+        if (FULL) {
+            if (HAS1) fetch(fullc, rs_r1, r, r1, 0, HAS2 ? 8 : 16);
+            if (HAS2) fetch(fullc, rs_r2, r, r2, 0, 8);
+        }
         const float bv = p.bias[n0 + 32 * r + c31];
         __syncthreads();
         WTT(3 + 4 * r)
@@ -472,14 +479,22 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
             auto mx = [&](int c) -> tf2 { return c < 16 ? src0[c * 512] : (c < 32 ? src1[(c - 16) * 512] : src2[(c - 32) * 512]); };
             tf2 tt[4][6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
+            for (int j = 0; j < 6; ++j) {
                 at6(mx(0 * 6 + j), mx(1 * 6 + j), mx(2 * 6 + j), mx(3 * 6 + j), mx(4 * 6 + j), mx(5 * 6 + j), tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
-            if (HAS2) { fetch(fullc, rs_r1, r, r1, 8, 16); fetch(fullc, rs_r2, r, r2, 8, 16); }
+                if (FEMASR_WINO_EPI_FENCE && (j & 1)) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (FULL && HAS2) { fetch(fullc, rs_r1, r, r1, 8, 16); fetch(fullc, rs_r2, r, r2, 8, 16); }
             const tf2 bv2 = {bv, bv};
             tf2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 tf2 y[4];
+                if (!FULL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (HAS1) fetch(fullc, rs_r1, r, r1, 4 * a, 4 * a + 4);
+                    if (HAS2) fetch(fullc, rs_r2, r, r2, 4 * a, 4 * a + 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 at6(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {

@@ -368,8 +368,10 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4c_kernel(const WinoPara
         cs_u = __builtin_amdgcn_readfirstlane(p.Cout * 4);
         rs_u = __builtin_amdgcn_readfirstlane(p.W * p.Cout * 4);
         asm volatile("" : "+s"(cs_u), "+s"(rs_u));
-        if (HAS1) fetch(fullc, rs_r1, r, r1, 0, HAS2 ? 8 : 16);
-        if (HAS2) fetch(fullc, rs_r2, r, r2, 0, 8);
+        if (FULL) {          // (a border block fetches row by row below: kernels_wino.hip)
+            if (HAS1) fetch(fullc, rs_r1, r, r1, 0, HAS2 ? 8 : 16);
+            if (HAS2) fetch(fullc, rs_r2, r, r2, 0, 8);
+        }
         const float bv = p.bias[n0 + 64 * r + lane];
         __syncthreads();
         WTT(3 + 4 * r)
@@ -383,12 +385,18 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4c_kernel(const WinoPara
 #pragma unroll
             for (int j = 0; j < 6; ++j)
                 at6(mx(0 * 6 + j), mx(1 * 6 + j), mx(2 * 6 + j), mx(3 * 6 + j), mx(4 * 6 + j), mx(5 * 6 + j), tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
-            if (HAS2) { fetch(fullc, rs_r1, r, r1, 8, 16); fetch(fullc, rs_r2, r, r2, 8, 16); }
+            if (FULL && HAS2) { fetch(fullc, rs_r1, r, r1, 8, 16); fetch(fullc, rs_r2, r, r2, 8, 16); }
             const tf2 bv2 = {bv, bv};
             tf2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 tf2 y[4];
+                if (!FULL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (HAS1) fetch(fullc, rs_r1, r, r1, 4 * a, 4 * a + 4);
+                    if (HAS2) fetch(fullc, rs_r2, r, r2, 4 * a, 4 * a + 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 at6(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {

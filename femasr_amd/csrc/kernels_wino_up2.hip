@@ -346,8 +346,10 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
         cs_u = __builtin_amdgcn_readfirstlane(p.Cout * 4);
         rs_u = __builtin_amdgcn_readfirstlane(p.Wo * p.Cout * 4);
         asm volatile("" : "+s"(cs_u), "+s"(rs_u));
-        if (HAS1) fetch(fullc, rs_r1, r, r1, 0, HAS2 ? 8 : 16);      // (two operands: upper tile rows now, lower ones behind the first pass - kernels_wino.hip)
-        if (HAS2) fetch(fullc, rs_r2, r, r2, 0, 8);
+        if (FULL) {          // (a border block fetches row by row below: kernels_wino.hip)
+            if (HAS1) fetch(fullc, rs_r1, r, r1, 0, HAS2 ? 8 : 16);      // (two operands: upper tile rows now, lower ones behind the first pass - kernels_wino.hip)
+            if (HAS2) fetch(fullc, rs_r2, r, r2, 0, 8);
+        }
         const float bv = p.bias[n0 + 32 * r + c31];
         __syncthreads();
         WUTT(3 + 4 * r)
@@ -362,12 +364,18 @@ __global__ __launch_bounds__(WU_NT, 2) void conv3x3_wino_up2_kernel(const WinoUp
 #pragma unroll
             for (int j = 0; j < 5; ++j)
                 at5(mx(0 * 5 + j), mx(1 * 5 + j), mx(2 * 5 + j), mx(3 * 5 + j), mx(4 * 5 + j), tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
-            if (HAS2) { fetch(fullc, rs_r1, r, r1, 8, 16); fetch(fullc, rs_r2, r, r2, 8, 16); }
+            if (FULL && HAS2) { fetch(fullc, rs_r1, r, r1, 8, 16); fetch(fullc, rs_r2, r, r2, 8, 16); }
             const tf2 bv2 = {bv, bv};
             tf2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 tf2 y[4];
+                if (!FULL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (HAS1) fetch(fullc, rs_r1, r, r1, 4 * a, 4 * a + 4);
+                    if (HAS2) fetch(fullc, rs_r2, r, r2, 4 * a, 4 * a + 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 at5(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], y[0], y[1], y[2], y[3]);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {

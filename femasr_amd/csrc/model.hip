@@ -224,6 +224,7 @@ struct Scope {   // event pair around one launch (or a small group of launches)
     }
     void set_slot(int s) { rec.slot = s; }
     void set_flops(double f) { rec.flops = f; }
+    void set_bytes(double b) { rec.bytes = b; }
     ~Scope()
     {
         if (!on) return;
@@ -472,6 +473,9 @@ struct Ctx {
         }
         sc.set_slot(SLOT_SMALL_COUNT + variant);
         sc.set_flops(flops);
+        // algorithmic bytes of the launch: every operand once - input (+ a second input), residuals, output, weights
+        sc.set_bytes(4.0 * ((double)x.numel() * (o.in_add ? 2 : 1) + (double)y.numel() * (1 + (o.res1 ? 1 : 0) + (o.res2 ? 1 : 0)) +
+                            (double)cout * x.C * o.ksz * o.ksz + cout));
         if (r && !rc) rc = r;
         return y;
     }

@@ -9,6 +9,7 @@
 #         other            bench.py for the other BASELINE configs (x2b32, hq8, tile2048)
 #         parity           tools/parity_report.py
 #         ubench_gemm      tools/ubench/gemm_bf16s (stand-alone split GEMM driver; UB_ARGS)
+#         pmc_calib        tools/ubench/pmc_calib under the FETCH_SIZE / WRITE_SIZE (+ request) counters: what the counters read for known bytes
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out; mkdir -p $O; TAG=${TAG:-r05}
 export TMPDIR=/tmp
@@ -34,6 +35,14 @@ for task in "$@"; do
       timeout 900 python tools/parity_report.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_parity_report.txt | tail -20 ;;
     ubench_gemm)
       (cd tools/ubench && GS_NOVERIFY=${GS_NOVERIFY:-1} GS_WARM=${GS_WARM:-400} timeout 300 ./gemm_bf16s ${UB_ARGS:-100}) 2>&1 | tee $O/${TAG}_ubench_gemm.log | tail -12 ;;
+    pmc_calib)
+      # known-bytes kernels under the FETCH_SIZE / WRITE_SIZE counters (tools/ubench/pmc_calib.hip; built here: hipcc cross-compiles)
+      R=$PWD; ( cd /tmp; rm -rf $R/$O/calib_*; B=$R/tools/ubench/pmc_calib
+        timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/$O/calib_w -o w -- $B > $R/$O/calib_w.log 2>&1; echo "write rc=$?"
+        timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/$O/calib_f -o f -- $B > $R/$O/calib_f.log 2>&1; echo "fetch rc=$?"
+        timeout 120 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace -d $R/$O/calib_q -o q -- $B > $R/$O/calib_q.log 2>&1; echo "wrreq rc=$?"
+        timeout 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace -d $R/$O/calib_r -o r -- $B > $R/$O/calib_r.log 2>&1; echo "rdreq rc=$?" )
+      python tools/rocpd_counters.py $(find $O/calib_w $O/calib_f $O/calib_q $O/calib_r -name "*.db") 2>&1 | tee $O/${TAG}_pmc_calib.txt | cut -c1-200 ;;
     *) echo "unknown task $task" ;;
   esac
 done
