@@ -29,6 +29,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -40,6 +41,10 @@ constexpr int VQ_R = 128;                  // rows per block of pass 1 (4 MFMA c
 constexpr int VQ_CMAX = 32;                // candidate slots per row (LDS list of pass 1 = the list handed to pass 2)
 constexpr int VQ_ALL = 0xFFFF;             // count marker: evaluate every code
 constexpr float VQ_EPS = 0.0042f;
+// one-launch form: line staging of the exact phase - per wave two buffers of (8 candidate slots + the rows of z) x 8 rows x 128 B
+constexpr int VQ_STAGE_BUF = 9 * 1024;
+constexpr int VQ_STAGE_BYTES = 8 * 2 * VQ_STAGE_BUF;              // 147 456: covers the bf16 image of the search (<= 131 072)
+__host__ __device__ constexpr size_t vq_fused_list0(int D) { return (size_t)VQ_R * D * 2 > (size_t)VQ_STAGE_BYTES ? (size_t)VQ_R * D * 2 : (size_t)VQ_STAGE_BYTES; }
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ unsigned pack_bf16(float a, float b)
@@ -145,46 +150,14 @@ __device__ __forceinline__ void vq_chain(const float *zr, const float *er, int D
     }
 }
 
-// The same two chains with the row of z in LDS (fp32, 16-byte chunks xor-swizzled by the row: the 8 rows a wave reads together sit in
-// different banks) and the code's row streamed from L2 one 128-byte burst ahead.  D % 64 == 0.  Operation order = vq_chain's.
-// (Three bursts ahead - 128 registers of code rows per lane - measured SLOWER: 336 against 311 us for the whole lookup at M = 82 944; every
-// lane walks its own 2-KB row, 16 bytes per request and line: the phase is bound by the texture addresser's line rate, not by latency.)
-__device__ __forceinline__ void vq_load_e(float4 (&e)[8], const float *er, int c)
-{
-#pragma unroll
-    for (int u = 0; u < 8; ++u) e[u] = ld4(er + c + 4 * u);
-}
-__device__ __forceinline__ void vq_chain_lds(const float *zrow, int sw, const float *er, int D, float &acc, float &zacc)
-{
-    float4 ea[8], eb[8];
-    vq_load_e(ea, er, 0);
-    for (int c = 0; c < D; c += 64) {
-        vq_load_e(eb, er, c + 32);
-        {
-            VqBurst b;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { b.z[u] = ld4(zrow + c + 4 * (u ^ sw)); b.e[u] = ea[u]; }
-            vq_chain_burst(b, acc, zacc);
-        }
-        if (c + 64 < D) vq_load_e(ea, er, c + 64);
-        {
-            VqBurst b;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { b.z[u] = ld4(zrow + c + 32 + 4 * (u ^ sw)); b.e[u] = eb[u]; }
-            vq_chain_burst(b, acc, zacc);
-        }
-    }
-}
-
 // pass 1.  Block = NW waves (2 per SIMD: one wave's bound arithmetic overlaps the other's MFMAs), 128 rows of z as a bf16
 // image in LDS (the MFMA B operand); wave w takes code-tile pairs w, w+NW, ..: per 16-deep k step 2 A fragments from global
 // (L2-resident packed codebook, 4-step register ring), 4 B fragments from LDS, 8 MFMAs.
 // Bound per row (see the header): every code's |d - zz - s| <= Erow, s = ee - 2 dot~, Erow = 2 VQ_EPS |z| |e|max + gz;
 // a code survives iff s <= min_j s_j + 2 Erow.
 // FUSED (round 4, the default): the block also runs the EXACT phase for its 128 rows - the lists never leave LDS, idx and z_q are written
-// here, ONE launch.  The bf16 image is dead after the search: its 128 KB take the fp32 rows of 64 rows at a time (re-read from L2 / MALL,
-// where this block's first read put them), lane = (row, candidate slot) walks the specified chains with z from LDS and the code's row
-// streamed from L2, and z_q = z + (e - z) is formed from the LDS copy.
+// here, ONE launch.  The bf16 image is dead after the search; round 5: its LDS becomes per-wave staging buffers through which the candidates'
+// code rows and the rows of z arrive line-coalesced (see the exact phase below), z_q = z + (e - z) is formed from registers.
 template <int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const VqCandParams p)
 {
@@ -192,14 +165,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, c31 = lane & 31, h = lane >> 5;
     const int D = p.D, CH = D >> 3, S = D >> 4, SWM = (CH < 16 ? CH : 16) - 1, LCH = 31 - __builtin_clz(CH);
     uint4 *zt = reinterpret_cast<uint4 *>(smem_raw);                               // [128][CH] 16-B chunks, XOR-swizzled
-    float *s_ee = reinterpret_cast<float *>(smem_raw + (size_t)VQ_R * D * 2);
+    // FUSED: the exact phase's line staging ring (8 waves x 2 x 9 KiB) takes the first 144 KiB once the image is dead; what it needs of the
+    // lists (ee, counts, codes) lies behind that, what only the search needs (running minima, the row bounds) inside its last 16 KiB
+    const size_t list0 = FUSED ? vq_fused_list0(D) : (size_t)VQ_R * D * 2;
+    float *s_ee = reinterpret_cast<float *>(smem_raw + list0);
     // (an explicit LDS pointer: through a generic `volatile float *` the address space is not inferred and every access becomes a flat one
     // with a 64-bit address)
     typedef __attribute__((address_space(3))) volatile float lds_vfloat;
     typedef __attribute__((address_space(3))) const volatile f32x4_t lds_vfloat4;
-    lds_vfloat *s_min = (lds_vfloat *)(s_ee + p.n_e);                                          // [128][NW] running min of s, read without barriers
-    float *s_e2 = s_ee + p.n_e + NW * VQ_R;                                        // [128] |z~|^2, then 2 Erow
-    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_e2 + VQ_R);
+    float *search_only = FUSED ? reinterpret_cast<float *>(smem_raw + VQ_STAGE_BYTES - (NW * VQ_R + VQ_R) * 4) : s_ee + p.n_e;
+    lds_vfloat *s_min = (lds_vfloat *)search_only;                                 // [128][NW] running min of s, read without barriers
+    float *s_e2 = search_only + NW * VQ_R;                                         // [128] |z~|^2, then 2 Erow
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(FUSED ? s_ee + p.n_e : s_e2 + VQ_R);
     unsigned short *s_code = reinterpret_cast<unsigned short *>(s_cnt + VQ_R);     // [128][VQ_CMAX]
 
     const long long row0 = (long long)blockIdx.x * VQ_R;
@@ -385,72 +362,64 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
         }
         return;
     }
-    // ---- exact phase: 512 lanes = 64 rows x 8 candidate slots, the block's rows in two halves
+    // ---- exact phase: 512 lanes = 64 rows x 8 candidate slots, the block's rows in two halves (the thread id as an opaque value from here on:
+    // with the plain one the addresses of this phase are loop-invariant for the search above and get hoisted over it)
     static_assert(!FUSED || NW == 8, "the fused exact phase maps 64 rows x 8 slots onto 8 waves");
-    // (the thread id as an opaque value from here on: with the plain one every swizzled row address of this phase is loop-invariant for
-    // the search above, gets hoisted over it and lands in scratch memory - 56 dwords per thread - because the search owns the registers)
     int te = t;
     asm volatile("" : "+v"(te));
     const int lane_e = te & 63, w_e = __builtin_amdgcn_readfirstlane(te >> 6);
-    float *zf = reinterpret_cast<float *>(smem_raw);            // [64][D] fp32 over the dead bf16 image (64 * D * 4 = 128 * D * 2 bytes)
-    const int D4 = D >> 2, LD4 = 31 - __builtin_clz(D4);
+    // Round 5: the code rows arrive LINE-COALESCED.  A wave = 8 rows x 8 candidate slots, as before, but a 128-byte line of a candidate's
+    // code row is fetched by the 8 lanes of its ROW group (16 bytes each, one load instruction per slot: 8 full lines per instruction
+    // instead of 64 lanes x 16 bytes of 64 different lines), written to the wave's staging buffer as [slot][row][chunk], and read back by
+    // the owner lane (row, slot) with 8 ds_read_b128.  The chunk a lane fetches is xor-ed with the slot so that the 16 lanes of a read
+    // group (2 rows x 8 slots) hit 16 different bank quads.  The row's line of z comes the same way (one more load: 8 rows x 128 B, read
+    // back as a broadcast by the row's slots) and STAYS in the fetching lane's registers: after the last line the 8 lanes of a row hold the
+    // row between them (16 lines x 16 B each) and form z_q = z + (e - z) from it, again 8 lanes per line - no fp32 copy of the rows in LDS,
+    // z is read twice per launch (search, here) as before.  No barriers: a staging buffer is private to its wave.
+    // Operation order of the chains = vq_chain's (one 32-float burst per line).
+    // (The same fetch through LDS-DMA - global_load_lds_dwordx4, no registers, two buffers per wave - was built first and is bit-identical:
+    // 161 us for this phase against the 143 of round 4; the copy path tops out near 6.4 TB/s for the chip (MI355X_MICROARCH.md
+    // "ldsdma-fill") and the phase moves 650 MB through it.)
+    unsigned char *stage_gen = smem_raw + (size_t)w_e * (2 * VQ_STAGE_BUF);
+    const int rl8 = lane_e >> 3, sl = lane_e & 7;
+    // (the number of lines is a COMPILE-TIME constant of the body: with a run-time `c < nline` guard in the unrolled line loops the register
+    // allocator put the kept rows of z - 64 registers - into scratch memory)
+    auto exact_phase = [&](auto nline_c) {
+    constexpr int nline = decltype(nline_c)::value;              // D / 32: 2, 4, 8 or 16
     for (int half = 0; half < 2; ++half) {
         const long long hrow0 = row0 + 64 * half;
         if (hrow0 >= p.M) break;                                 // (block-uniform)
-        for (int i0 = te; i0 < 64 * D4; i0 += NW * 64 * 8) {      // 8 loads in flight per thread, consecutive lanes walk a row
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * NW * 64, r = i >> LD4, c4 = i & (D4 - 1);
-                v[u] = float4{0.f, 0.f, 0.f, 0.f};
-                if (i < 64 * D4 && hrow0 + r < p.M) v[u] = ld4(p.z + (size_t)(hrow0 + r) * D + 4 * c4);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * NW * 64, r = i >> LD4, c4 = i & (D4 - 1);
-                if (i < 64 * D4) *reinterpret_cast<float4 *>(zf + r * D + 4 * (c4 ^ (r & 7))) = v[u];
-            }
-        }
-        __syncthreads();
-        const int rl = te >> 3, sl = te & 7;                       // row of the half, candidate slot; a wave = 8 rows
-        const long long row = hrow0 + rl;
+        const int lrow = 64 * half + w_e * 8 + rl8;              // row of the block; a wave = 8 rows x 8 slots
+        const long long row = row0 + lrow;
         const bool rok = row < p.M;
-        const float *zrow = zf + rl * D;
-        const unsigned ncnt = rok ? s_cnt[64 * half + rl] : 0u;
+        const unsigned ncnt = rok ? s_cnt[lrow] : 0u;
         const bool all = ncnt > (unsigned)VQ_CMAX;
         const int n = all ? 0 : (int)ncnt;
         int nmax = n;
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) nmax = max(nmax, __shfl_xor(nmax, sft, 64));
-        float zzr = 0.f, bd = INFINITY;
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        const int zk = rl8 >> 1;                                 // (z chunks xor-ed with the row pair: the four rows of a read group in four bank quads)
+        const int zoff = 4 * (sl ^ zk);                          // this lane's chunk of every line of its row (z, z_q and the winner's code row)
+        const float *zsrc = p.z + (size_t)(rok ? row : p.M - 1) * D + zoff;
+        float4 zkeep[16];                                        // (statically indexed: the line loops below are fully unrolled)
+        float bd = INFINITY;
         int bi = 0x7fffffff;
-        for (int base = 0; base < nmax; base += 8) {
-            const int k = base + sl;
-            const bool act = k < n;
-            int code = 0;
-            float acc = 0.f, zacc = 0.f;
-            if (act) {
-                code = (int)s_code[(64 * half + rl) * VQ_CMAX + k];
-                vq_chain_lds(zrow, rl & 7, p.cb + (size_t)code * D, D, acc, zacc);
-            }
-            if (base == 0) zzr = __shfl(zacc, lane_e & ~7, 64);        // slot 0 is active whenever the row has a candidate
-            const float d = (zzr + s_ee[code]) - 2.0f * acc;
-            if (act && (d < bd || (d == bd && code < bi))) { bd = d; bi = code; }
-        }
-        // rows marked "every code": the whole wave scans the codebook, 64 codes per step (constructed inputs only)
+        // rows marked "every code": the whole wave scans the codebook, 64 codes per step (constructed inputs only).
+        // First: the passes below keep the wave's rows of z in registers until z_q is written - nothing that needs many registers may sit between
         unsigned long long allmask = __ballot(all && sl == 0);
         while (allmask) {
             const int l = __builtin_ctzll(allmask);
             allmask &= allmask - 1;
-            const int ra = (w_e * 64 + l) >> 3;
+            const long long ra_ = hrow0 + ((w_e * 64 + l) >> 3);
             float wd = INFINITY;
             int wi = 0x7fffffff;
             for (int j0 = 0; j0 < p.n_e; j0 += 64) {
                 const int code = j0 + lane_e;
                 float acc = 0.f, zacc = 0.f;
-                vq_chain_lds(zf + ra * D, ra & 7, p.cb + (size_t)code * D, D, acc, zacc);
+                vq_chain(p.z + (size_t)ra_ * D, p.cb + (size_t)code * D, D, acc, zacc);
                 const float d = (zacc + s_ee[code]) - 2.0f * acc;
-                if (d < wd) { wd = d; wi = code; }                   // ascending codes per lane_e: strict < keeps the first
+                if (d < wd) { wd = d; wi = code; }                   // ascending codes per lane: strict < keeps the first
             }
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) {
@@ -460,6 +429,80 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
             }
             if ((lane_e & ~7) == l) { bd = wd; bi = wi; }              // all eight lanes of that row
         }
+        auto run = [&](int base, auto keep_c) {                // one pass over the rows' slots base .. base + 7; keep_c: the pass that keeps z
+            constexpr bool KEEP = decltype(keep_c)::value;
+            const int nb = nmax - base < 8 ? nmax - base : 8;    // slots in use by any row of the wave (uniform)
+            // the eight codes of this lane's row at slots base .. base + 7 (entries past the row's count are never fetched)
+            const uint4 cw = *reinterpret_cast<const uint4 *>(s_code + lrow * VQ_CMAX + base);
+            const unsigned cws[4] = {cw.x, cw.y, cw.z, cw.w};
+            auto code_of = [&](int i) -> int { return (int)((cws[i >> 1] >> (16 * (i & 1))) & 0xffffu); };
+            unsigned eoff[8];                                    // float offsets into the codebook (< 2^19): one register per slot
+#pragma unroll
+            for (int i = 0; i < 8; ++i) eoff[i] = (unsigned)((base + i < n ? code_of(i) : 0) * D + 4 * (sl ^ i));
+            const bool act = base + sl < n;
+            int code = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) code = sl == i ? code_of(i) : code;
+            if (!act) code = 0;
+            float acc = 0.f, zacc = 0.f;
+            auto load_line = [&](int c, float4 (&r)[8], float4 &zr) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    r[i] = float4{0.f, 0.f, 0.f, 0.f};
+                    if (i < nb && base + i < n) r[i] = ld4(p.cb + (eoff[i] + 32u * c));
+                }
+                zr = ld4(zsrc + 32 * c);
+            };
+            auto put_line = [&](const float4 (&r)[8], const float4 &zr, int buf) {
+                float4 *dst = reinterpret_cast<float4 *>(stage_gen + buf * VQ_STAGE_BUF) + lane_e;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i < nb && base + i < n) dst[64 * i] = r[i];
+                dst[512] = zr;
+            };
+            auto chain_line = [&](int buf) {      // (LDS operations of one wave complete in order: these reads see put_line's stores)
+                if (!act) return;
+                const float4 *eb = reinterpret_cast<const float4 *>(stage_gen + buf * VQ_STAGE_BUF + sl * 1024 + rl8 * 128);
+                const float4 *zb = reinterpret_cast<const float4 *>(stage_gen + buf * VQ_STAGE_BUF + 8192 + rl8 * 128);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {     // vq_chain_burst's order, 8 channels at a time (16 live registers instead of 64)
+                    const float4 z0 = zb[(2 * g) ^ zk], z1 = zb[(2 * g + 1) ^ zk], e0 = eb[(2 * g) ^ sl], e1 = eb[(2 * g + 1) ^ sl];
+                    acc = __builtin_fmaf(z0.x, e0.x, acc);
+                    acc = __builtin_fmaf(z1.x, e1.x, acc);
+                    acc = __builtin_fmaf(z0.y, e0.y, acc);
+                    acc = __builtin_fmaf(z1.y, e1.y, acc);
+                    acc = __builtin_fmaf(z0.z, e0.z, acc);
+                    acc = __builtin_fmaf(z1.z, e1.z, acc);
+                    acc = __builtin_fmaf(z0.w, e0.w, acc);
+                    acc = __builtin_fmaf(z1.w, e1.w, acc);
+                    zacc = __builtin_fmaf(z0.x, z0.x, zacc);
+                    zacc = __builtin_fmaf(z0.y, z0.y, zacc);
+                    zacc = __builtin_fmaf(z0.z, z0.z, zacc);
+                    zacc = __builtin_fmaf(z0.w, z0.w, zacc);
+                    zacc = __builtin_fmaf(z1.x, z1.x, zacc);
+                    zacc = __builtin_fmaf(z1.y, z1.y, zacc);
+                    zacc = __builtin_fmaf(z1.z, z1.z, zacc);
+                    zacc = __builtin_fmaf(z1.w, z1.w, zacc);
+                }
+            };
+            // one register set: a line's registers are free once it sits in LDS, so line c + 1 is requested before line c is evaluated
+            float4 ra[8], zt2[2];                                // (zt2: the row's line in the passes that do not keep it)
+            load_line(0, ra, KEEP ? zkeep[0] : zt2[0]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (c < nline) {                                 // (uniform)
+                    put_line(ra, KEEP ? zkeep[c] : zt2[c & 1], c & 1);
+                    if (c + 1 < 16 && c + 1 < nline) load_line(c + 1, ra, KEEP ? zkeep[c + 1] : zt2[(c + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    chain_line(c & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const float d = (zacc + s_ee[code]) - 2.0f * acc;    // every active lane of a row has the row's |z|^2 chain (same sequence)
+            if (act && (d < bd || (d == bd && code < bi))) { bd = d; bi = code; }
+        };
+        run(0, std::true_type{});                              // (also when no row of the wave has a list: it fetches the rows of z for z_q)
+        for (int base = 8; base < nmax; base += 8) run(base, std::false_type{});      // rows with more than 8 candidates (~1 % of them)
 #pragma unroll
         for (int sft = 4; sft >= 1; sft >>= 1) {
             const float od = __shfl_xor(bd, sft, 64);
@@ -468,39 +511,35 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_candidates_kernel(const Vq
         }
         bi = bi < 0 ? 0 : (bi >= p.n_e ? p.n_e - 1 : bi);       // rows with no finite distance keep the sentinel, as the single-pass path
         if (rok && sl == 0) p.idx[row] = (long long)bi;
-        // z_q of this wave's 8 rows from the LDS copy of z, 4 rows at a time (all code rows requested before the first store)
-        for (int r0 = 0; r0 < 8; r0 += 4) {
-            float4 ev[4][2];
+        // z_q = z + (e - z): the row's 8 lanes hold z between them; the winner's code row and the stores go 8 lanes per 128-byte line too
+        // (every line of the code row requested before the first store)
+        {
+            const float *ewin = p.cb + (size_t)bi * D + zoff;
+            float *qdst = p.zq + (size_t)(rok ? row : 0) * D + zoff;
+            float4 ev[16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = __shfl(bi, (r0 + r) * 8, 64);
+            for (int c = 0; c < 16; ++c)
+                if (c < nline) ev[c] = ld4(ewin + 32 * c);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = lane_e * 4 + 256 * j;
-                    ev[r][j] = float4{0.f, 0.f, 0.f, 0.f};
-                    if (c < D) ev[r][j] = ld4(p.cb + (size_t)b * D + c);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = w_e * 8 + r0 + r;
-                const long long rr = hrow0 + lr;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c4 = lane_e + 64 * j;
-                    if (rr < p.M && 4 * c4 < D) {
-                        const float4 zv = ld4(zf + lr * D + 4 * (c4 ^ (lr & 7))), ef = ev[r][j];
-                        float4 q;
-                        q.x = zv.x + (ef.x - zv.x);
-                        q.y = zv.y + (ef.y - zv.y);
-                        q.z = zv.z + (ef.z - zv.z);
-                        q.w = zv.w + (ef.w - zv.w);
-                        *reinterpret_cast<float4 *>(p.zq + (size_t)rr * D + 4 * c4) = q;
-                    }
+            for (int c = 0; c < 16; ++c) {
+                if (c < nline && rok) {
+                    const float4 z4 = zkeep[c], ef = ev[c];
+                    float4 q;
+                    q.x = z4.x + (ef.x - z4.x);
+                    q.y = z4.y + (ef.y - z4.y);
+                    q.z = z4.z + (ef.z - z4.z);
+                    q.w = z4.w + (ef.w - z4.w);
+                    *reinterpret_cast<float4 *>(qdst + 32 * c) = q;
                 }
             }
         }
-        __syncthreads();                                             // the next half overwrites zf
+    }
+    };
+    switch (D >> 5) {                                            // (femasr_vq_twopass_ok: e_dim in {64, 128, 256, 512})
+    case 16: exact_phase(std::integral_constant<int, 16>{}); break;
+    case 8: exact_phase(std::integral_constant<int, 8>{}); break;
+    case 4: exact_phase(std::integral_constant<int, 4>{}); break;
+    default: exact_phase(std::integral_constant<int, 2>{}); break;
     }
 }
 
@@ -609,8 +648,9 @@ __global__ __launch_bounds__(256, 4) void vq_exact_kernel(const float *__restric
 
 constexpr int VQ_NW = 8;
 
-size_t cand_lds_bytes(int n_e, int D)
+size_t cand_lds_bytes(int n_e, int D, bool fused)
 {
+    if (fused) return vq_fused_list0(D) + (size_t)n_e * 4 + VQ_R * 4 + (size_t)VQ_R * VQ_CMAX * 2;      // 160 256 at n_e = 1024
     return (size_t)VQ_R * D * 2 + (size_t)n_e * 4 + (size_t)VQ_NW * VQ_R * 4 + VQ_R * 8 + (size_t)VQ_R * VQ_CMAX * 2;
 }
 
@@ -661,7 +701,7 @@ size_t femasr_vq_scratch_bytes(int64_t M, int n_e)
 
 static int launch_candidates(hipStream_t s, const VqCandParams &p, bool fused)
 {
-    const int lds = (int)cand_lds_bytes(p.n_e, p.D);
+    const int lds = (int)cand_lds_bytes(p.n_e, p.D, fused);
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
