@@ -38,11 +38,11 @@ class ConvArgs(ctypes.Structure):
         ('act', ctypes.c_int32),
         ('res1', vp), ('res2', vp), ('out', vp),
         ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32),
-        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp), ('w_wino', vp), ('fast_act', ctypes.c_int32), ('in_add', vp), ('w_bf16s', vp),
+        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp), ('w_wino', vp), ('fast_act', ctypes.c_int32), ('in_add', vp), ('w_bf16s', vp), ('in_bf16s', vp), ('out_bf16s', vp),
     ]
 
 
-ABI_VERSION = 101      # femasr_version(): femasr_conv_args ends with w_bf16s
+ABI_VERSION = 102      # femasr_version(): femasr_conv_args ends with in_bf16s / out_bf16s
 PRO_NONE, PRO_GN_SILU, PRO_LN = 0, 1, 2
 ACT_NONE, ACT_GELU = 0, 1
 
@@ -107,17 +107,21 @@ SIGNATURES = {
     'femasr_set_linear_math': (c_int, [vp, c_int]),
     'femasr_packed_weight_bf16s_bytes': (szt, [c_int, c_int]),
     'femasr_repack_k1_bf16s': (c_int, [vp, vp, c_int, c_int, vp]),
-    'femasr_debug_mfma_bf16': (c_int, [vp, vp, vp, vp, c_int, vp]),
+    'femasr_packed_rows_bf16s_bytes': (szt, [c_i64, c_int]),
+    'femasr_pack_rows_bf16s': (c_int, [vp, vp, c_i64, c_int, vp]),
+    'femasr_unpack_rows_bf16s': (c_int, [vp, vp, c_i64, c_int, vp]),
+    'femasr_layernorm_bf16s': (c_int, [vp, vp, c_i64, c_int, vp, vp, c_f32, vp]),
     'femasr_image_u8_to_f32': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_image_f32_to_u8': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_clock_probe': (c_int, [vp, c_int, vp]),
+    'femasr_clock_probe_entries': (c_int, []),
+}
+# test / measurement hooks: include/femasr_hip_debug.h (exported by the library, not part of the drop-in interface)
+DEBUG_SIGNATURES = {
+    'femasr_debug_set_wino_limits': (c_int, [vp, c_int, c_int]),
+    'femasr_debug_mfma_bf16': (c_int, [vp, vp, vp, vp, c_int, vp]),
     'femasr_gemm_force_config': (c_int, [c_int]),
     'femasr_conv_small_launch_blocks': (c_int, [c_int]),
-    'femasr_debug_wino_limits': (c_int, [c_int, c_int]),
-    'femasr_debug_wino_form': (c_int, [c_int]),
-    'femasr_debug_wino_mphase': (c_int, [c_int]),
-    'femasr_clock_probe_entries': (c_int, []),
-    'femasr_mlp_fused': (c_int, [vp, vp, c_i64, c_int, c_int, vp, vp, vp, vp, vp, vp]),
 }
 
 _lib = None
@@ -137,7 +141,7 @@ def load():
     if lib.femasr_version() != ABI_VERSION:
         raise FemasrError(f'{SO_PATH} reports ABI version {lib.femasr_version()}, this binding is written for {ABI_VERSION} '
                           '(femasr_conv_args layout): rebuild with `python femasr_amd/csrc/build.py --force`')
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -204,6 +204,7 @@ class FeMaSRNet(nn.Module):
         # batches); results are bit-identical.
         self.use_graph = False
         self._graphs = {}
+        self.debug_wino_limits = None   # tests only: (log2_total, log2_image) for this net's planner (include/femasr_hip_debug.h)
 
     # ------------------------------------------------------------------ weight change tracking
     # The native handle holds REPACKED COPIES of the weights.  Changes made through the nn.Module API are seen
@@ -273,7 +274,7 @@ class FeMaSRNet(nn.Module):
                 _lib.check(lib.femasr_finalize_weights(self._handle))
             self._version_sum = self._param_stamp()
             self._weights_dirty = False
-        if self._streams_set != (self._handle.value, self.num_streams, self.decoder_math, self.linear_math):
+        if self._streams_set != (self._handle.value, self.num_streams, self.decoder_math, self.linear_math, self.debug_wino_limits):
             if self.decoder_math not in ('fp32', 'bf16x3', 'fp32_direct', 'fp32_strict'):
                 raise ValueError(f"decoder_math must be 'fp32', 'fp32_strict', 'fp32_direct' or 'bf16x3', got {self.decoder_math!r}")
             if self.linear_math not in ('fp32', 'bf16_split'):
@@ -281,7 +282,9 @@ class FeMaSRNet(nn.Module):
             _lib.check(lib.femasr_set_linear_math(self._handle, {'fp32': 0, 'bf16_split': 1}[self.linear_math]))
             _lib.check(lib.femasr_set_streams(self._handle, int(self.num_streams)))
             _lib.check(lib.femasr_set_decoder_math(self._handle, {'fp32': 0, 'bf16x3': 1, 'fp32_direct': 2, 'fp32_strict': 3}[self.decoder_math]))
-            self._streams_set = (self._handle.value, self.num_streams, self.decoder_math, self.linear_math)
+            if self.debug_wino_limits is not None:
+                _lib.check(lib.femasr_debug_set_wino_limits(self._handle, int(self.debug_wino_limits[0]), int(self.debug_wino_limits[1])))
+            self._streams_set = (self._handle.value, self.num_streams, self.decoder_math, self.linear_math, self.debug_wino_limits)
         return lib, self._handle
 
     def _param_stamp(self):

@@ -10,8 +10,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['kernels_conv.hip', 'kernels_gemm.hip', 'kernels_gemm_bf16.hip', 'kernels_mlp.hip', 'kernels_vq.hip', 'kernels_wino.hip', 'kernels_wino_c128.hip', 'kernels_wino_up2.hip', 'kernels_conv_bf16.hip', 'kernels_misc.hip', 'model.hip']
-HEADERS = ['common.h', 'conv_common.h', 'wino_common.h', 'detmath.h', '../../include/femasr_hip.h']
+SOURCES = ['kernels_conv.hip', 'kernels_gemm.hip', 'kernels_gemm_bf16.hip', 'kernels_vq.hip', 'kernels_wino.hip', 'kernels_wino_up2.hip', 'kernels_conv_bf16.hip', 'kernels_misc.hip', 'model.hip']
+HEADERS = ['common.h', 'conv_common.h', 'wino_common.h', 'detmath.h', '../../include/femasr_hip.h', '../../include/femasr_hip_debug.h']
 SO = os.path.join(HERE, 'libfemasr_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result']
@@ -47,20 +47,27 @@ def build(force=False, verbose=True, gate='fail'):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-    if jobs and gate != 'off' and os.environ.get('FEMASR_SKIP_SCRATCH_CHECK') != '1':
-        # gate: no kernel of the default schedule may (newly) use scratch memory - kernel_meta.py reads the code objects' metadata
+    if gate != 'off' and os.environ.get('FEMASR_SKIP_SCRATCH_CHECK') != '1':
+        # gates (every build, also one that compiled nothing): kernel_meta.py reads the code objects' metadata and ISA -
+        #   * no kernel of the default schedule may (newly) use scratch memory;
+        #   * the main loop of the split GEMM holds hand-counted `s_waitcnt vmcnt(N)` waits: no VMEM instruction other than the
+        #     inline-asm loads / LDS-DMA copies may appear between them, and the wait values must be the source's.
         sys.path.insert(0, HERE)
         import kernel_meta
+        problems = []
         try:
             _, bad = kernel_meta.check()
-        except Exception as e:              # (llvm-readelf missing, another object layout: the gate is a check, not a dependency)
-            print(f'kernel_meta: scratch check skipped ({type(e).__name__}: {e})', flush=True)
-            bad = []
-        if bad and gate == 'warn':
-            print('WARNING: kernels of the default schedule use (more) scratch memory:\n' + kernel_meta.table(bad), flush=True)
-        elif bad:
-            raise RuntimeError('kernels of the default schedule use (more) scratch memory:\n' + kernel_meta.table(bad) +
-                               '(fix the spill, or list the instantiation in kernel_meta.py with the reason)')
+            if bad:
+                problems.append('kernels of the default schedule use (more) scratch memory:\n' + kernel_meta.table(bad) +
+                                '(fix the spill, or list the instantiation in kernel_meta.py with the reason)')
+            problems += kernel_meta.check_counted_waits()
+        except Exception as e:              # (llvm tools missing, another object layout: the gate is a check, not a dependency)
+            print(f'kernel_meta: checks skipped ({type(e).__name__}: {e})', flush=True)
+        if problems and gate == 'warn':
+            print('WARNING: ' + '\n'.join(problems), flush=True)
+        elif problems:
+            os.remove(SO)                   # a library that failed its gate must not be picked up by a later import
+            raise RuntimeError('\n'.join(problems))
     return SO
 
 

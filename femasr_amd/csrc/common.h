@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
-#include "../../include/femasr_hip.h"
+#include "../../include/femasr_hip_debug.h"      // (includes femasr_hip.h)
 
 // thread-local error message plumbing (model.hip)
 int femasr_set_error(int code, const char *fmt, ...);
@@ -57,24 +57,17 @@ int femasr_gemm_bf16s_launch(hipStream_t s, const femasr_conv_args *a, const voi
 int femasr_gemm_bf16s_variant_count();
 const char *femasr_gemm_bf16s_variant_name(int v);
 
-// the Swin MLP in one kernel (kernels_mlp.hip): fc1 + exact GELU + fc2 + residual, hidden activation on chip
-bool femasr_mlp_fused_shape_ok(int C, int hidden);
-int femasr_mlp_fused_launch(hipStream_t s, const float *x, long long M, const float *w1p, const float *b1, const float *w2p, const float *b2,
-                            const float *res, float *out, double *flops_out);
-const char *femasr_mlp_fused_variant_name();
-
 // Winograd F(4x4,3x3) 3x3 convs (kernels_wino.hip)
-size_t femasr_wino_limit_total();       // element limits of the Winograd-form kernels (2^31 / 2^27 per image; femasr_debug_wino_limits)
-size_t femasr_wino_limit_image();
+constexpr int FEMASR_WINO_LOG2_TOTAL = 31, FEMASR_WINO_LOG2_IMAGE = 27;      // element limits of the Winograd-form kernels (32-bit byte offsets)
 bool femasr_conv_wino_shape_ok(const femasr_conv_args *a);
-bool femasr_wino_mphase_bf16();       // default-mode F(4x4) convs run their M phase on the bf16 matrix pipe (FEMASR_WINO_M / femasr_debug_wino_mphase)
+bool femasr_conv_wino_shape_ok_lim(const femasr_conv_args *a, int log2_total, int log2_image);      // a handle's planner may lower the limits (femasr_debug_set_wino_limits)
 int femasr_conv_wino_gn_tiles(int H, int W);      // fused GroupNorm partials of a Winograd conv: one per 16x16-pixel sub-block
 int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out);
-bool femasr_wino_c128_shape(int Cin, int Cout);      // kernels_wino_c128.hip: this layer runs (and its weights are packed) in the 16x16 x 128 block shape
 int femasr_conv_wino_variant_count();
 const char *femasr_conv_wino_variant_name(int v);
 // nn.Upsample(x2) + 3x3 conv in the 25-product Winograd-type form (kernels_wino_up2.hip); GroupNorm partials per 16x16 OUTPUT sub-block
 bool femasr_conv_wino_up2_shape_ok(const femasr_conv_args *a);
+bool femasr_conv_wino_up2_shape_ok_lim(const femasr_conv_args *a, int log2_total, int log2_image);
 int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double *flops_out);
 const char *femasr_conv_wino_up2_variant_name();
 

@@ -18,9 +18,6 @@ READELF = '/opt/rocm/lib/llvm/bin/llvm-readelf'
 # kernels that may use scratch: not on the default schedule (opt-in modes, test hooks, the C-ABI-only instantiations)
 ALLOW_SCRATCH = (
     'conv3x3_halo_bf16x3_kernel',       # decoder_math='bf16x3' (secondary mode): 2-8 dwords
-    'mlp_fused_kernel',                 # FEMASR_MLP=fused
-    'conv3x3_wino4_kernelILi1ELb1ELi0ELi1E', 'conv3x3_wino4_kernelILi1ELb1ELi1ELi1E', 'conv3x3_wino4_kernelILi1ELb1ELi2ELi1E',
-                                        # FEMASR_WINO_M=bf16 (the measured-slower bf16-pipe M phase, opt-in): one dword
 )
 
 
@@ -120,6 +117,103 @@ def check(verbose=False):
     return rows, bad
 
 
+OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+VMEM_PREFIXES = ('global_', 'buffer_', 'scratch_', 'flat_', 'tbuffer_')
+# kernels_gemm_bf16.hip: what one trip of the MFMA loop may contain.  AIN = 1 (planes by LDS-DMA): one step = six copies, one counted wait
+# (the six copies of the next step stay in flight).  AIN = 0 (fp32 rows): two chunks = four steps = twelve W copies + two 4-load row fetches,
+# waits 14 / 10 / 10 per chunk.  The numbers are the source's (`s_waitcnt vmcnt(N)` in the inline asm); check_counted_waits() also reads them there.
+COUNTED = {
+    1: {'global_load_lds_dwordx4': 6, 'vmcnt': {6: 1}},
+    0: {'global_load_lds_dwordx4': 12, 'global_load_dwordx4': 8, 'vmcnt': {14: 2, 10: 4}},
+}
+
+
+def disassemble(obj_path):
+    """{kernel symbol: [(address, mnemonic, operands)]} of the gfx950 code object inside a hipcc .o."""
+    elf = device_elf(obj_path)
+    if not elf:
+        return {}
+    with tempfile.NamedTemporaryFile(suffix='.co') as t:
+        t.write(elf)
+        t.flush()
+        txt = subprocess.run([OBJDUMP, '-d', t.name], capture_output=True, text=True, check=True).stdout
+    out, cur = {}, None
+    for line in txt.splitlines():
+        m = re.match(r'^[0-9a-f]+ <(\S+)>:', line)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        m = re.match(r'^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):', line)
+        if m and cur is not None:
+            cur.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    return out
+
+
+def mfma_loops(insts):
+    """Innermost backward-branch loops that contain MFMAs: [(first index, branch index)]."""
+    addr_index = {a: i for i, (a, _, _) in enumerate(insts)}
+    loops = []
+    for i, (a, op, args) in enumerate(insts):
+        if not op.startswith('s_cbranch') and op != 's_branch':
+            continue
+        try:
+            simm = int(args.split()[0])
+        except (ValueError, IndexError):
+            continue
+        if simm >= 32768:
+            simm -= 65536
+        if simm >= 0:
+            continue
+        tgt = addr_index.get(a + 4 + 4 * simm)
+        if tgt is None:
+            continue
+        if any(o.startswith('v_mfma') for _, o, _ in insts[tgt:i]):
+            loops.append((tgt, i))
+    return [l for l in loops if not any(m != l and l[0] <= m[0] and m[1] <= l[1] for m in loops)]      # innermost only
+
+
+def check_counted_waits(obj=None):
+    """The split GEMM's main loops hold hand-counted `s_waitcnt vmcnt(N)` waits around inline-asm loads / LDS-DMA copies: a VMEM instruction
+    the COMPILER adds between them (a spill, a hoisted bias load, a future scheduler) would make the counts wrong and feed stale operands to the
+    MFMAs - silently, only the bit-exact GPU tests would tell.  Returns a list of problems (empty = fine)."""
+    obj = obj or os.path.join(HERE, 'kernels_gemm_bf16.o')
+    problems = []
+    src = open(os.path.join(HERE, 'kernels_gemm_bf16.hip')).read()
+    src_counts = sorted({int(v) for v in re.findall(r's_waitcnt vmcnt\((\d+)\)', src)})
+    want_counts = sorted({0} | {n for c in COUNTED.values() for n in c['vmcnt']})
+    if src_counts != want_counts:
+        problems.append(f'kernels_gemm_bf16.hip waits for vmcnt {src_counts}, kernel_meta.COUNTED expects {want_counts}: update both together')
+    seen = 0
+    for name, insts in disassemble(obj).items():
+        m = re.search(r'gemm_bf16s_kernelILi(\d)E', name)
+        if not m:
+            continue
+        seen += 1
+        want = COUNTED[int(m.group(1))]
+        loops = mfma_loops(insts)
+        if len(loops) != 1:
+            problems.append(f'{demangle_short(name)}: expected one MFMA loop, found {len(loops)}')
+            continue
+        body = insts[loops[0][0]:loops[0][1] + 1]
+        vmem, waits = {}, {}
+        for _, op, args in body:
+            if op.startswith(VMEM_PREFIXES):
+                vmem[op] = vmem.get(op, 0) + 1
+            if op == 's_waitcnt':
+                for n in re.findall(r'vmcnt\((\d+)\)', args):
+                    waits[int(n)] = waits.get(int(n), 0) + 1
+        want_vmem = {k: v for k, v in want.items() if k != 'vmcnt'}
+        if vmem != want_vmem:
+            problems.append(f'{demangle_short(name)}: VMEM instructions in the MFMA loop {vmem}, the counted waits assume exactly {want_vmem}')
+        if waits != want['vmcnt']:
+            problems.append(f'{demangle_short(name)}: vmcnt waits in the MFMA loop {waits}, the source has {want["vmcnt"]}')
+        if not any(op == 's_barrier' for _, op, _ in body):
+            problems.append(f'{demangle_short(name)}: no s_barrier in the MFMA loop')
+    if seen < 14:
+        problems.append(f'only {seen} gemm_bf16s_kernel instantiations found in {obj}')
+    return problems
+
+
 if __name__ == '__main__':
     rows, bad = check(verbose='--quiet' not in sys.argv)
     if '--table' in sys.argv:
@@ -127,4 +221,8 @@ if __name__ == '__main__':
     if bad:
         print('kernels of the default schedule that use scratch memory:')
         print(table(bad))
+        sys.exit(1)
+    probs = check_counted_waits()
+    if probs:
+        print('\n'.join(probs))
         sys.exit(1)

@@ -28,12 +28,8 @@
 // stores, and accumulates the fused GroupNorm partial moments (fp64) per 16x16 sub-block in the order of orc_gn_coeffs mode 2.
 #define FEMASR_WTT_BUF g_wi_ttbuf
 #include "wino_common.h"
-#include <string.h>
 #ifndef FEMASR_WINO_EPI_FENCE
 #define FEMASR_WINO_EPI_FENCE 1
-#endif
-#ifndef FEMASR_WINO_M_DEFAULT
-#define FEMASR_WINO_M_DEFAULT 0      // the M phase of the default-mode F(4x4) convs: 0 fp32 MFMA, 1 bf16 matrix pipe (see MM below)
 #endif
 
 namespace {
@@ -41,35 +37,12 @@ namespace {
 // SiLU of the staged input.  FAST: x * rcp(1 + exp2(-x log2 e)) on the hardware transcendental units (v_exp_f32 / v_rcp_f32,
 // 1 ulp each) - the default of the model: these convs sit behind the codebook lookup, the result stays within ~1e-6 relative of
 // the exact form.  !FAST: the IEEE-exact polynomial + division of detmath.h, bit-identical to the oracle (decoder_math 'fp32_strict').
-// MM (round 5): arithmetic of the M phase.  0: fp32 MFMA (v_mfma_f32_32x32x2_f32), every value one fixed IEEE sequence == the oracle.
-// 1: the same products as an fp32-GRADE evaluation on the bf16 matrix pipe - V split exactly into three bf16 terms where its fragment
-// is read (each V value is read by exactly one wave, so the T phase and the V layout are untouched), U pre-split at pack time, the six
-// partial products of relative size >= 2^-16 (kernels_gemm_bf16.hip) as v_mfma_f32_32x32x8_bf16_1k: 6 x 32 cycles per (component,
-// column tile) and step where the fp32 form needs 4 x 64 x 2.  Only with the hardware SiLU (FAST): the default mode, which is checked against
-// the oracle with a tolerance anyway; 'fp32_strict' keeps MM = 0 and stays bit-identical to the oracle.
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-struct UFrag {            // MM = 0: ab = the fp32 fragment.  MM = 1: ab = planes 1 and 2 (4 bf16 each), c = plane 3
-    u32x4_t ab;
-    unsigned c0, c1;
-};
-__device__ __forceinline__ unsigned w_cvt_pk_bf16(float a, float b)
-{
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(tf2{a, b}, bf2));
-}
-__device__ __forceinline__ void w_split3_pair(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3)
-{
-    p1 = w_cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
-    p2 = w_cvt_pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xffff0000u);
-    p3 = w_cvt_pk_bf16(sa, sb);
-}
-
-template <int PRO, bool FAST, int NRES, int MM = 0>
+// (Round 5 built the M phase on the bf16 matrix pipe as a fourth template parameter - V split into three bf16 terms where its fragment is
+// read, U pre-split at pack time, six v_mfma_f32_32x32x8_bf16_1k per (component, column tile) and step: fp32-grade, 4 % SLOWER per launch
+// (profiles/r05_wino_bf16m_ab.txt; DESIGN.md 5 "Round 5" 6.) - and round 6 removed it from the tree: git history has it.)
+template <int PRO, bool FAST, int NRES>
 __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParams p)
 {
-    static_assert(MM == 0 || FAST, "the bf16-pipe M phase belongs to the default (hardware SiLU) mode");
     constexpr bool HAS1 = NRES >= 1, HAS2 = NRES >= 2;      // residual operands of the epilogue (compile time: no selects per pixel)
         extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ps = smem;                        // [2][W4_PSZ]
@@ -128,10 +101,7 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     const int zo1 = t >= W4_UNITS_SB - 512 ? KINDS * p.Cin : 0;          // table offset of unit 1's sub-block (unit 0: first, unit 2: second)
     // buffer loads: descriptor + uniform byte offset in SGPRs, ONE 32-bit per-lane offset register per load (no 64-bit VALU adds)
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void *)(p.in + (size_t)sn[0] * p.H * p.W * p.Cin), 0, 0x7fffffff, 0x00020000);
-    // (MM = 1: behind the fp32 image lie the bf16 images - planes 1 + 2, 16 bytes per lane and pair, the size of the fp32 image; plane 3, 8 bytes)
-    const size_t u_img = (size_t)p.nsteps * 36 * p.NT32 * 256;
-    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void *)(p.u + (MM ? u_img : 0)), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_u3 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.u + (MM ? 2 * u_img : 0)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, 0x7fffffff, 0x00020000);
     float4 rp[3];
     auto load_patch_to = [&](float4 (&rr)[3], int s) {       // unconditional (steps past the end re-read the last one): the wait counters stay static
         const int sc = s < p.nsteps ? s : p.nsteps - 1;
@@ -246,25 +216,17 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
     const int aoff = c31 * 8 + hh * 4;
     auto pcomp = [&](int q) -> int { return q < 8 ? 4 * wave + (q >> 1) : 32 + (wave >> 1); };
     auto pntl = [&](int q) -> int { return q < 8 ? (q & 1) : (wave & 1); };
-    auto ldU = [&](int s, int q) -> UFrag {       // unconditional, like load_patch
+    auto ldU = [&](int s, int q) -> u32x4_t {       // unconditional, like load_patch
         const int sc = s < p.nsteps ? s : p.nsteps - 1;
-        UFrag f;
-        f.c0 = f.c1 = 0u;
-        if (FEMASR_WINO_ABL & 2) { f.ab = u32x4_t{0x3f003f80u, 0x3e803e00u, 0x3f003f80u, 0x3e803e00u}; return f; }
+        if (FEMASR_WINO_ABL & 2) return u32x4_t{0x3f003f80u, 0x3e803e00u, 0x3f003f80u, 0x3e803e00u};
         const int pr = (sc * 36 + pcomp(q)) * p.NT32 + 2 * nb + pntl(q);
-        f.ab = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, lw, pr << 10, 0);
-        if (MM) {
-            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-            const u32x2_t c = __builtin_amdgcn_raw_buffer_load_b64(rsrc_u3, lw >> 1, pr << 9, 0);
-            f.c0 = c[0]; f.c1 = c[1];
-        }
-        return f;
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, lw, pr << 10, 0);
     };
     // U fragments.  ring: pairs 0-2 of the NEXT step, loaded behind this step's pairs 0-2 (live across the T phase).
     // early: pairs 3-5, issued at the end of the T phase (the registers are free again): in flight across the barrier for
     // waves 0-3, whose M phase follows it.
     // late: pairs 6-8, issued at the start of the M phase (6 pairs = 1536 MFMA cycles ahead of their use).
-    UFrag ring[3], early[3], late[3];
+    u32x4_t ring[3], early[3], late[3];
     auto issue_early = [&](int s) {
 #pragma unroll
         for (int q = 3; q < 6; ++q) early[q - 3] = ldU(s, q);
@@ -275,39 +237,16 @@ __global__ __launch_bounds__(W4_NT, 2) void conv3x3_wino4_kernel(const WinoParam
 #pragma unroll
         for (int q = 6; q < 9; ++q) late[q - 6] = ldU(s, q);
         f32x4_t an = *reinterpret_cast<const f32x4_t *>(Vb + pcomp(0) * 256);
-        unsigned ap[3][2] = {};
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
             const f32x4_t a = an;
             if ((q & 1) && q + 1 < 9) an = *reinterpret_cast<const f32x4_t *>(Vb + pcomp(q + 1) * 256);      // one A fragment per component
-            const UFrag bu = q < 3 ? ring[q] : (q < 6 ? early[q - 3] : late[q - 6]);
-            if (MM == 0) {
-                const f32x4_t b = __builtin_bit_cast(f32x4_t, bu.ab);
+            const f32x4_t b = __builtin_bit_cast(f32x4_t, q < 3 ? ring[q] : (q < 6 ? early[q - 3] : late[q - 6]));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (FEMASR_WINO_ABL & 8) { asm volatile("" :: "v"(a[e]), "v"(b[e])); continue; }
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
-                }
-            } else {
-                // the lane's four channel values of this component -> three bf16 planes (once per component: both column tiles use them)
-                if (!(q & 1) || q == 8) {
-                    w_split3_pair(a[0], a[1], ap[0][0], ap[1][0], ap[2][0]);
-                    w_split3_pair(a[2], a[3], ap[0][1], ap[1][1], ap[2][1]);
-                }
-                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                const s16x4_t a1 = __builtin_bit_cast(s16x4_t, u32x2_t{ap[0][0], ap[0][1]}), a2 = __builtin_bit_cast(s16x4_t, u32x2_t{ap[1][0], ap[1][1]}),
-                              a3 = __builtin_bit_cast(s16x4_t, u32x2_t{ap[2][0], ap[2][1]});
-                const s16x4_t b1 = __builtin_bit_cast(s16x4_t, u32x2_t{bu.ab[0], bu.ab[1]}), b2 = __builtin_bit_cast(s16x4_t, u32x2_t{bu.ab[2], bu.ab[3]}),
-                              b3 = __builtin_bit_cast(s16x4_t, u32x2_t{bu.c0, bu.c1});
-                if (!(FEMASR_WINO_ABL & 8)) {       // small terms first, a1 b1 last (one accumulator: 144 registers leave no room for a second)
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a3, b1, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1, b3, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a2, b2, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a2, b1, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1, b2, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1, b1, acc[q], 0, 0, 0);
-                }
+            for (int e = 0; e < 4; ++e) {
+                if (FEMASR_WINO_ABL & 8) { asm volatile("" :: "v"(a[e]), "v"(b[e])); continue; }
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[q], 0, 0, 0);
             }
             if (q < 3) ring[q] = ldU(s + 1, q);
             if (q == 5) {      // behind the step's U requests (earlier it delays them: loads return in order)
@@ -600,41 +539,6 @@ __global__ void repack_wino_kernel(const float *__restrict__ in, int O, int I, f
     }
 }
 
-// the bf16 images of the same U (MM = 1): per (step, component, 32-column tile, lane) the lane's four values - column o = 32 tile + lane%32,
-// ci = 8 step + 2 j + lane/32, j = 0..3: exactly the four values of the fp32 fragment - split into three bf16 planes; planes 1 and 2 as
-// one 16-byte record [b1(j0,j1), b1(j2,j3), b2(j0,j1), b2(j2,j3)], plane 3 as an 8-byte record
-__global__ void repack_wino_bf16_kernel(const float *__restrict__ in, int O, int I, uint4 *__restrict__ outA, uint2 *__restrict__ outB, size_t total)
-{
-    const int NT32 = (O + 31) / 32;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int lane = (int)(idx & 63);
-        size_t rest = idx >> 6;
-        const int ntile = (int)(rest % NT32);
-        rest /= NT32;
-        const int comp = (int)(rest % 36), step = (int)(rest / 36);
-        const int o = ntile * 32 + (lane & 31);
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ci = 8 * step + 2 * j + (lane >> 5);
-            v[j] = 0.f;
-            if (ci < I && o < O) {
-                const int i = comp / 6, jj = comp - 6 * i;
-                const float *gw = in + ((size_t)o * I + ci) * 9;
-                float ur[3];
-#pragma unroll
-                for (int x = 0; x < 3; ++x) ur[x] = wino_g6(i, gw[x], gw[3 + x], gw[6 + x]);
-                v[j] = wino_g6(jj, ur[0], ur[1], ur[2]);
-            }
-        }
-        unsigned p1[2], p2[2], p3[2];
-        w_split3_pair(v[0], v[1], p1[0], p2[0], p3[0]);
-        w_split3_pair(v[2], v[3], p1[1], p2[1], p3[1]);
-        outA[idx] = uint4{p1[0], p1[1], p2[0], p2[1]};
-        outB[idx] = uint2{p3[0], p3[1]};
-    }
-}
-
 struct WVariant {
     const char *name;
     void (*kern)(const WinoParams);
@@ -643,24 +547,20 @@ struct WVariant {
 };
 #define FEMASR_WINO(PRO, FAST, NRES) { "conv3x3_wino4<2x16x16px x64," #PRO "," #FAST ",res=" #NRES ",waves=8>", conv3x3_wino4_kernel<PRO, FAST, NRES>, 0ull, 0 }
 #define FEMASR_WINO3(PRO, FAST) FEMASR_WINO(PRO, FAST, 0), FEMASR_WINO(PRO, FAST, 1), FEMASR_WINO(PRO, FAST, 2)
-#define FEMASR_WINOS(NRES) { "conv3x3_wino4s<2x16x16px x64,FEMASR_PRO_GN_SILU,true,res=" #NRES ",waves=8>", conv3x3_wino4_kernel<FEMASR_PRO_GN_SILU, true, NRES, 1>, 0ull, 0 }
 WVariant g_wv[] = {                               // index = 3 * (prologue form) + residual operands
     FEMASR_WINO3(FEMASR_PRO_NONE, false),
     FEMASR_WINO3(FEMASR_PRO_GN_SILU, false),      // exact SiLU
     FEMASR_WINO3(FEMASR_PRO_GN_SILU, true),       // hardware exp2 / rcp SiLU
-    FEMASR_WINOS(0), FEMASR_WINOS(1), FEMASR_WINOS(2),      // ... and the M phase on the bf16 matrix pipe (fast_act = 2)
 };
 constexpr int kNumW = sizeof(g_wv) / sizeof(g_wv[0]);
 
 }  // namespace
 
-static std::atomic<int> g_log2_total{31}, g_log2_image{27};
-size_t femasr_wino_limit_total() { return (size_t)1 << g_log2_total.load(std::memory_order_relaxed); }
-size_t femasr_wino_limit_image() { return (size_t)1 << g_log2_image.load(std::memory_order_relaxed); }
-
-bool femasr_conv_wino_shape_ok(const femasr_conv_args *a)
+// Element limits of the Winograd-form kernels (32-bit byte offsets: 2^31 elements per tensor, 2^27 per image).  A handle may LOWER them
+// for its planner (femasr_debug_set_wino_limits, include/femasr_hip_debug.h: tests of both sides of the limit at sizes they can allocate).
+bool femasr_conv_wino_shape_ok_lim(const femasr_conv_args *a, int log2_total, int log2_image)
 {
-    const size_t tot = femasr_wino_limit_total(), img = femasr_wino_limit_image();
+    const size_t tot = (size_t)1 << log2_total, img = (size_t)1 << log2_image;
     return a->ksz == 3 && a->stride == 1 && a->pad == 1 && !a->up2 && a->act == FEMASR_ACT_NONE && (a->Cin % BK) == 0 && a->Cin <= 1024 &&
            (a->Cout % 64) == 0 && (a->prologue == FEMASR_PRO_NONE || a->prologue == FEMASR_PRO_GN_SILU) &&
            (size_t)a->B * a->H * a->W * a->Cin < tot && (size_t)a->B * a->H * a->W * a->Cout < tot &&
@@ -668,8 +568,9 @@ bool femasr_conv_wino_shape_ok(const femasr_conv_args *a)
            (size_t)a->H * a->W * a->Cout < img &&         // ... and of the output / residual descriptors
            (size_t)36 * a->Cin * a->Cout < ((size_t)1 << 29);
 }
-int femasr_conv_wino_variant_count() { return kNumW + femasr_conv_wino_c128_variant_count(); }      // (profile slots: this form, then the x128 form)
-const char *femasr_conv_wino_variant_name(int v) { return v >= 0 && v < kNumW ? g_wv[v].name : femasr_conv_wino_c128_variant_name(v - kNumW); }
+bool femasr_conv_wino_shape_ok(const femasr_conv_args *a) { return femasr_conv_wino_shape_ok_lim(a, FEMASR_WINO_LOG2_TOTAL, FEMASR_WINO_LOG2_IMAGE); }
+int femasr_conv_wino_variant_count() { return kNumW; }
+const char *femasr_conv_wino_variant_name(int v) { return v >= 0 && v < kNumW ? g_wv[v].name : "?"; }
 int femasr_conv_wino_gn_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }
 
 int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out, double *flops_out)
@@ -693,12 +594,7 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
     FEMASR_REQUIRE(a->res1 || !a->res2, "conv_wino: res2 without res1");
     FEMASR_REQUIRE(!a->in_add, "conv_wino: in_add is only taken by the x2 form");
     if (flops_out) *flops_out = 2.0 * (double)a->B * a->H * a->W * 9.0 * (double)a->Cin * (double)a->Cout;      // ALGORITHMIC, see below
-    if (femasr_wino_c128_shape(a->Cin, a->Cout)) {       // 16x16 pixels x 128 channels per block (kernels_wino_c128.hip; its own weight layout)
-        const int rc = femasr_conv_wino_c128_launch(s, a, variant_out);
-        if (rc == FEMASR_OK && variant_out) *variant_out += kNumW;
-        return rc;
-    }
-    const int vi = 3 * (gn ? (a->fast_act ? (a->fast_act == 2 ? 3 : 2) : 1) : 0) + (a->res1 ? (a->res2 ? 2 : 1) : 0);
+    const int vi = 3 * (gn ? (a->fast_act ? 2 : 1) : 0) + (a->res1 ? (a->res2 ? 2 : 1) : 0);
     WVariant &v = g_wv[vi];
     const size_t lds = wino_lds_bytes(a->Cin, gn);
     int dev = 0;
@@ -721,45 +617,7 @@ int femasr_conv_wino_launch(hipStream_t s, const femasr_conv_args *a, int *varia
     return FEMASR_OK;
 }
 
-static std::atomic<int> g_wino_m{-1};       // -1: not read yet; 0 fp32 M phase, 1 bf16-pipe M phase
-bool femasr_wino_mphase_bf16()
-{
-    int v = g_wino_m.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("FEMASR_WINO_M");
-        v = e ? (!strcmp(e, "bf16") ? 1 : 0) : FEMASR_WINO_M_DEFAULT;
-        g_wino_m.store(v, std::memory_order_relaxed);
-    }
-    return v == 1;
-}
-
 extern "C" {
-
-// tests / A-B measurements: 1 = the F(4x4,3x3) convs of the DEFAULT decoder math ('fp32') run their M phase on the bf16 matrix pipe (three-term
-// split, six products; femasr_conv_args.fast_act = 2), 0 = on the fp32 MFMA, < 0 = what the environment says (FEMASR_WINO_M=bf16|fp32).
-// Process-global, atomic; plans do not depend on it.
-int femasr_debug_wino_mphase(int bf16)
-{
-    g_wino_m.store(bf16 < 0 ? -1 : (bf16 ? 1 : 0), std::memory_order_relaxed);
-    return FEMASR_OK;
-}
-
-int femasr_debug_wino_limits(int log2_total, int log2_image)
-{
-    FEMASR_REQUIRE(log2_total >= 0 && log2_total <= 31 && log2_image >= 0 && log2_image <= 27, "debug_wino_limits: exponents are 0 (default) or up to 31 / 27");
-    g_log2_total.store(log2_total ? log2_total : 31, std::memory_order_relaxed);
-    g_log2_image.store(log2_image ? log2_image : 27, std::memory_order_relaxed);
-    return FEMASR_OK;
-}
-
-// tests / A-B measurements: 0 = every layer in the 2 x 16x16-pixel x 64-channel form (the default), 1 = layers with Cout % 128 == 0 in the
-// 16x16 x 128 form of kernels_wino_c128.hip, < 0 = what the environment says (FEMASR_WINO_C128, default 0).  Weights packed under one
-// setting must be launched under the same one.
-int femasr_debug_wino_form(int c128)
-{
-    femasr_wino_c128_set_form(c128);
-    return FEMASR_OK;
-}
 
 #ifdef FEMASR_WINO_TT
 int femasr_debug_wino_ttbuf(unsigned long long *dev_buf)      // [blocks][2][64] on the device, zero-filled by the caller
@@ -768,24 +626,15 @@ int femasr_debug_wino_ttbuf(unsigned long long *dev_buf)      // [blocks][2][64]
 }
 #endif
 
-// fp32 image + (round 5) the bf16 images of the same U for the bf16-pipe M phase: planes 1 + 2 (the size of the fp32 image) and plane 3 (half)
-static size_t wino_fp32_floats(int O, int I) { return (I % 32) == 0 ? (size_t)(I / 8) * 36 * ((O + 31) / 32) * 256 : 0; }
-size_t femasr_wino_weight_floats(int O, int I) { const size_t n = wino_fp32_floats(O, I); return 2 * n + n / 2; }
+size_t femasr_wino_weight_floats(int O, int I) { return (I % 32) == 0 ? (size_t)(I / 8) * 36 * ((O + 31) / 32) * 256 : 0; }
 
 int femasr_repack_oihw_wino(void *stream, const float *in, int O, int I, float *out)
 {
     FEMASR_REQUIRE(in && out && O > 0 && I > 0 && (I % 32) == 0, "repack_wino: needs a 3x3 OIHW weight with I %% 32 == 0");
-    const size_t total = wino_fp32_floats(O, I);
-    if (femasr_wino_c128_shape(I, O)) return femasr_repack_oihw_wino_c128((hipStream_t)stream, in, O, I, out, total);      // the layout of the x128 block shape
+    const size_t total = femasr_wino_weight_floats(O, I);
     size_t blocks = (total + 255) / 256;
     if (blocks > 65535) blocks = 65535;
     hipLaunchKernelGGL(repack_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, O, I, out, total);
-    FEMASR_CHECK_HIP(hipGetLastError());
-    const size_t recs = total / 4;            // one record per (step, component, tile, lane)
-    blocks = (recs + 255) / 256;
-    if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(repack_wino_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, O, I,
-                       reinterpret_cast<uint4 *>(out + total), reinterpret_cast<uint2 *>(out + 2 * total), recs);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

@@ -503,15 +503,17 @@ unsigned long long g_attr_devs[6] = {0, 0, 0, 0, 0, 0};
 
 }  // namespace
 
-bool femasr_conv_wino_up2_shape_ok(const femasr_conv_args *a)
+bool femasr_conv_wino_up2_shape_ok_lim(const femasr_conv_args *a, int log2_total, int log2_image)
 {
+    const size_t tot = (size_t)1 << log2_total, img = (size_t)1 << log2_image;
     return a->ksz == 3 && a->stride == 1 && a->pad == 1 && a->up2 && a->act == FEMASR_ACT_NONE && a->prologue == FEMASR_PRO_NONE &&
            (a->Cin % BK) == 0 && a->Cin <= 1024 && (a->Cout % 64) == 0 &&
-           (size_t)a->B * a->H * a->W * a->Cin < femasr_wino_limit_total() && (size_t)a->B * 4 * a->H * a->W * a->Cout < femasr_wino_limit_total() &&
-           (size_t)a->H * a->W * a->Cin < femasr_wino_limit_image() &&          // two images within the 2 GiB range of the input descriptor
-           (size_t)4 * a->H * a->W * a->Cout < femasr_wino_limit_image() &&     // ... and of the output descriptor
+           (size_t)a->B * a->H * a->W * a->Cin < tot && (size_t)a->B * 4 * a->H * a->W * a->Cout < tot &&
+           (size_t)a->H * a->W * a->Cin < img &&          // two images within the 2 GiB range of the input descriptor
+           (size_t)4 * a->H * a->W * a->Cout < img &&     // ... and of the output descriptor
            (size_t)25 * a->Cin * a->Cout < ((size_t)1 << 29);
 }
+bool femasr_conv_wino_up2_shape_ok(const femasr_conv_args *a) { return femasr_conv_wino_up2_shape_ok_lim(a, FEMASR_WINO_LOG2_TOTAL, FEMASR_WINO_LOG2_IMAGE); }
 const char *femasr_conv_wino_up2_variant_name() { return "conv3x3_wino_up2<2x16x16px x64,waves=8>"; }
 
 int femasr_conv_wino_up2_launch(hipStream_t s, const femasr_conv_args *a, double *flops_out)

@@ -83,7 +83,6 @@ struct WSpec {
     void *lin3 = nullptr;   // three bf16 planes of a 1x1 / linear weight (femasr_repack_k1_bf16s), owned
     float *up2w = nullptr;  // phase matrices of a nearest-x2 conv (femasr_repack_oihw_up2), owned
     float *wino = nullptr;  // Winograd-domain weights (decoder-side 3x3 convs of single-codebook networks), owned
-    bool wino_c128 = false; // ... packed in the layout of the 16x16-pixel x 128-channel block shape (femasr_debug_wino_form at pack time)
     bool up2 = false;       // the conv behind nn.Upsample(x2) of an up / decoder block
     bool set = false;
     size_t numel() const { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i]; return n; }
@@ -113,6 +112,7 @@ struct T {          // NHWC activation view
     int B = 0, H = 0, W = 0, C = 0;
     double *gn_part = nullptr;   // fused GroupNorm partial moments written by the producing bf16x3 conv (or null)
     int gn_tiles = 0;
+    void *planes = nullptr;      // instead of p: the tensor as three packed bf16 planes (femasr_pack_rows_bf16s layout; Swin tokens in linear_math 1)
     size_t numel() const { return (size_t)B * H * W * C; }
 };
 
@@ -188,6 +188,7 @@ struct femasr_handle {
     // one sub-batch's kernels fill the tail / HBM-bound phases of the other's
     int decoder_math = 0;   // femasr_set_decoder_math
     int linear_math = 1;    // femasr_set_linear_math: 1 = fp32-grade product on the bf16 matrix pipe, 0 = fp32 MFMA chain
+    int wino_log2_total = FEMASR_WINO_LOG2_TOTAL, wino_log2_image = FEMASR_WINO_LOG2_IMAGE;      // femasr_debug_set_wino_limits (planner only)
     int nsub = 1;
     std::vector<hipStream_t> sub_streams;
     std::vector<hipEvent_t> sub_done;
@@ -197,9 +198,9 @@ struct femasr_handle {
 
 namespace {
 
-enum { SLOT_GN = 0, SLOT_LN, SLOT_ATTN, SLOT_VQ, SLOT_LAYOUT, SLOT_MLP, SLOT_SMALL_COUNT };
+enum { SLOT_GN = 0, SLOT_LN, SLOT_ATTN, SLOT_VQ, SLOT_LAYOUT, SLOT_SMALL_COUNT };
 const char *kSmallNames[SLOT_SMALL_COUNT] = {"gn_moments", "layernorm", "window_attention", "vq(codebook lookup)",
-                                             "pad/crop/gather layout", "mlp_fused<128 tokens,fc1+gelu+fc2,waves=8>"};
+                                             "pad/crop/gather layout"};
 
 struct Scope {   // event pair around one launch (or a small group of launches)
     femasr_handle *h;
@@ -377,12 +378,23 @@ struct Ctx {
         const float *in_add = nullptr;   // second input, added while staging: only when up2_wino_ok() said the x2 Winograd-type form will run
         bool lowp = false;       // behind the VQ lookup: may use the bf16x3 path when the handle opts in
         bool want_gn = false;    // the output feeds a GroupNorm: let a bf16x3 conv emit its partial moments
+        // linear_math 1 only (planes_ok()): the input is given as packed bf16 planes (x.p is then not read: x carries the shape) /
+        // the output is written as packed planes into the buffer the returned T carries in .planes (y.p stays null)
+        const void *in_planes = nullptr;
+        bool out_planes = false;
     };
     T conv(const T &x, const std::string &prefix, int cout, const ConvOpt &o)
     {
         const int Hv = o.up2 ? 2 * x.H : x.H, Wv = o.up2 ? 2 * x.W : x.W;
         const int Ho = (Hv + 2 * o.pad - o.ksz) / o.stride + 1, Wo = (Wv + 2 * o.pad - o.ksz) / o.stride + 1;
-        T y = alloc_t(x.B, Ho, Wo, cout);
+        T y;
+        if (o.out_planes) {
+            y.B = x.B; y.H = Ho; y.W = Wo; y.C = cout;
+            y.planes = arena->alloc(femasr_packed_rows_bf16s_bytes((int64_t)x.B * Ho * Wo, cout));
+            if (!y.planes && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
+        } else {
+            y = alloc_t(x.B, Ho, Wo, cout);
+        }
         // The args struct is populated (shapes; pointers may be null in the dry run) BEFORE the planning decisions, and the
         // same eligibility helpers decide in the dry and in the real run, so both plan identical buffers.
         femasr_conv_args a{};
@@ -391,6 +403,7 @@ struct Ctx {
         a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
         a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
         a.in_add = o.in_add;
+        a.in_bf16s = o.in_planes; a.out_bf16s = y.planes;
         const void *split = nullptr;
         // (several codebooks: the decoder feeds the later lookups through before_quant_group[q > 0]: only the convs that follow the LAST
         // lookup may take the bf16x3 / Winograd forms - behind_every_lookup)
@@ -404,7 +417,8 @@ struct Ctx {
         // (they cannot move a VQ index; oracle: OracleNet.wino).  decoder_math 2 = 'fp32_direct' keeps the direct form; 0 runs the
         // SiLU of their GroupNorm prologue on the hardware exp2 / rcp units, 3 = 'fp32_strict' keeps it IEEE-exact (== oracle).
         const bool wino_on = !lowp_on && behind && (h->decoder_math == 0 || h->decoder_math == 3) &&
-                             (o.up2 ? femasr_conv_wino_up2_shape_ok(&a) : femasr_conv_wino_shape_ok(&a));
+                             (o.up2 ? femasr_conv_wino_up2_shape_ok_lim(&a, h->wino_log2_total, h->wino_log2_image)
+                                    : femasr_conv_wino_shape_ok_lim(&a, h->wino_log2_total, h->wino_log2_image));
         const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
                                    : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
         if (o.want_gn && gn_ok) {
@@ -430,11 +444,6 @@ struct Ctx {
         if (wino_on) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) wino_w = h->specs[it->second].wino;
-            if (wino_w && !o.up2 && h->specs[it->second].wino_c128 != femasr_wino_c128_shape(a.Cin, a.Cout)) {
-                // femasr_debug_wino_form changed between femasr_finalize_weights and this forward: the two block shapes read different layouts
-                rc = femasr_set_error(FEMASR_ERR_WEIGHT, "conv %s: its Winograd weights were packed under another femasr_debug_wino_form setting - finalize the weights again", prefix.c_str());
-                return y;
-            }
         }
         if (o.in_add && !(wino_on && o.up2)) {
             rc = femasr_set_error(FEMASR_ERR_INVALID, "conv %s: a second input was scheduled for a conv that does not run in the x2 Winograd-type form", prefix.c_str());
@@ -451,6 +460,10 @@ struct Ctx {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) lin3 = h->specs[it->second].lin3;
         }
+        if ((o.in_planes || o.out_planes) && !lin3) {
+            rc = femasr_set_error(FEMASR_ERR_INVALID, "conv %s: bf16 planes were scheduled for a layer that does not run in the split arithmetic", prefix.c_str());
+            return y;
+        }
         if (lin3) {
             r = femasr_gemm_bf16s_launch(s(), &a, lin3, &variant, &flops);
             variant += femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count() + femasr_conv_wino_variant_count() + 1;
@@ -460,7 +473,7 @@ struct Ctx {
             variant += femasr_conv_variant_count();
         } else if (wino_w) {
             a.w_wino = wino_w;
-            a.fast_act = h->decoder_math == 0 ? (femasr_wino_mphase_bf16() && !o.up2 ? 2 : 1) : 0;      // 2: + the M phase on the bf16 matrix pipe (kernels_wino.hip MM = 1)
+            a.fast_act = h->decoder_math == 0 ? 1 : 0;
             if (o.up2) {
                 r = femasr_conv_wino_up2_launch(s(), &a, &flops);
                 variant = femasr_conv_wino_variant_count();          // the slot behind the F(4x4,3x3) variants
@@ -529,18 +542,31 @@ struct Ctx {
     T swin_block(const T &y, int B, int H, int W, const std::string &bp, int shift)
     {
         const int rows = B * H * W, C = 256;
+        // linear_math 1 (round 6): norm1 / norm2 write the three bf16 planes of their output in the packed layout the split GEMM copies
+        // straight into LDS (6 bytes per value instead of 4; the GEMM's A side does no conversion work), and fc1 hands its GELU output to fc2
+        // the same way.  The attention kernel still writes fp32 rows: proj splits them in its staging.
+        const bool planes = h->linear_math == 1;
         auto ln = [&](const T &t, const std::string &np) {       // normalised tokens, materialised once (read by DMA in the GEMM)
-            T o = alloc_t(1, rows, 1, C);
+            T o;
+            o.B = 1; o.H = rows; o.W = 1; o.C = C;
+            if (planes) {
+                o.planes = arena->alloc(femasr_packed_rows_bf16s_bytes(rows, C));
+                if (!o.planes && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
+            } else {
+                o.p = alloc_f(o.numel());
+            }
             if (rc || dry()) return o;
-            Scope sc(h, s(), dry(), SLOT_LN, 0.0, (double)t.numel() * 8.0);
-            const int r = femasr_layernorm(s(), t.p, rows, C, Wt(np + ".weight"), Wt(np + ".bias"), 1e-5f, o.p);
+            Scope sc(h, s(), dry(), SLOT_LN, 0.0, (double)t.numel() * (planes ? 10.0 : 8.0));
+            const int r = planes ? femasr_layernorm_bf16s(s(), t.p, rows, C, Wt(np + ".weight"), Wt(np + ".bias"), 1e-5f, o.planes)
+                                 : femasr_layernorm(s(), t.p, rows, C, Wt(np + ".weight"), Wt(np + ".bias"), 1e-5f, o.p);
             if (r && !rc) rc = r;
             return o;
         };
+        auto drop = [&](T &t) { if (t.planes) { release(t.planes); t.planes = nullptr; } else release(t); };
         T n1 = ln(y, bp + ".norm1");
-        ConvOpt oq; oq.ksz = 1; oq.pad = 0;
+        ConvOpt oq; oq.ksz = 1; oq.pad = 0; oq.in_planes = n1.planes;
         T qkv = conv(n1, bp + ".attn.qkv", 3 * C, oq);
-        release(n1);
+        drop(n1);
         T att = alloc_t(1, rows, 1, C);
         if (!rc && !dry()) {
             Scope sc(h, s(), dry(), SLOT_ATTN, 4.0 * (double)rows * 64.0 * C, (double)rows * C * 16.0);
@@ -552,29 +578,12 @@ struct Ctx {
         T y1 = conv(att, bp + ".attn.proj", C, op);
         release(att);
         T n2 = ln(y1, bp + ".norm2");
-        // FEMASR_MLP=fused: fc1 + GELU + fc2 + residual in one kernel (kernels_mlp.hip) - bit-identical to the two launches below, measured
-        // 18 % SLOWER than them at B = 16 (0.94 vs 0.80 ms per block-layer, profiles/r04_mlp_fused.txt), so it is not the default
-        static const bool fused_mlp = [] { const char *e = getenv("FEMASR_MLP"); return e && !strcmp(e, "fused"); }();
-        if (fused_mlp && femasr_mlp_fused_shape_ok(C, 4 * C)) {
-            T y2 = alloc_t(1, rows, 1, C);
-            if (!rc && !dry()) {
-                Scope sc(h, s(), dry(), SLOT_MLP, 0.0, (double)rows * C * 12.0);
-                double flops = 0;
-                const int r = femasr_mlp_fused_launch(s(), n2.p, rows, Wt(bp + ".mlp.fc1.weight"), Wt(bp + ".mlp.fc1.bias"), Wt(bp + ".mlp.fc2.weight"),
-                                                      Wt(bp + ".mlp.fc2.bias"), y1.p, y2.p, &flops);
-                sc.set_flops(flops);
-                if (r && !rc) rc = r;
-            }
-            release(n2);
-            release(y1);
-            return y2;
-        }
-        ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.act = FEMASR_ACT_GELU;
+        ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.act = FEMASR_ACT_GELU; o1.in_planes = n2.planes; o1.out_planes = planes;
         T hdn = conv(n2, bp + ".mlp.fc1", 4 * C, o1);
-        release(n2);
-        ConvOpt o2; o2.ksz = 1; o2.pad = 0; o2.res1 = y1.p;
+        drop(n2);
+        ConvOpt o2; o2.ksz = 1; o2.pad = 0; o2.res1 = y1.p; o2.in_planes = hdn.planes;
         T y2 = conv(hdn, bp + ".mlp.fc2", C, o2);
-        release(hdn);
+        drop(hdn);
         release(y1);
         return y2;
     }
@@ -609,7 +618,7 @@ struct Ctx {
         femasr_conv_args a{};
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ksz = 3; a.stride = 1; a.pad = 1; a.up2 = 1;
         a.prologue = FEMASR_PRO_NONE; a.act = FEMASR_ACT_NONE; a.Ho = 2 * H; a.Wo = 2 * W;
-        return (h->decoder_math == 0 || h->decoder_math == 3) && femasr_conv_wino_up2_shape_ok(&a);
+        return (h->decoder_math == 0 || h->decoder_math == 3) && femasr_conv_wino_up2_shape_ok_lim(&a, h->wino_log2_total, h->wino_log2_image);
     }
 
     T up_block(const T &x, const std::string &p, int cout, const float *res2_last, bool lowp = false, const float *in_add = nullptr)   // Upsample x2 -> conv -> RB -> RB
@@ -867,7 +876,7 @@ int check_ready(const femasr_handle *h)
 extern "C" {
 
 const char *femasr_last_error(void) { return g_err; }
-int femasr_version(void) { return 101; }
+int femasr_version(void) { return 102; }
 
 int femasr_create(const femasr_config *cfg, femasr_handle **out)
 {
@@ -987,7 +996,6 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
         rc = w.up2 ? femasr_repack_oihw_wino_up2(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.wino)
                    : femasr_repack_oihw_wino(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.wino);
         if (rc) return rc;
-        w.wino_c128 = !w.up2 && femasr_wino_c128_shape((int)w.shape[1], (int)w.shape[0]);      // (the layout femasr_repack_oihw_wino just chose)
     }
     if (w.kind == W_CONV && dec_side && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {
         const size_t nb = femasr_packed_weight_bf16x3_bytes((int)w.shape[0], (int)w.shape[1], 3, 3);
@@ -1228,6 +1236,16 @@ int femasr_set_decoder_math(femasr_handle *h, int mode)
     FEMASR_REQUIRE(h && mode >= 0 && mode <= 3, "set_decoder_math: mode must be 0 (fp32), 1 (bf16x3), 2 (fp32, direct convs only) or 3 (fp32, exact SiLU)");
     if (h->decoder_math != mode) h->plans.clear();
     h->decoder_math = mode;
+    return FEMASR_OK;
+}
+
+int femasr_debug_set_wino_limits(femasr_handle *h, int log2_total, int log2_image)
+{
+    FEMASR_REQUIRE(h && log2_total >= 0 && log2_total <= FEMASR_WINO_LOG2_TOTAL && log2_image >= 0 && log2_image <= FEMASR_WINO_LOG2_IMAGE,
+                   "debug_set_wino_limits: exponents are 0 (default) or up to %d / %d", FEMASR_WINO_LOG2_TOTAL, FEMASR_WINO_LOG2_IMAGE);
+    h->wino_log2_total = log2_total ? log2_total : FEMASR_WINO_LOG2_TOTAL;
+    h->wino_log2_image = log2_image ? log2_image : FEMASR_WINO_LOG2_IMAGE;
+    h->plans.clear();
     return FEMASR_OK;
 }
 

@@ -1,5 +1,6 @@
-// wino_common.h - what the two F(4x4,3x3) kernels (kernels_wino.hip: 2 x 16x16 pixels x 64 output channels; kernels_wino_c128.hip:
-// 16x16 pixels x 128 output channels) share: launch parameters, LDS geometry, the 6-point transforms, experiment switches.
+// wino_common.h - launch parameters, LDS geometry, the 6-point transforms and the experiment switches of the F(4x4,3x3) kernel
+// (kernels_wino.hip: 2 x 16x16 pixels x 64 output channels per block).  Round 4's second block shape (16x16 pixels x 128 channels,
+// kernels_wino_c128.hip: 7 % fewer cycles, 3 % more time at the 1400 W package limit) was removed in round 6; git history and profiles/r04_j_* have it.
 // The including file defines FEMASR_WTT_BUF (the name of its cycle-stamp buffer) first.
 #pragma once
 #include "conv_common.h"
@@ -104,14 +105,6 @@ __device__ __forceinline__ float wino_g6(int r, float g0, float g1, float g2)
 }
 
 }  // namespace
-
-// kernels_wino_c128.hip: the 16x16-pixel x 128-channel block shape (layers with Cout % 128 == 0)
-bool femasr_wino_c128_shape(int Cin, int Cout);
-void femasr_wino_c128_set_form(int on);
-int femasr_conv_wino_c128_variant_count();
-const char *femasr_conv_wino_c128_variant_name(int v);
-int femasr_repack_oihw_wino_c128(hipStream_t s, const float *in, int O, int I, float *out, size_t total);
-int femasr_conv_wino_c128_launch(hipStream_t s, const femasr_conv_args *a, int *variant_out);
 
 // Schedule variants built and A/B-measured in round 4 (all bit-identical; profiles/r04_wino_variants.txt), removed again except the last two:
 //   * the patch of step s+2 requested at the start of the M phase instead of at pair 5: 4 % SLOWER - loads return in order, the slow HBM

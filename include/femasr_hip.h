@@ -59,7 +59,8 @@ typedef struct {
 } femasr_config;
 
 const char *femasr_last_error(void);
-/* 100 * major + minor.  101: femasr_conv_args ends with w_bf16s (a caller built against 100 passes a shorter struct: rebuild). */
+/* 100 * major + minor.  102: femasr_conv_args ends with in_bf16s / out_bf16s; the debug hooks moved to femasr_hip_debug.h; femasr_mlp_fused and the
+ * process-global femasr_debug_wino_* switches are gone (a caller built against 101 passes a shorter struct: rebuild). */
 int femasr_version(void);
 
 /* ---- model handle ------------------------------------------------------------------ */
@@ -185,9 +186,7 @@ typedef struct {
     int32_t fast_act;     /* Winograd convs with the GN+SiLU prologue only: 1 = SiLU through the hardware exp2 / rcp units
                              (v_exp_f32, v_rcp_f32: 1 ulp each) instead of the IEEE-exact polynomial + division - ~6x fewer
                              VALU instructions in the staging; output within ~1e-6 relative of the exact form (no longer
-                             bit-identical to the oracle).  0 = exact.  2 (round 5) = 1 + the M phase of the F(4x4,3x3) form (not the x2 form) on the
-                             bf16 matrix pipe: V and U split exactly into three bf16 terms, six partial products (v_mfma_f32_32x32x8_bf16_1k),
-                             fp32 accumulation - fp32-grade, output within ~1e-6 relative of fast_act = 1. */
+                             bit-identical to the oracle).  0 = exact. */
     const float *in_add;  /* optional second INPUT tensor of the same (B,H,W,Cin) shape: the conv reads in + in_add (one fp32 add per
                              element while staging).  Only the x2 Winograd-type form takes it (up2 = 1 with w_wino; anything else refuses):
                              FeMaSRNet's decoder adds the encoder's skip feature to a stage's input (`x = x + enc_feats[i]`,
@@ -198,6 +197,13 @@ typedef struct {
                              partial products of relative size >= 2^-16 accumulated in fp32 (two accumulators), ~3x closer to the fp64
                              result than the fp32 fmaf chain and bit-identical to oracle/femasr_oracle.c orc_linear_bf16s, which restates
                              the instruction's accumulation arithmetic from hardware probes (kernels_gemm_bf16.hip).  `w` is not read. */
+    const void *in_bf16s; /* optional (struct version 102, with w_bf16s only): the INPUT as its three bf16 planes in the packed layout of
+                             femasr_pack_rows_bf16s - what femasr_layernorm_bf16s and a producing layer's out_bf16s write.  The kernel's A side is
+                             then pure LDS-DMA (no conversion work in its main loop); `in` is not read and may be NULL.  Same bits as with the
+                             fp32 input: the split is a pure function of the fp32 value. */
+    void *out_bf16s;      /* optional (struct version 102, with w_bf16s and in_bf16s only; Cout % 16 == 0, no residual operands): the OUTPUT is written as
+                             its three bf16 planes (packed layout, femasr_packed_rows_bf16s_bytes(rows, Cout) bytes) instead of fp32 rows - the
+                             next linear takes it as in_bf16s (fc1 -> fc2: network_swinir.py:25-29); `out` is not written and may be NULL. */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 
@@ -216,6 +222,10 @@ int femasr_ln_stats(void *stream, const float *x, int64_t rows, int C, float eps
  * (network_swinir.py:243,277: norm1 / norm2 ahead of qkv / fc1). */
 int femasr_layernorm(void *stream, const float *x, int64_t rows, int C, const float *gamma, const float *beta,
                      float eps, float *y);
+/* The same LayerNorm (C = 256), written as the three bf16 planes of y in the packed layout above (femasr_packed_rows_bf16s_bytes(rows, 256)
+ * bytes): norm1 / norm2 in front of qkv / fc1 when those run with in_bf16s (linear_math 1) - 6 bytes per value instead of 4, and the
+ * consuming GEMM does no conversion work.  femasr_unpack_rows_bf16s of the result equals femasr_layernorm's output bit for bit. */
+int femasr_layernorm_bf16s(void *stream, const float *x, int64_t rows, int C, const float *gamma, const float *beta, float eps, void *out);
 /* 8x8 (shifted-)window multi-head attention incl. rel-pos bias and shift mask
  * (network_swinir.py:114-145, 216-237, 249-272).  qkv (B,H*W,3C) -> out (B,H*W,C), natural token order. */
 int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W, int C, int heads, int shift,
@@ -274,9 +284,7 @@ size_t femasr_up2_weight_floats(int O, int I);
 /* 3x3 OIHW -> femasr_conv_args.w_wino: U = G g G^T (6x6 per (o, i)) of F(4x4,3x3), down the columns then along the rows in
  * the operation order of oracle/femasr_oracle.c orc_g6, stored [Cin/8][36 components][Cout/32][lane][4] (the MFMA B fragments
  * of one 8-channel step: 1 KiB per wave load).  out: femasr_wino_weight_floats(O, I) floats = 36 * I * 32*ceil(O/32).
- * Under femasr_debug_wino_form(1) / FEMASR_WINO_C128=1 layers with O % 128 == 0 run in the 16x16-pixel x 128-channel block shape and are stored
- * [Cin/16][36][Cout/64][channel quad 4][lane = output channel % 64][4 channels] instead - the same number of floats; the layout is
- * private to the library (pack and launch through it). */
+ * The layout is private to the library (pack and launch through it). */
 size_t femasr_wino_weight_floats(int O, int I);
 int femasr_repack_oihw_wino(void *stream, const float *in, int O, int I, float *out);
 /* The same for the conv behind nn.Upsample(x2, nearest) (femasr_arch.py:172-173,202-203): a 4x4 output tile reads a 4x4 patch of
@@ -291,14 +299,17 @@ int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *o
  * [Cin/16][ceil(Cout/32)][plane][lane][8 bf16] - the MFMA B fragments of one 16-channel step, 1 KiB per (column tile, plane). */
 size_t femasr_packed_weight_bf16s_bytes(int O, int I);
 int femasr_repack_k1_bf16s(void *stream, const float *w_oi, int O, int I, void *out);
+/* The same split for ACTIVATION rows (femasr_conv_args.in_bf16s / out_bf16s): fp32 (rows, C) row-major, C % 16 == 0 ->
+ * [ceil(rows/128)][C/16][plane 3][granule 2][row % 128][8 bf16]: one 16-channel step of a 128-row block is 12 contiguous KiB, which
+ * the GEMM copies into LDS as twelve 1-KiB LDS-DMA pieces; x = plane1 + plane2 + plane3 exactly.  Rows past `rows` in the last block
+ * are zero (pack) / unspecified (a producer's output) and are never read into a stored result.  unpack is the exact inverse (tests). */
+size_t femasr_packed_rows_bf16s_bytes(int64_t rows, int C);
+int femasr_pack_rows_bf16s(void *stream, const float *x, int64_t rows, int C, void *out);
+int femasr_unpack_rows_bf16s(void *stream, const void *in, int64_t rows, int C, float *x);
 /* Arithmetic of the network's 1x1 convs / nn.Linear layers (the Swin qkv / proj / fc1 / fc2 and before_quant):
  * 1 (default, 'bf16_split'): the fp32-grade product on the bf16 matrix pipe described at femasr_conv_args.w_bf16s;
  * 0 ('fp32'): one fp32 fmaf chain per output on the fp32 MFMA (kernels_gemm.hip), bit-identical to OracleNet(linear_math='fp32'). */
 int femasr_set_linear_math(femasr_handle *h, int mode);
-/* Test hook behind that arithmetic: n independent v_mfma_f32_32x32x16_bf16 evaluations, case i = 16 products a[i][s] * b[i][s]
- * (bf16 bit patterns; k slot s = 8 * (lane / 32) + element) plus the fp32 accumulator input c[i] -> d[i].  tests/test_gpu_r5.py runs
- * constructed cases through it and compares them bit for bit with the oracle's restatement (orc_mfma_dot8). */
-int femasr_debug_mfma_bf16(void *stream, const uint16_t *a, const uint16_t *b, const float *c, int n, float *d);
 
 /* Split-bf16 (hi/lo) fragment-major weights for the opt-in bf16x3 conv path (3x3 convs behind the VQ lookup). */
 size_t femasr_packed_weight_bf16x3_bytes(int O, int I, int kh, int kw);
@@ -330,42 +341,8 @@ int femasr_image_f32_to_u8(void *stream, const float *in_chw, int H, int W, int 
 #define FEMASR_CLOCK_PROBE_BLOCKS 256
 int femasr_clock_probe(void *stream, int mfmas_per_wave, unsigned long long *ticks);
 int femasr_clock_probe_entries(void);      /* number of 64-bit entries femasr_clock_probe writes (size the buffer from this) */
-/* Tuning / test hook of the 1x1-conv and linear GEMM (kernels_gemm.hip): force one block configuration for every later launch -
- * 0: 128x128 tiles, 32-deep chunks, 2 stages;  1: 128x128, 16-deep, 3 stages;  2: 64x64 tiles (what small launches get);
- * any negative value: automatic choice by tile count (the default).  Results are bit-identical in every configuration (each
- * output is the same fmaf chain); the parity tests run all of them.  Returns the previous setting (negative = automatic). */
-int femasr_gemm_force_config(int cfg);
-/* Same kind of hook for the 3x3 / strided convs with more than 64 output channels: a launch of fewer than `blocks` 128-column
- * blocks runs with 64-column blocks instead (twice the blocks, half the serial chain each: batch-1 latency).  0 = never,
- * negative = the default (1.5 x the device's compute units: 384 on a 256-CU MI355X).  Bit-identical either way (same weights layout, same per-wave pixel tiles, same GroupNorm
- * partial-moment order).  Returns the previous threshold. */
-int femasr_conv_small_launch_blocks(int blocks);
-/* The Swin MLP (network_swinir.py:14-30,276-277) in ONE kernel: out = res + fc2(gelu(fc1(x))), x / res / out (M, C) row-major,
- * w1_packed / w2_packed = fc1.weight (hidden, C) / fc2.weight (C, hidden) through femasr_repack_oihw(.., kh = kw = 1) (the GEMM layout);
- * res may be NULL.  Built for C = 256, hidden = 1024 (the reference's only configuration: embed_dim 256, mlp_ratio 4); every output
- * is the same fp32 fmaf chain as femasr_conv2d's two launches (fc1 with FEMASR_ACT_GELU, fc2 with res1), i.e. bit-identical.
- * Measured slower than the two launches on MI355X (one 8-wave block per CU in lockstep loses more at its barriers than the hidden
- * tensor's HBM round trip, already hidden, cost): FeMaSRNet's forward keeps the two launches unless FEMASR_MLP=fused is set. */
-int femasr_mlp_fused(void *stream, const float *x, int64_t M, int C, int hidden, const float *w1_packed, const float *b1,
-                     const float *w2_packed, const float *b2, const float *res, float *out);
-/* Test hook of the Winograd-form convs' size limits (kernels_wino.hip / kernels_wino_up2.hip address their tensors with 32-bit
- * byte offsets: a layer whose input or output has 2^31 or more elements, or 2^27 or more per image, runs in the direct /
- * phase-filter form instead).  log2_total / log2_image replace the two exponents (31 / 27; smaller values move the boundary down
- * to sizes a test can allocate), 0 = the default.  Process-global, atomic; plans cached by a handle are not re-made - set it
- * before the first forward of a shape.  Returns FEMASR_OK. */
-int femasr_debug_wino_limits(int log2_total, int log2_image);
-/* Test / measurement hook of the F(4x4,3x3) convs' block shape.  c128 = 0 (the default): every layer runs as 2 x 16x16 pixels x 64
- * output channels per block (kernels_wino.hip); c128 > 0: layers with Cout % 128 == 0 run as 16x16 pixels x 128 channels per block
- * (kernels_wino_c128.hip: half the staging / transform work per MFMA, twice the weight-fragment traffic; measured 7 % fewer cycles
- * and 3 % more time - it reaches the 1400 W package limit and the clock drops); c128 < 0: what the environment says
- * (FEMASR_WINO_C128=1 selects the x128 form).  The two forms produce the same bits and have different packed-weight layouts
- * (femasr_repack_oihw_wino follows the setting): weights packed under one setting must be launched under the same one - set it
- * before femasr_finalize_weights / femasr_repack_oihw_wino.  Process-global, atomic.  Returns FEMASR_OK. */
-int femasr_debug_wino_form(int c128);
-/* Test / measurement hook: 1 = the F(4x4,3x3) convs of decoder math 0 ('fp32', the default) run their M phase on the bf16 matrix pipe
- * (femasr_conv_args.fast_act = 2), 0 = on the fp32 MFMA, < 0 = what the environment says (FEMASR_WINO_M=bf16|fp32).  Process-global, atomic. */
-int femasr_debug_wino_mphase(int bf16);
-
+/* Test / tuning hooks (process-global block-shape overrides, the per-handle Winograd size limit, the MFMA probe) are declared in
+ * include/femasr_hip_debug.h: they are exported by the library but are not part of the drop-in interface. */
 #ifdef __cplusplus
 }
 #endif

@@ -244,13 +244,17 @@ def test_fuzz_gn_and_ln_moments_bit_exact(cuda_device, seed):
 
 @pytest.mark.parametrize('seed', range(4 * _MULT))
 def test_fuzz_test_tile_vs_oracle(cuda_device, seed):
-    """`test_tile` with random tile size / pad (ragged border tiles, several shape classes) == the oracle's test_tile."""
+    """`test_tile` with random tile size / pad (ragged border tiles, several shape classes) == the oracle's test_tile.  The first case of
+    every four runs the product default arithmetic of the linears, the others the fp32 chain on both sides (this test is about the tiling
+    logic; the restated matrix-instruction arithmetic costs ~30x on the CPU side and has its own tests)."""
     import gpu_utils as G
     import torch
     from helpers import oracle_net, synth_weights
     rng = np.random.RandomState(1500 + seed)
     w = synth_weights('x4', 31 + seed, 'trained')
     net = G.build_net('x4', w, cuda_device)
+    lm = 'bf16_split' if seed % 4 == 0 else 'fp32'
+    net.linear_math = lm
     net.num_streams = int(rng.choice([1, 2]))
     ts, pad = int(rng.choice([24, 32, 40, 48])), int(rng.choice([0, 4, 8]))
 
@@ -260,6 +264,6 @@ def test_fuzz_test_tile_vs_oracle(cuda_device, seed):
     h, wd = size(), size()
     x = synth.synth_input(60 + seed, (1, 3, h, wd))
     y = net.test_tile(torch.from_numpy(x).to(cuda_device), ts, pad).cpu().numpy()
-    yo = oracle_net('x4', w).test_tile(x, ts, pad)
+    yo = oracle_net('x4', w, linear_math=lm).test_tile(x, ts, pad)
     assert y.shape == yo.shape == (1, 3, 4 * h, 4 * wd)
     assert np.array_equal(y, yo), f'max-abs {np.abs(y - yo).max():.3e}'

@@ -1,7 +1,7 @@
 """-m gpu, round 4:
   * both sides of the Winograd-form size limit (the kernels address tensors with 32-bit byte offsets; a layer beyond the limit runs
     in the direct / phase-filter form - femasr_conv_wino_shape_ok, oracle.wino_fits): the limit is moved down to sizes a test can
-    allocate with the femasr_debug_wino_limits hook, on the GPU and in the oracle together;
+    allocate with the per-handle femasr_debug_set_wino_limits hook, on the GPU and in the oracle together;
   * the whole reference testset/ directory through the CLI arithmetic (tests/golden/make_golden_r4.py), see test_testset_dir."""
 import numpy as np
 import pytest
@@ -15,16 +15,15 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def wino_limits():
-    """(log2_total, log2_image) -> set on the library and on the oracle; restored afterwards."""
+    """(net, log2_total, log2_image) -> set on the net's native handle (femasr_debug_set_wino_limits: per handle since round 6) and on the
+    oracle; the oracle's is restored afterwards, the handle dies with its net."""
     from oracle import oracle as orc
-    lib = _lib.load()
     prev = list(orc.WINO_LOG2_LIMITS)
 
-    def set_(total, image):
-        _lib.check(lib.femasr_debug_wino_limits(total, image))
+    def set_(net, total, image):
+        net.debug_wino_limits = (total, image)
         orc.WINO_LOG2_LIMITS[:] = [total or 31, image or 27]
     yield set_
-    _lib.check(lib.femasr_debug_wino_limits(0, 0))
     orc.WINO_LOG2_LIMITS[:] = prev
 
 
@@ -41,14 +40,16 @@ def test_winograd_size_limit_both_sides(cuda_device, wino_limits, log2_image, cr
     x = synth.synth_input(77, (2, 3, 32, 32))
     xg = torch.from_numpy(x).to(cuda_device)
     net0 = G.build_net('x4', w, cuda_device, decoder_math='fp32_strict')
+    net0.linear_math = 'fp32'         # (this test is about the conv forms: the fp32 chain keeps the CPU side of it 30x cheaper)
     y0, i0 = net0.test_with_indices(xg)
     y0, i0 = y0.cpu().numpy(), i0.cpu().numpy()
     del net0
-    wino_limits(0, log2_image)
     net = G.build_net('x4', w, cuda_device, decoder_math='fp32_strict')
+    net.linear_math = 'fp32'
+    wino_limits(net, 0, log2_image)
     y, idx = net.test_with_indices(xg)
     y, idx = y.cpu().numpy(), idx.cpu().numpy()
-    yo, io = oracle_net('x4', w).test(x, return_indices=True)
+    yo, io = oracle_net('x4', w, linear_math='fp32').test(x, return_indices=True)
     assert np.array_equal(idx, io) and np.array_equal(idx, i0)
     assert np.array_equal(y, yo), f'limit 2^{log2_image} ({crossing}): max-abs vs oracle {np.abs(y - yo).max():.3e}'
     d = float(np.abs(y - y0).max())
@@ -200,46 +201,6 @@ def test_test_out_parameter_writes_in_place(cuda_device):
     assert torch.equal(yt, seq)
 
 
-@pytest.mark.parametrize('rows,res', [(128, True), (300, True), (4096 + 17, True), (200, False)])
-def test_mlp_fused_bit_exact(cuda_device, rows, res):
-    """The Swin MLP in one kernel (kernels_mlp.hip: fc1 + exact GELU + fc2 + residual, the 1024-wide hidden activation stays on
-    the CU): bit-identical to the oracle's two linears and to the two-launch GEMM form, also with a ragged last 128-token tile."""
-    import ctypes
-    import gpu_utils as G
-    from oracle import oracle as orc
-    lib = _lib.load()
-    C, Hd = 256, 1024
-    x = synth.uniform(31, 'mx', (rows, C), -2.0, 2.0)
-    w1 = synth.uniform(31, 'mw1', (C, Hd), -0.08, 0.08)          # (in, out)
-    b1 = synth.uniform(31, 'mb1', (Hd,), -0.3, 0.3)
-    w2 = synth.uniform(31, 'mw2', (Hd, C), -0.05, 0.05)
-    b2 = synth.uniform(31, 'mb2', (C,), -0.3, 0.3)
-    r = synth.uniform(31, 'mr', (rows, C), -1.0, 1.0) if res else None
-    ref = orc.linear(orc.linear(x, w1, b1, act=_lib.ACT_GELU), w2, b2, res=r)
-    dev = cuda_device
-    xg = torch.from_numpy(x).to(dev)
-    # torch Linear weights are (out, in): pack them as set_weight does (femasr_repack_oihw with 1x1 taps -> the GEMM layout)
-    w1_oi = torch.from_numpy(np.ascontiguousarray(w1.T)).to(dev)
-    w2_oi = torch.from_numpy(np.ascontiguousarray(w2.T)).to(dev)
-    w1p = torch.empty(int(lib.femasr_packed_weight_floats(Hd, C, 1, 1)), device=dev)
-    w2p = torch.empty(int(lib.femasr_packed_weight_floats(C, Hd, 1, 1)), device=dev)
-    _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(w1_oi), Hd, C, 1, 1, _lib.ptr(w1p)))
-    _lib.check(lib.femasr_repack_oihw(None, _lib.ptr(w2_oi), C, Hd, 1, 1, _lib.ptr(w2p)))
-    b1g, b2g = torch.from_numpy(b1).to(dev), torch.from_numpy(b2).to(dev)
-    rg = torch.from_numpy(r).to(dev) if res else None
-    out = torch.full((rows + 3, C), 123.0, device=dev)          # canary rows behind the last one
-    _lib.check(lib.femasr_mlp_fused(None, _lib.ptr(xg), rows, C, Hd, _lib.ptr(w1p), _lib.ptr(b1g), _lib.ptr(w2p), _lib.ptr(b2g),
-                                    _lib.ptr(rg) if res else None, _lib.ptr(out)))
-    torch.cuda.synchronize()
-    got = out.cpu().numpy()
-    assert (got[rows:] == 123.0).all(), 'rows past M were written'
-    assert np.array_equal(got[:rows], ref), f'fused MLP vs oracle: max-abs {np.abs(got[:rows] - ref).max():.3e}'
-    # ... and the two-launch form it replaces
-    hid = G.conv2d(x.reshape(1, rows, 1, C), w1.reshape(1, 1, C, Hd), b1, 1, act=_lib.ACT_GELU)
-    two = G.conv2d(hid, w2.reshape(1, 1, Hd, C), b2, 1, res1=None if r is None else r.reshape(1, rows, 1, C))
-    assert np.array_equal(got[:rows], two.reshape(rows, C))
-
-
 @pytest.mark.parametrize('cin,cout,shape,nres', [(64, 128, (2, 9, 13), 0), (256, 128, (1, 12, 20), 1), (128, 64, (2, 16, 16), 0)])
 def test_conv_up2_winograd_second_input(cuda_device, cin, cout, shape, nres):
     """femasr_conv_args.in_add: the x2 Winograd-type conv reads in + in_add (the decoder's `x = x + enc_feats[i]`, femasr_arch.py:361-362,
@@ -262,66 +223,3 @@ def test_conv_up2_winograd_second_input(cuda_device, cin, cout, shape, nres):
         G.conv2d(x, wt, bias, 3, 1, 1, True, in_add=sk)              # phase-filter form
     with pytest.raises(FemasrError):
         G.conv2d(x, wt, bias, 3, 1, 1, False, wino=True, in_add=sk)   # F(4x4,3x3) form
-
-
-@pytest.fixture
-def wino_form():
-    """femasr_debug_wino_form(...) for the duration of a test; afterwards the environment decides again (default: the x64 form)."""
-    lib = _lib.load()
-
-    def set_(c128):
-        _lib.check(lib.femasr_debug_wino_form(1 if c128 else 0))
-    yield set_
-    _lib.check(lib.femasr_debug_wino_form(-1))
-
-
-@pytest.mark.parametrize('cin,cout,shape,gn,fast,nres', [
-    (32, 128, (1, 16, 16), False, False, 0),      # one full sub-block, two steps
-    (64, 128, (2, 21, 35), True, False, 1),       # ragged both ways, two images
-    (128, 256, (1, 40, 24), True, False, 2),      # two 128-channel column blocks, both residual operands
-    (256, 128, (3, 7, 50), False, False, 1),      # narrow image: sub-blocks cut at the bottom and the right
-    (128, 512, (1, 16, 33), True, True, 1),       # four column blocks, hardware-SiLU staging
-    (512, 256, (1, 72, 72), False, False, 0)])    # after_quant at the benchmarked size
-def test_conv_winograd_both_block_shapes(cuda_device, wino_form, cin, cout, shape, gn, fast, nres):
-    """The second block shape of the F(4x4,3x3) form - 16x16 pixels x 128 channels per block for layers with Cout % 128 == 0
-    (kernels_wino_c128.hip: v_mfma_f32_16x16x1_f32, 16-channel steps, its own weight layout; opt-in, FEMASR_WINO_C128=1) - against
-    the default 2 x 16x16 x 64 form of kernels_wino.hip: the same bits - outputs and the fused GroupNorm partial moments - and, with
-    the exact SiLU, the oracle's."""
-    import gpu_utils as G
-    from oracle import oracle as orc
-    b, h, w = shape
-    x = synth.uniform(43, 'cx', (b, h, w, cin), -2.0, 2.0)
-    wt = synth.uniform(43, 'cw', (3, 3, cin, cout), -0.1, 0.1)
-    bias = synth.uniform(43, 'cb', (cout,), -0.5, 0.5)
-    res = [synth.uniform(43, f'cr{k}', (b, h, w, cout), -1, 1) for k in range(nres)]
-    r1, r2 = (res + [None, None])[:2]
-    pro, xin = (None, None, None), x
-    if gn:
-        ga = synth.uniform(43, 'cga', (b, cin), 0.5, 1.5)
-        gb = synth.uniform(43, 'cgb', (b, cin), -0.5, 0.5)
-        pro, xin = (ga, gb, None), orc.scale_shift_silu(x, ga, gb)
-    kw = dict(prologue=_lib.PRO_GN_SILU if gn else 0, pro=pro, res1=r1, res2=r2, wino=True, gn_part=True, fast_act=fast)
-    wino_form(False)
-    y64, p64 = G.conv2d(x, wt, bias, 3, 1, 1, **kw)
-    wino_form(True)
-    y128, p128 = G.conv2d(x, wt, bias, 3, 1, 1, **kw)
-    assert np.array_equal(y128, y64), f'x128 vs x64 blocks: max-abs {np.abs(y128 - y64).max():.3e}'
-    assert np.array_equal(p128.cpu().numpy(), p64.cpu().numpy()), 'fused GroupNorm partial moments differ between the block shapes'
-    if not fast:
-        ref = orc.conv2d(xin, wt, bias, 3, 1, 1, res1=r1, res2=r2, wino=True)
-        assert np.array_equal(y128, ref), f'x128 blocks vs oracle: max-abs {np.abs(y128 - ref).max():.3e}'
-
-
-def test_wino_form_change_after_finalize_is_refused(cuda_device, wino_form):
-    """The two Winograd block shapes read different packed-weight layouts: a handle whose weights were packed under one setting must not
-    run under the other - the forward fails loudly instead of convolving with mis-laid weights."""
-    import gpu_utils as G
-    from femasr_amd._lib import FemasrError
-    net = G.build_net('x4', synth_weights('x4', 2, 'trained'), cuda_device)
-    x = torch.from_numpy(synth.synth_input(5, (1, 3, 32, 48))).to(cuda_device)
-    ref = net.test(x)
-    wino_form(True)
-    with pytest.raises(FemasrError, match='femasr_debug_wino_form'):
-        net.test(x)
-    wino_form(False)
-    assert torch.equal(net.test(x), ref)

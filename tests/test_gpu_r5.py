@@ -111,7 +111,7 @@ def test_linear_bf16s_refusals(cuda_device):
     with pytest.raises(_lib.FemasrError):          # in_add with w_bf16s (was silently ignored with w_bf16x3)
         G.conv2d(np.zeros((1, 8, 1, 64), np.float32), np.zeros((1, 1, 64, 8), np.float32), np.zeros(8, np.float32), 1, bf16s=True,
                  in_add=np.zeros((1, 8, 1, 64), np.float32))
-    assert _lib.load().femasr_version() == _lib.ABI_VERSION == 101
+    assert _lib.load().femasr_version() == _lib.ABI_VERSION
 
 
 @pytest.mark.parametrize('linear_math', ['bf16_split', 'fp32'])
@@ -280,67 +280,3 @@ def test_config5_hq_at_stated_batch_8(cuda_device):
     st = int(g['out_stride'])
     assert np.array_equal(il[0][5].cpu().numpy().reshape(-1), g['vq_indices'].reshape(-1))
     assert float(np.abs(out[5].cpu().numpy()[:, ::st, ::st] - g['output'][0]).max()) < 1e-3
-
-
-@pytest.mark.parametrize('cin,cout,h,w,nres', [(128, 128, 40, 56, 1), (64, 64, 33, 47, 0), (256, 128, 24, 24, 2), (512, 256, 16, 24, 1)])
-def test_winograd_m_phase_on_bf16_pipe(cuda_device, cin, cout, h, w, nres):
-    """femasr_conv_args.fast_act = 2: the F(4x4,3x3) conv with its M phase on the bf16 matrix pipe (V and U split exactly into three bf16
-    terms, six partial products) against fast_act = 1 (fp32 MFMA M phase, same hardware SiLU) and against the exact oracle form: the split
-    product is fp32-grade, so the two agree to fp32 rounding of a K = 9 Cin dot product - and the GroupNorm partial moments it emits with them."""
-    import gpu_utils as G
-    from oracle import oracle as orc
-    rng = np.random.default_rng(cin + h)
-    x = rng.standard_normal((2, h, w, cin)).astype(np.float32)
-    wt = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
-    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
-    ga, gb = orc.gn_coeffs(x, 1 + 0.1 * rng.standard_normal(cin).astype(np.float32), 0.1 * rng.standard_normal(cin).astype(np.float32))
-    r1 = rng.standard_normal((2, h, w, cout)).astype(np.float32) if nres >= 1 else None
-    r2 = rng.standard_normal((2, h, w, cout)).astype(np.float32) if nres >= 2 else None
-    kw = dict(prologue=_lib.PRO_GN_SILU, pro=(ga, gb, None), res1=r1, res2=r2, wino=True, gn_part=True)
-    y1, p1 = G.conv2d(x, wt, b, 3, 1, 1, fast_act=1, **kw)
-    y2, p2 = G.conv2d(x, wt, b, 3, 1, 1, fast_act=2, **kw)
-    act = orc.scale_shift_silu(x, ga, gb)
-    yo = orc.conv2d(act, wt, b, 3, 1, 1, res1=r1, res2=r2, wino=True)
-    # the definition in fp64 (what both Winograd evaluations approximate): conv of the activated input, + bias, + residuals
-    ref = torch.nn.functional.conv2d(torch.from_numpy(act.astype(np.float64)).permute(0, 3, 1, 2), torch.from_numpy(wt.astype(np.float64)).permute(3, 2, 0, 1),
-                                     torch.from_numpy(b.astype(np.float64)), padding=1).permute(0, 2, 3, 1).numpy()
-    for r in (r1, r2):
-        if r is not None:
-            ref = ref + r
-    scale = float(np.abs(yo).max())
-    d12, e2, e1 = float(np.abs(y2 - y1).max()), float(np.abs(y2 - ref).max()), float(np.abs(y1 - ref).max())
-    print(f'{cin}->{cout} {h}x{w}: |out|max {scale:.2f}; max error against the fp64 definition: bf16-pipe M phase {e2:.2e}, fp32 M phase {e1:.2e}; the two against each other {d12:.2e}')
-    assert not np.array_equal(y1, y2)                       # the other kernel really ran
-    assert e2 <= 1.5 * e1 + 1e-6, (e2, e1)                  # fp32-grade: no further from the definition than the fp32 Winograd form itself
-    assert np.allclose(p1.cpu().numpy(), p2.cpu().numpy(), rtol=1e-5, atol=1e-3)
-
-
-def test_network_with_winograd_m_phase_on_bf16_pipe(cuda_device):
-    """The default decoder math with femasr_debug_wino_mphase(1): VQ indices identical (these convs sit behind every lookup), image within
-    1e-4 of 'fp32_strict' (== the oracle) and within 1e-3 (measured ~1e-5) of the reference golden, for the small and the full-size x4 fixture."""
-    import gpu_utils as G
-    lib = _lib.load()
-    try:
-        for name in ('x4_small_trained', 'x4_tile128_trained'):
-            g = load_golden(name)
-            cn = cfg_name_of(g)
-            w = synth_weights(cn, int(g['seed']), str(g['codebook']))
-            x = torch.from_numpy(synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))).to(cuda_device)
-            _lib.check(lib.femasr_debug_wino_mphase(0))
-            net = G.build_net(cn, w, cuda_device, decoder_math='fp32')
-            y0, i0 = net.test_with_indices(x)
-            net.decoder_math = 'fp32_strict'
-            ys, _ = net.test_with_indices(x)
-            net.decoder_math = 'fp32'
-            _lib.check(lib.femasr_debug_wino_mphase(1))
-            y1, i1 = net.test_with_indices(x)
-            assert torch.equal(i0, i1) and not torch.equal(y0, y1)
-            st = int(g['out_stride']) if 'out_stride' in g else 1
-            e_ref = float(np.abs(y1.cpu().numpy()[:, :, ::st, ::st] - g['output']).max())
-            e_ref0 = float(np.abs(y0.cpu().numpy()[:, :, ::st, ::st] - g['output']).max())
-            e_str = float((y1 - ys).abs().max())
-            print(f'{name}: bf16-pipe M phase: max-abs vs reference {e_ref:.2e} (fp32 M phase: {e_ref0:.2e}), vs fp32_strict {e_str:.2e}')
-            assert e_ref < 1e-3 and e_str < 1e-4
-            del net
-    finally:
-        _lib.check(lib.femasr_debug_wino_mphase(-1))

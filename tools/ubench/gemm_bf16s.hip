@@ -71,35 +71,46 @@ int main(int argc, char **argv)
         femasr_conv_args a{};
         a.in = dA; a.bias = db; a.out = dout; a.res1 = sh.res ? dr : nullptr; a.B = 1; a.H = M; a.W = 1; a.Ho = M; a.Wo = 1; a.Cin = K; a.Cout = N;
         a.ksz = 1; a.stride = 1; a.pad = 0; a.act = sh.act ? FEMASR_ACT_GELU : FEMASR_ACT_NONE; a.prologue = FEMASR_PRO_NONE;
+        // round 6: the same layer with A handed over as packed planes (LDS-DMA A side), and - where the shape allows - planes out as well
+        void *dAp, *dOp = nullptr; float *dout2;
+        CK(hipMalloc(&dAp, femasr_packed_rows_bf16s_bytes(M, K))); CK(hipMalloc(&dout2, hr.size() * 4)); CK(hipMemset(dout2, 0xff, hr.size() * 4));
+        if (femasr_pack_rows_bf16s(0, dA, M, K, dAp)) return 1;
+        femasr_conv_args ap = a; ap.in = nullptr; ap.in_bf16s = dAp; ap.out = dout2;
+        const bool can_po = !sh.res && (N % 16) == 0;
+        femasr_conv_args apo = ap;
+        if (can_po) { CK(hipMalloc(&dOp, femasr_packed_rows_bf16s_bytes(M, N))); apo.out = nullptr; apo.out_bf16s = dOp; }
         int variant; double flops;
         if (femasr_gemm_bf16s_launch(0, &a, dWp, &variant, &flops)) return 1;
+        if (femasr_gemm_bf16s_launch(0, &ap, dWp, nullptr, nullptr)) return 1;
         CK(hipDeviceSynchronize());
-        { int nb = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_gsv[variant].kern, 256, GS_LDS_BYTES)); if (&sh == &shapes[0]) printf("resident blocks per CU: %d (GS_ABL=%d)\n", nb, GS_ABL); }
+        { int nb = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_gsv[variant].kern, 256, GS_LDS_BYTES)); if (&sh == &shapes[0]) printf("resident blocks per CU: %d\n", nb); }
         const int warm = getenv("GS_WARM") ? atoi(getenv("GS_WARM")) : 0;
-        for (int i = 0; i < warm; ++i) femasr_gemm_bf16s_launch(0, &a, dWp, nullptr, nullptr);
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        CK(hipEventRecord(e0));
-        for (int i = 0; i < reps; ++i) femasr_gemm_bf16s_launch(0, &a, dWp, nullptr, nullptr);
-        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        if (GS_TT) {
-            const int nblk = ((M + 127) / 128) * ((N + 127) / 128);
-            long long *dtt; CK(hipMalloc(&dtt, (size_t)nblk * 16 * 8)); CK(hipMemset(dtt, 0, (size_t)nblk * 16 * 8));
-            GemmSParams q{}; q.A = dA; q.W = (const uint4 *)dWp; q.bias = db; q.res1 = a.res1; q.out = dout; q.M = M; q.N = N; q.K = K; q.NT32 = (N + 31) / 32;
-            q.MB = (M + 127) / 128; q.NB = (N + 127) / 128; q.tt = dtt;
-            for (int i = 0; i < warm; ++i) femasr_gemm_bf16s_launch(0, &a, dWp, nullptr, nullptr);
-            hipLaunchKernelGGL(g_gsv[variant].kern, dim3(nblk), dim3(256), GS_LDS_BYTES, 0, q);
-            CK(hipDeviceSynchronize());
-            std::vector<long long> h((size_t)nblk * 16); CK(hipMemcpy(h.data(), dtt, h.size() * 8, hipMemcpyDeviceToHost));
-            double sum[8] = {0}; long long tmin = h[2], tmax = h[3];
-            for (int b = 0; b < nblk * 2; ++b) { if (h[(size_t)b * 8 + 2] < tmin) tmin = h[(size_t)b * 8 + 2]; if (h[(size_t)b * 8 + 3] > tmax) tmax = h[(size_t)b * 8 + 3]; }
-            printf("   kernel span %lld cycles (first prologue stamp .. last epilogue stamp)\n", tmax - tmin);
-            for (int b = 0; b < nblk * 2; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)h[(size_t)b * 8 + k];
-            printf("   block life (cycles, mean of waves 0 and 3): prologue %.0f | main loop %.0f = %.0f per 16-deep step (MFMA floor 768) | epilogue %.0f | total %.0f\n",
-                   sum[0] / (2 * nblk), sum[1] / (2 * nblk), sum[1] / (2 * nblk) / (K / 16), sum[6] / (2 * nblk), sum[7] / (2 * nblk));
-            hipFree(dtt);
+        auto time_of = [&](const femasr_conv_args &q) {
+            for (int i = 0; i < warm; ++i) femasr_gemm_bf16s_launch(0, &q, dWp, nullptr, nullptr);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < reps; ++i) femasr_gemm_bf16s_launch(0, &q, dWp, nullptr, nullptr);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1));
+            return t / reps;
+        };
+        const float ms = time_of(a), ms_p = time_of(ap), ms_po = can_po ? time_of(apo) : 0.f;
+        {   // the planes form against the fp32-row form: every output, bit for bit
+            std::vector<float> h1(hr.size()), h2(hr.size());
+            CK(hipMemcpy(h1.data(), dout, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), dout2, h2.size() * 4, hipMemcpyDeviceToHost));
+            size_t nd = 0; for (size_t i = 0; i < h1.size(); ++i) nd += f2u(h1[i]) != f2u(h2[i]);
+            size_t nd2 = 0;
+            if (can_po) {
+                CK(hipMemset(dout2, 0xff, hr.size() * 4));
+                if (femasr_unpack_rows_bf16s(0, dOp, M, N, dout2)) return 1;
+                CK(hipMemcpy(h2.data(), dout2, h2.size() * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < h1.size(); ++i) nd2 += f2u(h1[i]) != f2u(h2[i]);
+            }
+            printf("%-22s M=%6d  fp32 rows %8.1f us (%6.1f TF) | planes in %8.1f us (%6.1f TF) | planes in+out %8.1f us | differing outputs: %zu, %zu\n", sh.name, M,
+                   ms * 1e3, flops / ms * 1e-9, ms_p * 1e3, flops / ms_p * 1e-9, ms_po * 1e3, nd, nd2);
         }
-        if (GS_ABL || GS_TT || getenv("GS_NOVERIFY")) { printf("%-22s M=%6d  %8.1f us  %7.1f TF(fp32-equivalent)\n", sh.name, M, ms * 1e3, flops / ms * 1e-9); hipFree(dA); hipFree(dW); hipFree(db); hipFree(dr); hipFree(dout); hipFree(dWp); continue; }
+        hipFree(dAp); hipFree(dout2); if (dOp) hipFree(dOp);
+        if (getenv("GS_NOVERIFY")) { hipFree(dA); hipFree(dW); hipFree(db); hipFree(dr); hipFree(dout); hipFree(dWp); continue; }
         std::vector<float> hout(hr.size());
         CK(hipMemcpy(hout.data(), dout, hout.size() * 4, hipMemcpyDeviceToHost));
         // verification on sampled rows (all columns of 24 rows incl. the last ones)
