@@ -123,8 +123,8 @@ VMEM_PREFIXES = ('global_', 'buffer_', 'scratch_', 'flat_', 'tbuffer_')
 # (the six copies of the next step stay in flight).  AIN = 0 (fp32 rows): two chunks = four steps = twelve W copies + two 4-load row fetches,
 # waits 14 / 10 / 10 per chunk.  The numbers are the source's (`s_waitcnt vmcnt(N)` in the inline asm); check_counted_waits() also reads them there.
 COUNTED = {
-    1: {'global_load_lds_dwordx4': 6, 'vmcnt': {6: 1}},
-    0: {'global_load_lds_dwordx4': 12, 'global_load_dwordx4': 8, 'vmcnt': {14: 2, 10: 4}},
+    1: {'loops': 1, 'global_load_lds_dwordx4': 6, 'vmcnt': {6: 1}},
+    0: {'loops': 1, 'global_load_lds_dwordx4': 12, 'global_load_dwordx4': 8, 'vmcnt': {14: 2, 10: 4}},
 }
 
 
@@ -191,24 +191,25 @@ def check_counted_waits(obj=None):
         seen += 1
         want = COUNTED[int(m.group(1))]
         loops = mfma_loops(insts)
-        if len(loops) != 1:
-            problems.append(f'{demangle_short(name)}: expected one MFMA loop, found {len(loops)}')
+        if len(loops) != want['loops']:
+            problems.append(f'{demangle_short(name)}: expected {want["loops"]} MFMA loop(s), found {len(loops)}')
             continue
-        body = insts[loops[0][0]:loops[0][1] + 1]
-        vmem, waits = {}, {}
-        for _, op, args in body:
-            if op.startswith(VMEM_PREFIXES):
-                vmem[op] = vmem.get(op, 0) + 1
-            if op == 's_waitcnt':
-                for n in re.findall(r'vmcnt\((\d+)\)', args):
-                    waits[int(n)] = waits.get(int(n), 0) + 1
-        want_vmem = {k: v for k, v in want.items() if k != 'vmcnt'}
-        if vmem != want_vmem:
-            problems.append(f'{demangle_short(name)}: VMEM instructions in the MFMA loop {vmem}, the counted waits assume exactly {want_vmem}')
-        if waits != want['vmcnt']:
-            problems.append(f'{demangle_short(name)}: vmcnt waits in the MFMA loop {waits}, the source has {want["vmcnt"]}')
-        if not any(op == 's_barrier' for _, op, _ in body):
-            problems.append(f'{demangle_short(name)}: no s_barrier in the MFMA loop')
+        for lo, hi in loops:
+            body = insts[lo:hi + 1]
+            vmem, waits = {}, {}
+            for _, op, args in body:
+                if op.startswith(VMEM_PREFIXES):
+                    vmem[op] = vmem.get(op, 0) + 1
+                if op == 's_waitcnt':
+                    for n in re.findall(r'vmcnt\((\d+)\)', args):
+                        waits[int(n)] = waits.get(int(n), 0) + 1
+            want_vmem = {k: v for k, v in want.items() if k not in ('vmcnt', 'loops')}
+            if vmem != want_vmem:
+                problems.append(f'{demangle_short(name)}: VMEM instructions in the MFMA loop {vmem}, the counted waits assume exactly {want_vmem}')
+            if waits != want['vmcnt']:
+                problems.append(f'{demangle_short(name)}: vmcnt waits in the MFMA loop {waits}, the source has {want["vmcnt"]}')
+            if not any(op == 's_barrier' for _, op, _ in body):
+                problems.append(f'{demangle_short(name)}: no s_barrier in the MFMA loop')
     if seen < 14:
         problems.append(f'only {seen} gemm_bf16s_kernel instantiations found in {obj}')
     return problems

@@ -189,6 +189,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
         issue(0, 0);
         issue(1, 1);
         int st = 0, st2 = 2;                               // stage of step s, of step s + 2 (uniform)
+        // (Round 6 measured what does NOT bound this loop, profiles/r06_gemm_experiments.txt: the copies ahead of or behind the MFMAs, in a
+        // different order in the CU's two resident blocks (slot parity from HW_REG_LDS_ALLOC), the second block of a CU started 8k - 40k cycles
+        // late - every variant within +-1.5 % of this one; constant instead of random operands: 15 % FASTER.  The launch runs at the package
+        // power limit: its time is joules per output, not schedule.)
 #pragma unroll 1
         for (int s = 0; s < nsteps; ++s) {
             // the six copies of step s have landed (the six of step s + 1 may be in flight); every wave has read step s - 1's stage

@@ -42,7 +42,7 @@ def test_pack_rows_bf16s_is_the_oracles_split(cuda_device, rows, c):
     x[0, :4] = [0.0, -0.0, 1e-30, -3e38]          # zeros, a tiny value, near the top of the range
     xg = torch.from_numpy(x).to(cuda_device)
     buf = _planes_of(xg)
-    assert np.array_equal(_unpack(buf, rows, c).view(np.uint32), x.view(np.uint32))
+    assert np.array_equal(_unpack(buf, rows, c), x)          # (as VALUES: -0 = (-0) + 0 + 0 comes back as +0; the planes themselves are compared below)
     p = orc.split3(x)
     mb, ns = (rows + 127) // 128, c // 16
     got = buf.cpu().numpy().view(np.uint16).reshape(mb, ns, 3, 2, 128, 8)
@@ -90,7 +90,7 @@ def test_linear_bf16s_planes_out_bit_exact(cuda_device, name, rows, cin, cout, a
     yo = orc.linear_bf16s(x, w, b, act)
     y = G.conv2d(x.reshape(1, rows, 1, cin), np.ascontiguousarray(w.T).reshape(1, 1, cin, cout), b, 1, act=act, bf16s=True, planes_in=True,
                  planes_out=True).reshape(rows, cout)
-    assert np.array_equal(y.view(np.uint32), yo.view(np.uint32)), f'{name}: {(y != yo).sum()} of {y.size} differ'
+    assert np.array_equal(y, yo), f'{name}: {(y != yo).sum()} of {y.size} differ'          # (values: a -0 output unpacks as +0)
 
 
 def test_linear_bf16s_planes_refusals(cuda_device):
@@ -122,7 +122,7 @@ def test_layernorm_bf16s_bit_exact(cuda_device, rows):
     buf = torch.full((int(lib.femasr_packed_rows_bf16s_bytes(rows, 256)),), 0xff, dtype=torch.uint8, device=cuda_device)
     _lib.check(lib.femasr_layernorm_bf16s(None, _lib.ptr(tx), rows, 256, _lib.ptr(tg), _lib.ptr(tb), ctypes.c_float(1e-5), _lib.ptr(buf)))
     got = _unpack(buf, rows, 256)
-    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f'{(got != ref).sum()} of {ref.size} differ'
+    assert np.array_equal(got, ref), f'{(got != ref).sum()} of {ref.size} differ'
     # the planes themselves are the pack of the fp32 result (same record layout)
     want = _planes_of(torch.from_numpy(ref).to(cuda_device)).cpu().numpy().view(np.uint16).reshape(-1, 16, 3, 2, 128, 8)
     have = buf.cpu().numpy().view(np.uint16).reshape(-1, 16, 3, 2, 128, 8)
@@ -174,5 +174,5 @@ def test_swin_mlp_chain_through_planes(cuda_device):
     lin(pn, C, Hd, p1, tb1, act=_lib.ACT_GELU, out_planes=ph)
     lin(ph, Hd, C, p2, tb2, res=tx, out_rows=out)
     torch.cuda.synchronize()
-    assert np.array_equal(_unpack(ph, rows, Hd).view(np.uint32), hdn.view(np.uint32))
+    assert np.array_equal(_unpack(ph, rows, Hd), hdn)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), yo.view(np.uint32))

@@ -56,6 +56,7 @@ int main(int argc, char **argv)
         const int M = sh.M, N = sh.N, K = sh.K;
         std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N), hr((size_t)M * N);
         for (auto &v : hA) v = nd(rng);
+        if (getenv("GS_ZERO")) { const float z = (float)atof(getenv("GS_ZERO")); for (auto &v : hA) v = z; }      // data-dependent power: constant operands
         const float ws = 1.f / sqrtf((float)K);
         for (auto &v : hW) v = nd(rng) * ws;
         for (auto &v : hb) v = nd(rng) * 0.1f;
