@@ -92,6 +92,8 @@ SIGNATURES = {
     'femasr_codebook_gather': (c_int, [vp, vp, c_i64, c_int, vp, c_int, vp]),
     'femasr_extract_tiles': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, vp]),
     'femasr_paste_tiles': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, vp]),
+    'femasr_extract_tiles_u8': (c_int, [vp, vp, c_int, c_int, c_int, vp, c_int, c_int, c_int, vp]),
+    'femasr_paste_tiles_u8': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, vp]),
     'femasr_concat_resize': (c_int, [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'femasr_repack_oihw': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'femasr_packed_weight_floats': (szt, [c_int, c_int, c_int, c_int]),

@@ -386,11 +386,12 @@ class FeMaSRNet(nn.Module):
         return out, idx
 
     @torch.no_grad()
-    def test_u8(self, img_u8, bgr=False):
+    def test_u8(self, img_u8, bgr=False, out=None):
         """The CLI arithmetic of inference_femasr.py:50-67 on the device in ONE native call: uint8 (H,W,3) or (B,H,W,3) image(s) ->
         uint8 (sH,sW,3) / (B,sH,sW,3); decode (`/255.`) is fused into the forward's mirror-pad kernel and tensor2img (clamp, x255,
         round half to even) into its crop kernel (femasr_forward_u8) - the same bits as imgproc.u8_to_input -> test() ->
-        imgproc.output_to_u8, without the two fp32 NCHW images in between."""
+        imgproc.output_to_u8, without the two fp32 NCHW images in between.  `out`: a contiguous uint8 (B,sH,sW,3) tensor the crop
+        kernel stores into (the tiled / multi-GPU callers pass slices of their result or all-gather send buffers)."""
         if img_u8.device.type != 'cuda':
             raise _lib.FemasrError('test_u8: tensor must be on the GPU (no CPU fallback)')
         single = img_u8.dim() == 3
@@ -406,7 +407,10 @@ class FeMaSRNet(nn.Module):
         nbytes = ctypes.c_size_t()
         _lib.check(lib.femasr_workspace_bytes(h, b, hh, ww, 1, ctypes.byref(nbytes)))
         ws = self._workspace(nbytes.value, x.device)
-        out = torch.empty((b, oh.value, ow.value, 3), dtype=torch.uint8, device=x.device)
+        if out is None:
+            out = torch.empty((b, oh.value, ow.value, 3), dtype=torch.uint8, device=x.device)
+        elif (out.dtype != torch.uint8 or tuple(out.shape) != (b, oh.value, ow.value, 3) or not out.is_contiguous() or out.device != x.device):
+            raise ValueError(f'test_u8(out=...): expected a contiguous uint8 {(b, oh.value, ow.value, 3)} tensor on {x.device}')
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(lib.femasr_forward_u8(h, ctypes.c_void_p(stream), _lib.ptr(x), b, hh, ww, int(bool(bgr)), 1, _lib.ptr(out), None,
                                          _lib.ptr(ws), ws.numel()))
@@ -477,7 +481,8 @@ class FeMaSRNet(nn.Module):
         s = self.scale_factor
         tiles = tiling.enumerate_tiles(height, width, tile_size, tile_pad)
         classes = tiling.shape_classes(tiles)
-        mine = tiling.partition(classes, rank, world_size, s)
+        owned_all = tiling.assign(classes, world_size, s)          # (once per call: every rank's share - the paste below indexes it)
+        mine = owned_all[rank]
         # `time_split = True`: record where the call's time goes (events on the current stream; read back in `last_split_ms`
         # = {'compute', 'gather', 'paste', 'tiles_owned'} after a synchronize) - bench.py --workload tile2048 reports it per rank
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (getattr(self, 'time_split', False) and input.is_cuda) else None
@@ -518,14 +523,107 @@ class FeMaSRNet(nn.Module):
             return None
         output = input.new_zeros((batch, channel, height * s, width * s))
         for r, res in enumerate(per_rank):
-            owned = tiling.partition(classes, r, world_size, s)
-            for hw, tl in owned.items():
+            for hw, tl in owned_all[r].items():
                 if tl:
                     self._paste_tiles(output, res[hw], tl, batch, s)
         if ev:
             ev[3].record()
             self._split_events = (ev, sum(len(tl) for tl in mine.values()))
         return output
+
+    @torch.no_grad()
+    def test_tile_u8(self, img_u8, tile_size=240, tile_pad=16, rank=0, world_size=1, gather=None, paste=True, bgr=False):
+        """`test_tile` on uint8 images end to end (round 6; the CLI's tiled branch, inference_femasr.py:58-67 with femasr_arch.py:387-447):
+        uint8 (H,W,3) / (B,H,W,3) in -> uint8 (sH,sW,3) / (B,sH,sW,3) out.  Tiles are cropped as uint8, every batched call is ONE
+        `test_u8` (decode fused into the mirror-pad kernel, tensor2img into the crop kernel, which stores straight into the result /
+        all-gather send buffer), the all-gather and the paste move one byte per value (a quarter of the fp32 path's xGMI and canvas
+        traffic; no 805-MB fp32 canvas at 8192^2).  Bit-identical to output_to_u8(test_tile(u8_to_input(img))): tensor2img is
+        element-wise and every output pixel comes from exactly one tile."""
+        single = img_u8.dim() == 3
+        x = img_u8.unsqueeze(0) if single else img_u8
+        if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[3] != 3:
+            raise ValueError(f'expected uint8 (H,W,3) or (B,H,W,3), got {img_u8.dtype} {tuple(img_u8.shape)}')
+        x = x.contiguous()
+        batch, height, width, channel = x.shape
+        s = self.scale_factor
+        tiles = tiling.enumerate_tiles(height, width, tile_size, tile_pad)
+        classes = tiling.shape_classes(tiles)
+        owned_all = tiling.assign(classes, world_size, s)          # (once: every rank's share, for the paste below)
+        mine = owned_all[rank]
+        alloc = getattr(gather, 'send_views', None) if world_size > 1 else None
+        if alloc is not None:
+            results = alloc(classes, batch, channel, s, torch.uint8, x.device, layout='nhwc')
+        else:
+            results = {hw: torch.empty((len(tl) * batch, hw[0] * s, hw[1] * s, channel), dtype=torch.uint8, device=x.device)
+                       for hw, tl in mine.items()}
+        per_call = max(1, self.max_tile_batch // batch)
+        in_place = 'out' in self._signature_of(self.test_u8)
+        for hw, tl in mine.items():
+            for i in range(0, len(tl), per_call):
+                chunk = tl[i:i + per_call]
+                dst = results[hw][i * batch:(i + len(chunk)) * batch]
+                crops = self._extract_tiles_u8(x, chunk, hw)
+                y = self.test_u8(crops, bgr=bgr, out=dst) if in_place else self.test_u8(crops, bgr=bgr)
+                if y.data_ptr() != dst.data_ptr():
+                    dst.copy_(y)
+        if world_size > 1:
+            if gather is None:
+                raise ValueError('world_size > 1 needs a gather callable')
+            per_rank = gather(results, classes, batch, channel, s, layout='nhwc')
+        else:
+            per_rank = [results]
+        if not paste:
+            return None
+        output = x.new_zeros((batch, height * s, width * s, channel))
+        for r, res in enumerate(per_rank):
+            for hw, tl in owned_all[r].items():
+                if tl:
+                    self._paste_tiles_u8(output, res[hw], tl, batch, s)
+        return output[0] if single else output
+
+    @staticmethod
+    def _signature_of(fn):
+        import inspect
+        try:
+            return inspect.signature(fn).parameters
+        except (TypeError, ValueError):
+            return {}
+
+    @staticmethod
+    def _extract_tiles_u8(x, chunk, hw):
+        """uint8 crops `img[:, y0p:y1p, x0p:x1p, :]` of one shape class as one (n*B, th, tw, 3) batch (tile-major): one native launch
+        (host tensors: slicing, for the CPU-side tests of the partition / gather logic)."""
+        if not x.is_cuda:
+            return torch.cat([x[:, t.y0p:t.y1p, t.x0p:t.x1p, :] for t in chunk], 0).contiguous()
+        lib = _lib.load()
+        b, h, w, _ = x.shape
+        yx = torch.tensor([v for t in chunk for v in (t.y0p, t.x0p)], dtype=torch.int32).to(x.device, non_blocking=True)
+        out = torch.empty((len(chunk) * b, hw[0], hw[1], 3), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.femasr_extract_tiles_u8(torch.cuda.current_stream().cuda_stream, x.data_ptr(), b, h, w, yx.data_ptr(),
+                                                   len(chunk), hw[0], hw[1], out.data_ptr()))
+        return out
+
+    @staticmethod
+    def _paste_tiles_u8(output, block, tl, batch, s):
+        if not output.is_cuda:
+            for k, t in enumerate(tl):
+                ys, ye, xs, xe = t.out_src(s)
+                dy0, dy1, dx0, dx1 = t.out_dst(s)
+                output[:, dy0:dy1, dx0:dx1, :] = block[k * batch:(k + 1) * batch, ys:ye, xs:xe, :]
+            return
+        lib = _lib.load()
+        block = block.contiguous()
+        rects, hmax = [], 0
+        for t in tl:
+            ys, ye, xs, xe = t.out_src(s)
+            dy0, _, dx0, _ = t.out_dst(s)
+            rects += [ys, xs, dy0, dx0, ye - ys, xe - xs]
+            hmax = max(hmax, ye - ys)
+        rd = torch.tensor(rects, dtype=torch.int32).to(output.device, non_blocking=True)
+        with torch.cuda.device(output.device):
+            _lib.check(lib.femasr_paste_tiles_u8(torch.cuda.current_stream().cuda_stream, block.data_ptr(), batch, len(tl), block.shape[1],
+                                                 block.shape[2], rd.data_ptr(), hmax, output.shape[1], output.shape[2], output.data_ptr()))
 
     def _test_takes_out(self):
         """False when `test` was replaced by a stand-in without the `out=` parameter (CPU-side tests of the host logic)."""

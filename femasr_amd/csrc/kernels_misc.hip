@@ -756,6 +756,36 @@ __global__ void paste_tiles_kernel(const float *__restrict__ tiles, int B, int C
     for (int x = threadIdx.x; x < rc[5]; x += blockDim.x) dst[x] = src[x];
 }
 
+// The same two steps on uint8 HWC images (round 6: the tiled / multi-GPU path moves one byte per value): crops of a (B,H,W,3) image -> (n*B, th, tw, 3);
+// tile bodies -> the (B,Ho,Wo,3) canvas.  Thread = one pixel row segment byte; rows are 3 * w contiguous bytes.
+__global__ void extract_tiles_u8_kernel(const unsigned char *__restrict__ in, int B, int H, int W, const int *__restrict__ yx, int n,
+                                        int th, int tw, unsigned char *__restrict__ out, size_t total)
+{
+    const int rowb = 3 * tw;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xb = (int)(i % rowb);
+        size_t r = i / rowb;
+        const int y = (int)(r % th);
+        r /= th;
+        const int b = (int)(r % B), k = (int)(r / B);
+        out[i] = in[(((size_t)b * H + yx[2 * k] + y) * W + yx[2 * k + 1]) * 3 + xb];
+    }
+}
+
+__global__ void paste_tiles_u8_kernel(const unsigned char *__restrict__ tiles, int B, int th, int tw, const int *__restrict__ rects,
+                                      int n, int Ho, int Wo, unsigned char *__restrict__ out, int hmax)
+{
+    size_t r = blockIdx.x;
+    const int y = (int)(r % hmax);
+    r /= hmax;
+    const int b = (int)(r % B), k = (int)(r / B);
+    const int *rc = rects + 6 * k;
+    if (y >= rc[4]) return;
+    const unsigned char *src = tiles + ((((size_t)k * B + b) * th + rc[0] + y) * tw + rc[1]) * 3;
+    unsigned char *dst = out + (((size_t)b * Ho + rc[2] + y) * Wo + rc[3]) * 3;
+    for (int x = threadIdx.x; x < 3 * rc[5]; x += blockDim.x) dst[x] = src[x];
+}
+
 // out[n,y,x,:] = cat(a[n,y,x,:Ca], b[n, y*Hb/H, x*Wb/W, :Cb]); one thread per float4 of the output (Ca, Cb % 4 == 0)
 __global__ void concat_resize_kernel(const float *__restrict__ a, int Ca, const float *__restrict__ b, int Hb, int Wb, int Cb,
                                      int H, int W, float *__restrict__ out, size_t total4)
@@ -1008,6 +1038,25 @@ int femasr_paste_tiles(void *stream, const float *tiles, int B, int C, int n, in
     const size_t rows = (size_t)n * B * C * hmax;
     FEMASR_REQUIRE(rows < ((size_t)1 << 31), "paste_tiles: too many rows");
     hipLaunchKernelGGL(paste_tiles_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, tiles, B, C, th, tw, rects_dev, n, Ho, Wo, out, hmax);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_extract_tiles_u8(void *stream, const uint8_t *in, int B, int H, int W, const int32_t *yx_dev, int n, int th, int tw, uint8_t *out)
+{
+    FEMASR_REQUIRE(in && yx_dev && out && B > 0 && n > 0 && th > 0 && tw > 0 && th <= H && tw <= W, "extract_tiles_u8: bad args");
+    const size_t total = (size_t)n * B * th * tw * 3;
+    hipLaunchKernelGGL(extract_tiles_u8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, B, H, W, yx_dev, n, th, tw, out, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_paste_tiles_u8(void *stream, const uint8_t *tiles, int B, int n, int th, int tw, const int32_t *rects_dev, int hmax, int Ho, int Wo, uint8_t *out)
+{
+    FEMASR_REQUIRE(tiles && rects_dev && out && B > 0 && n > 0 && th > 0 && tw > 0 && hmax > 0 && hmax <= th, "paste_tiles_u8: bad args");
+    const size_t rows = (size_t)n * B * hmax;
+    FEMASR_REQUIRE(rows < ((size_t)1 << 31), "paste_tiles_u8: too many rows");
+    hipLaunchKernelGGL(paste_tiles_u8_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, tiles, B, th, tw, rects_dev, n, Ho, Wo, out, hmax);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

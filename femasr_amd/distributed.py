@@ -55,8 +55,9 @@ class TileGather:
     Sizes follow from the deterministic partition (tiling.partition), so no size exchange is needed; every
     rank's slab is `cap` = the largest rank payload (ranks with fewer tiles leave their tail unused)."""
 
-    def __init__(self, classes, batch, channel, scale, dtype, device, group=None):
+    def __init__(self, classes, batch, channel, scale, dtype, device, group=None, layout='nchw'):
         self.group = group
+        self.layout = layout            # 'nchw': fp32 tiles (n, C, H, W) of test_tile; 'nhwc': uint8 tiles (n, H, W, C) of test_tile_u8
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.classes, self.batch, self.channel, self.scale = classes, batch, channel, scale
@@ -70,7 +71,9 @@ class TileGather:
         d, off = {}, 0
         for hw, tl in self.owned[r].items():
             n = _class_numel(hw, len(tl), self.batch, self.channel, self.scale)
-            d[hw] = flat[off:off + n].view(len(tl) * self.batch, self.channel, hw[0] * self.scale, hw[1] * self.scale)
+            shp = (len(tl) * self.batch, self.channel, hw[0] * self.scale, hw[1] * self.scale) if self.layout == 'nchw' else \
+                  (len(tl) * self.batch, hw[0] * self.scale, hw[1] * self.scale, self.channel)
+            d[hw] = flat[off:off + n].view(shp)
             off += n
         return d
 
@@ -127,23 +130,23 @@ class TileExchange:
         self._key = None
         self._tg = None
 
-    def _get(self, classes, batch, channel, scale, dtype, device):
+    def _get(self, classes, batch, channel, scale, dtype, device, layout='nchw'):
         # (world size and rank are part of the key: after destroy_process_group + a new init in the same process - or a freed group's
         # id() coming back - a TileGather built for another world would hand stale sizes to the collective)
         key = (tuple((hw, tuple(t.index for t in tl)) for hw, tl in classes.items()), batch, channel, scale, dtype, str(device),
-               dist.get_world_size(self.group), dist.get_rank(self.group))
+               dist.get_world_size(self.group), dist.get_rank(self.group), layout)
         if key != self._key:
             self._tg = None                 # one geometry at a time keeps the footprint bounded
-            self._tg = TileGather(classes, batch, channel, scale, dtype, device, self.group)
+            self._tg = TileGather(classes, batch, channel, scale, dtype, device, self.group, layout)
             self._key = key
         return self._tg
 
-    def send_views(self, classes, batch, channel, scale, dtype, device):
-        return self._get(classes, batch, channel, scale, dtype, torch.device(device)).send_views()
+    def send_views(self, classes, batch, channel, scale, dtype, device, layout='nchw'):
+        return self._get(classes, batch, channel, scale, dtype, torch.device(device), layout).send_views()
 
-    def __call__(self, results, classes, batch, channel, scale):
+    def __call__(self, results, classes, batch, channel, scale, layout='nchw'):
         ref = next(iter(results.values()))
-        tg = self._get(classes, batch, channel, scale, ref.dtype, ref.device)
+        tg = self._get(classes, batch, channel, scale, ref.dtype, ref.device, layout)
         for hw, dst in tg.send_views().items():
             src = results[hw]
             if src.data_ptr() != dst.data_ptr() or src.numel() != dst.numel():
@@ -161,25 +164,30 @@ def _exchange_for(group):
     sig = (id(group), dist.get_world_size(group), dist.get_rank(group))
     for k in [k for k in _exchanges if k[0] == sig[0] and k != sig]:
         del _exchanges[k]
-    return _exchanges.setdefault(sig, TileExchange(group))
+    if sig not in _exchanges:               # (not setdefault(sig, TileExchange(group)): its argument is built on every call)
+        _exchanges[sig] = TileExchange(group)
+    return _exchanges[sig]
 
 
-def gather_tiles(results, classes, batch, channel, scale, group=None):
+def gather_tiles(results, classes, batch, channel, scale, group=None, layout='nchw'):
     """All-gather every rank's upscaled tiles with ONE `all_gather_into_tensor` on persistent buffers (functional form of
     TileExchange; the tiles are copied into the send slab unless they already live there).
 
     results: {(h,w): tensor (n_owned*batch, channel, h*s, w*s)} of THIS rank.
     Returns a list (one entry per rank) of dicts with the same structure (views into the receive buffer,
     valid until the next call with the same geometry)."""
-    return _exchange_for(group)(results, classes, batch, channel, scale)
+    return _exchange_for(group)(results, classes, batch, channel, scale, layout)
 
 
 def test_tile_parallel(net, x, tile_size=240, tile_pad=16, group=None, root_only=False):
     """`net.test_tile` sharded over the process group.  Every rank returns the full upscaled image, or - root_only=True - only
-    rank 0 pastes it (the others return None): one canvas write per job instead of one per rank."""
+    rank 0 pastes it (the others return None): one canvas write per job instead of one per rank.
+    A uint8 image ((H,W,3) / (B,H,W,3), the CLI's data type) takes the uint8 path (`net.test_tile_u8`): tiles are produced, gathered
+    and pasted as bytes - a quarter of the fp32 path's xGMI payload and canvas traffic."""
+    fn = net.test_tile_u8 if x.dtype == torch.uint8 else net.test_tile
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return net.test_tile(x, tile_size, tile_pad)
+        return fn(x, tile_size, tile_pad)
     ex = _exchange_for(group)
     rank = dist.get_rank(group)
-    return net.test_tile(x, tile_size, tile_pad, rank=rank, world_size=dist.get_world_size(group), gather=ex,
-                         paste=(rank == 0 or not root_only))
+    return fn(x, tile_size, tile_pad, rank=rank, world_size=dist.get_world_size(group), gather=ex,
+              paste=(rank == 0 or not root_only))

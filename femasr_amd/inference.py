@@ -79,12 +79,12 @@ def main(argv=None):
             # whole image: ONE native call, uint8 in -> uint8 out (decode fused into the pad kernel, tensor2img into the crop kernel)
             u8 = model.test_u8(xu8) if rank == 0 else None
         else:
-            x = imgproc.u8_to_input(xu8)
+            # tiled: uint8 tiles in, uint8 tiles out - crops, the all-gather over xGMI and the paste move one byte per value, no fp32 image
+            # or canvas is ever held (FeMaSRNet.test_tile_u8); with several ranks only rank 0 pastes
             if world > 1:
-                out = fd.test_tile_parallel(model, x, args.tile_size, args.tile_pad)
+                u8 = fd.test_tile_parallel(model, xu8, args.tile_size, args.tile_pad, root_only=True)
             else:
-                out = model.test_tile(x, args.tile_size, args.tile_pad)
-            u8 = imgproc.output_to_u8(out) if rank == 0 else None
+                u8 = model.test_tile_u8(xu8, args.tile_size, args.tile_pad)
         if rank == 0:
             Image.fromarray(u8.cpu().numpy(), 'RGB').save(os.path.join(args.output, img_name))
     if world > 1:

@@ -265,6 +265,12 @@ int femasr_extract_tiles(void *stream, const float *in, int B, int C, int H, int
                          float *out);
 int femasr_paste_tiles(void *stream, const float *tiles, int B, int C, int n, int th, int tw, const int32_t *rects_dev, int hmax,
                        int Ho, int Wo, float *out);
+/* The same on uint8 HWC images (3 channels): crops of a (B,H,W,3) image -> (n*B, th, tw, 3), ready for femasr_forward_u8; tile bodies of
+ * (n*B, th, tw, 3) -> the (B,Ho,Wo,3) canvas.  FeMaSRNet.test_tile_u8 and the all-gather of the multi-GPU path move these bytes - a
+ * quarter of the fp32 tiles' - and the CLI's tiled branch (inference_femasr.py:58-67) never holds an fp32 image. */
+int femasr_extract_tiles_u8(void *stream, const uint8_t *in, int B, int H, int W, const int32_t *yx_dev, int n, int th, int tw, uint8_t *out);
+int femasr_paste_tiles_u8(void *stream, const uint8_t *tiles, int B, int n, int th, int tw, const int32_t *rects_dev, int hmax,
+                          int Ho, int Wo, uint8_t *out);
 
 /* OIHW -> the packed FRAGMENT-MAJOR weight layout of femasr_conv_args.w (also nn.Linear (out,in) with kh=kw=1
  * and the codebook for femasr_vq):  out[q][ntile][lane][kk], zero padded, with

@@ -38,11 +38,17 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 def lib():
     global _lib
     if _lib is None:
-        # libgomp reads OMP_NUM_THREADS when it is loaded: one thread per PHYSICAL core unless the caller chose (on SMT hosts
-        # - this dev container, the GPU box - the default of one thread per logical CPU runs the integer-heavy loops slower)
-        os.environ.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 2) // 2)))
         build()
         L = ctypes.CDLL(_SO)
+        # one thread per PHYSICAL core unless the caller chose (on SMT hosts - this dev container, the GPU box - the default of one
+        # thread per logical CPU runs the integer-heavy loops slower).  Set through the OpenMP runtime the oracle's .so is linked
+        # against, NOT through os.environ: the environment variable would also change torch's CPU thread pool if torch initialises
+        # afterwards.
+        if 'OMP_NUM_THREADS' not in os.environ:
+            try:
+                ctypes.CDLL('libgomp.so.1').omp_set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+            except OSError:
+                pass
         i, i64, f, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
         L.orc_math_eval.argtypes = [i, vp, vp, i64]
         L.orc_pad_nchw_to_nhwc.argtypes = [vp, i, i, i, i, i, i, vp]

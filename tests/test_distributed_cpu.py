@@ -22,9 +22,23 @@ def _fake_test(self, t):
     return up * 0.5 + t.amax(dim=(1, 2, 3), keepdim=True) + 0.001 * t.shape[2] + 0.01 * t.shape[3]
 
 
+def _to_f32(u8):          # imgproc.u8_to_input on the host: (B,H,W,3) uint8 -> (B,3,H,W) float in [0,1]
+    return u8.permute(0, 3, 1, 2).float() / 255.0
+
+
+def _to_u8(y):            # imgproc.output_to_u8 (tensor2img): clamp, x255, round half to even -> (B,H,W,3) uint8
+    return (y.clamp(0, 1) * 255.0).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+def _fake_test_u8(self, t, bgr=False):
+    # stand-in of FeMaSRNet.test_u8 (no `out=`: test_tile_u8 copies): the fp32 stand-in between the CLI's decode and tensor2img
+    return _to_u8(_fake_test(self, _to_f32(t)) * 0.25)
+
+
 def _make_net():
     net = build_network(dict(type='FeMaSRNet', **CONFIGS['x4']))
     net.test = _fake_test.__get__(net)
+    net.test_u8 = _fake_test_u8.__get__(net)
     net.max_tile_batch = 3
     return net
 
@@ -89,9 +103,12 @@ def _worker8(rank, world, port, x, expects, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     fd.init_from_env('gloo')
     ok = []
-    for (ts, pad, _), expect in zip(_GEOMS8, expects):
+    xu8 = (x[0].permute(1, 2, 0) * 255).round().to(torch.uint8)          # (H,W,3): the CLI's data type
+    for (ts, pad, _), (expect, expect_u8) in zip(_GEOMS8, expects):
         y = fd.test_tile_parallel(_make_net(), x, ts, pad)
         ok.append(bool(torch.equal(y, expect)))
+        yu = fd.test_tile_parallel(_make_net(), xu8, ts, pad)               # uint8 tiles through the same partition / ONE all-gather / paste
+        ok.append(yu.dtype == torch.uint8 and bool(torch.equal(yu, expect_u8)))
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -145,7 +162,12 @@ def test_eight_rank_tile_parallel_config3_geometries():
         else:
             assert len(classes) == 9 and sorted((len(tl) for tl in classes.values()), reverse=True)[:5] == \
                 ([400, 20, 20, 20, 20] if ntiles == 484 else [49, 7, 7, 7, 7])
-        expects.append(net.test_tile(x, ts, pad))
+        # the uint8 path (round 6): single-rank test_tile_u8 == tensor2img of the fp32 path's canvas built from the SAME decoded image
+        xu8 = (x[0].permute(1, 2, 0) * 255).round().to(torch.uint8)
+        want_u8 = net.test_tile_u8(xu8, ts, pad)
+        ref = net.test_tile(_to_f32(xu8[None]), ts, pad)
+        assert want_u8.dtype == torch.uint8 and torch.equal(want_u8, _to_u8(ref * 0.25)[0])
+        expects.append((net.test_tile(x, ts, pad), want_u8))
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -156,7 +178,7 @@ def test_eight_rank_tile_parallel_config3_geometries():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert sorted(res) == [(r, [True, True, True]) for r in range(world)]
+    assert sorted(res) == [(r, [True] * 6) for r in range(world)]
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -213,7 +235,10 @@ def _worker_root(rank, world, port, x, ts, pad, expect, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     fd.init_from_env('gloo')
     y = fd.test_tile_parallel(_make_net(), x, ts, pad, root_only=True)
-    q.put((rank, bool(torch.equal(y, expect)) if rank == 0 else y is None))
+    xu8 = (x.permute(0, 2, 3, 1) * 255).round().to(torch.uint8)           # batched uint8 (B,H,W,3): the same call takes the uint8 path
+    yu = fd.test_tile_parallel(_make_net(), xu8, ts, pad, root_only=True)
+    ok_u8 = bool(torch.equal(yu, _make_net().test_tile_u8(xu8, ts, pad))) if rank == 0 else yu is None
+    q.put((rank, (bool(torch.equal(y, expect)) if rank == 0 else y is None) and ok_u8))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -104,7 +104,11 @@ def test_cli_tiled_branch_on_testset_png(cuda_device, math):
     assert err < TOL, (err, flips)
     if flips == 0:
         assert abs(float(yn.astype(np.float64).mean()) - float(g['out_mean'])) < 1e-5
-    out = imgproc.output_to_u8(y).cpu().numpy()
+    out_t = imgproc.output_to_u8(y)
+    # round 6: the uint8 tile path (crops, forwards and paste on bytes; what the CLI's tiled branch calls) gives the same image, bit for bit
+    out_u8 = net.test_tile_u8(u8, ts, pad)
+    assert out_u8.dtype == torch.uint8 and torch.equal(out_u8, out_t), int((out_u8 != out_t).sum())
+    out = out_t.cpu().numpy()
     diff = np.abs(out[::4, ::4].astype(np.int16) - g['output_u8_stride4'].astype(np.int16)).max(axis=2)[~mask[::4, ::4]]
     # a value within ~1e-5 of x.5/255 may round the other way
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (int(diff.max()), float((diff > 0).mean()))
