@@ -45,7 +45,7 @@ X4_CFG = dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512]], LQ_stage=True
 WORKLOADS = {
     'x2b32': dict(cfg=dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512]], LQ_stage=True, scale_factor=2), batch=32, hw=256, fn='test', out_hw=512,
                   gflop=1075.05, tile='256x256->512x512', metric='SR output megapixels/sec at x2 (256->512)',
-                  text='BASELINE config 4: x2 SR FeMaSRNet.test (scale_factor=2 encoder head: 3->128 in_conv, ONE stride-2 stage), batch {B} of 256x256 LR tiles -> 512x512 '
+                  text='BASELINE config 4: x2 SR FeMaSRNet.test (scale_factor=2 encoder head: 3->128 in_conv, TWO stride-2 stages 128->256->256, femasr_arch.py:255-256), batch {B} of 256x256 LR tiles -> 512x512 '
                        '(padded 288->576 inside)'),
     'hq8': dict(cfg=dict(type='FeMaSRNet', codebook_params=[[32, 1024, 512]], LQ_stage=False), batch=8, hw=512, fn='forward', out_hw=512,
                 gflop=544.21, tile='512x512->512x512', metric='autoencoded megapixels/sec (HQ pretrain stage, 512x512)',
@@ -308,6 +308,10 @@ def main():
     ap.add_argument('--no-gather', action='store_true', help='tiles16, N>1: skip the all-gather of upscaled tiles')
     ap.add_argument('--force-gather', action='store_true',
                     help='N=1: still run the all-gather path through a one-rank RCCL group (exercises the N>1 code on one GPU)')
+    ap.add_argument('--no-strong-leg', action='store_true',
+                    help='N > 1, tiles16: do not append the strong-scaling leg (BASELINE config 3a: ONE 2048x2048 LR image, 256 tiles of 128, sharded '
+                         'over the ranks; all-gather + paste timed) that makes the same JSON line carry both scalings')
+    ap.add_argument('--strong-steps', type=int, default=2, help='timed steps of the strong-scaling leg (after one warm-up step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bf16x3-leg', '--no-exact-leg', dest='no_second_leg', action='store_true',
                     help='skip the extra timing of the other decoder-math mode')
@@ -526,6 +530,55 @@ def main():
     if args.workload == 'tiles16' and do_gather:
         res['config']['gather_overlap'] = 'all-gather of step k overlaps step k+1'
 
+    # ---------------------------------------------------------------- strong-scaling leg (all ranks; after the timed region of record)
+    # the driver runs ONE command per N.  With N > 1 the default (weak-scaling) workload therefore appends BASELINE
+    # config 3a - one 2048x2048 LR image = 256 tiles of 128x128, sharded over the ranks by the work-balanced partition, ONE RCCL all-gather
+    # of the upscaled tiles, paste on rank 0 - so that the same JSON line records a point of the strong curve too, with each rank's
+    # compute / gather / paste split.  (`--workload tile2048` is the same thing as the workload of record, with every rank pasting.)
+    if world > 1 and args.workload == 'tiles16' and not args.no_strong_leg and use_pg:
+        if sg is not None:
+            sg.wait_all()
+        S = 512 if dry else args.image
+        img = torch.from_numpy(synth.synth_input(2000, (1, 3, S, S))).to(dev)
+        keep_batch = net.max_tile_batch
+        net.max_tile_batch = B
+        net.time_split = not dry
+
+        def strong_step():
+            return fd.test_tile_parallel(net, img, 128, 0, root_only=True)
+        strong_step()
+        dist.barrier()
+        sync()
+        ts0 = time.perf_counter()
+        for _ in range(max(1, args.strong_steps)):
+            ys = strong_step()
+        dist.barrier()
+        sync()
+        dts = (time.perf_counter() - ts0) / max(1, args.strong_steps)
+        tall = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([dts], dtype=torch.float64, device=dev))
+        dts_max = max(float(t.item()) for t in tall)
+        split = [None] * world
+        dist.all_gather_object(split, net.last_split_ms if not dry else None)
+        from femasr_amd import tiling
+        cls = tiling.shape_classes(tiling.enumerate_tiles(S, S, 128, 0))
+        if rank == 0:
+            assert ys is not None and tuple(ys.shape) == (1, 3, 4 * S, 4 * S)
+        res['strong_scaling'] = {
+            'workload': (f'x4 SR of ONE {S}x{S} LR image: test_tile(128, 0) = {(S // 128) ** 2} tiles sharded over {world} ranks in batches of {B}, ONE RCCL '
+                         f'all-gather of the upscaled fp32 tiles, paste into the {4 * S}x{4 * S} canvas on rank 0 - all inside the timed step (BASELINE config 3a)'),
+            'scaling': 'strong', 'steps': max(1, args.strong_steps), 'warmup': 1,
+            'ms_per_step': round(dts_max * 1e3, 3), 'value': round((4 * S) * (4 * S) / 1e6 / dts_max, 4), 'unit': 'MPix/s',
+            'per_rank_ms_per_step': [round(float(t.item()) * 1e3, 3) for t in tall],
+            'last_step_split_ms_per_rank': split,
+            'tiles_per_rank': [sum(len(tl) for tl in o.values()) for o in tiling.assign(cls, world, 4)],
+            'partition_bound': round(tiling.balance_bound(cls, world, 4), 3),
+            'one_gpu_reference': 'profiles/r04_tile2048_bench.json: 1.147 s per step = 58.5 MPix/s on one MI355X (round 4; gather 0.005 ms, paste 0.62 ms)',
+        }
+        net.max_tile_batch = keep_batch
+        net.time_split = False
+        del img, ys
+
     # ---------------------------------------------------------------- rank-0 extras (not part of the timed region)
     if rank == 0 and not dry:
         x16 = x if (args.workload == 'tiles16' or wl) else torch.from_numpy(synth.synth_input(1000, (B, 3, 128, 128))).to(dev)
@@ -632,11 +685,25 @@ def main():
                 'note': 'per GPU; flops of one profiled step (kernel launch records) over the TIMED step time of this rank'}
             res['roofline']['measured_in'] = (f'{psteps} serialized steps (streams=1, {prof_ms_per_step:.1f} ms/step, batch {B} of 128x128 tiles, '
                                               f"decoder_math={args.decoder_math}) right after the timed region")
+            # the split GEMM on ITS pipe: six bf16 passes per multiply-add of the definition over the dense bf16 peak - at the
+            # nominal 2.4 GHz and at the engine clock the power sampler read during the timed steps (the launch is power-bound: profiles/r06_gemm_experiments.txt).
+            # Price per v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD (SQ_VALU_MFMA_BUSY_CYCLES = 32 x MFMAs in every profiled launch) = the 2.5 PF figure.
+            sclk = (power or {}).get('sclk_mhz_median')
+
+            def bf16_pipe(k, v):
+                if not k.startswith('gemm_bf16s') or v[2] <= 0:
+                    return {}
+                pf = 6.0 * v[2] / (v[0] * 1e-3) / 1e12
+                return {'bf16_pipe_tflops': round(pf, 1), 'bf16_pipe_frac_at_2.4GHz': round(pf / PEAK_BF16_MFMA_TFLOPS, 4),
+                        **({'bf16_pipe_frac_at_measured_clock': round(pf / (PEAK_BF16_MFMA_TFLOPS * sclk / 2400.0), 4)} if sclk else {})}
             res['roofline']['per_kernel'] = {
                 k: {'ms_per_step': round(v[0] / psteps, 3), 'launches_per_step': v[1] // psteps,
                     **({'issued_tflops': round(v[2] * issued_share(k) / (v[0] * 1e-3) / 1e12, 1),
-                        'algorithmic_tflops': round(v[2] / (v[0] * 1e-3) / 1e12, 1)} if v[2] > 0 else {})}
+                        'algorithmic_tflops': round(v[2] / (v[0] * 1e-3) / 1e12, 1)} if v[2] > 0 else {}), **bf16_pipe(k, v)}
                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            lin = {k: v for k, v in prof.items() if k.startswith('gemm_bf16s') or k.startswith('gemm_dma') or k == 'layernorm'}
+            if lin:
+                res['roofline']['swin_linear_bucket_ms_per_step'] = round(sum(v[0] for v in lin.values()) / psteps, 3)
             vq = prof.get('vq(codebook lookup)')
             if vq:          # the north-star's VQ figure: algorithmic HBM bytes (23.37 MB per tile) / time
                 res['roofline']['vq'] = {'ms_per_step': round(vq[0] / psteps, 3), 'algorithmic_GB_per_step': round(vq[3] / psteps / 1e9, 4),

@@ -545,7 +545,8 @@ struct Ctx {
         // linear_math 1 (round 6): norm1 / norm2 write the three bf16 planes of their output in the packed layout the split GEMM copies
         // straight into LDS (6 bytes per value instead of 4; the GEMM's A side does no conversion work), and fc1 hands its GELU output to fc2
         // the same way.  The attention kernel still writes fp32 rows: proj splits them in its staging.
-        const bool planes = h->linear_math == 1;
+        static const bool planes_env = [] { const char *e = getenv("FEMASR_LINEAR_PLANES"); return !(e && e[0] == '0'); }();      // (A/B measurement of round 6)
+        const bool planes = h->linear_math == 1 && planes_env;
         auto ln = [&](const T &t, const std::string &np) {       // normalised tokens, materialised once (read by DMA in the GEMM)
             T o;
             o.B = 1; o.H = rows; o.W = 1; o.C = C;

@@ -32,3 +32,10 @@ def test_self_launch_two_ranks(extra, scaling, units):
     assert r['config']['gather'] is True and r['config']['backend'] == 'gloo'
     assert r['value'] > 0 and r['higher_is_better'] is True and r['vs_baseline'] is None
     assert 'dry-net' in r['data']
+    if scaling == 'weak':
+        # one driver call, both scalings: the default workload on N > 1 ranks appends the strong-scaling leg
+        ss = r['strong_scaling']
+        assert ss['scaling'] == 'strong' and ss['value'] > 0 and ss['ms_per_step'] > 0 and len(ss['per_rank_ms_per_step']) == 2
+        assert sum(ss['tiles_per_rank']) == 16 and ss['partition_bound'] == 2.0        # dry net: a 512x512 stand-in image = 16 tiles of 128
+    else:
+        assert 'strong_scaling' not in r
