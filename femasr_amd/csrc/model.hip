@@ -545,8 +545,8 @@ struct Ctx {
         // linear_math 1 (round 6): norm1 / norm2 write the three bf16 planes of their output in the packed layout the split GEMM copies
         // straight into LDS (6 bytes per value instead of 4; the GEMM's A side does no conversion work), and fc1 hands its GELU output to fc2
         // the same way.  The attention kernel still writes fp32 rows: proj splits them in its staging.
-        static const bool planes_env = [] { const char *e = getenv("FEMASR_LINEAR_PLANES"); return !(e && e[0] == '0'); }();      // (A/B measurement of round 6)
-        const bool planes = h->linear_math == 1 && planes_env;
+        static const int planes_env = [] { const char *e = getenv("FEMASR_LINEAR_PLANES"); return e ? atoi(e) : 1; }();      // (A/B measurement of round 6: 0 off, 1 all, 2 LayerNorm outputs only)
+        const bool planes = h->linear_math == 1 && planes_env != 0;
         auto ln = [&](const T &t, const std::string &np) {       // normalised tokens, materialised once (read by DMA in the GEMM)
             T o;
             o.B = 1; o.H = rows; o.W = 1; o.C = C;
@@ -579,7 +579,7 @@ struct Ctx {
         T y1 = conv(att, bp + ".attn.proj", C, op);
         release(att);
         T n2 = ln(y1, bp + ".norm2");
-        ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.act = FEMASR_ACT_GELU; o1.in_planes = n2.planes; o1.out_planes = planes;
+        ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.act = FEMASR_ACT_GELU; o1.in_planes = n2.planes; o1.out_planes = planes && planes_env == 1;
         T hdn = conv(n2, bp + ".mlp.fc1", 4 * C, o1);
         drop(n2);
         ConvOpt o2; o2.ksz = 1; o2.pad = 0; o2.res1 = y1.p; o2.in_planes = hdn.planes;

@@ -189,7 +189,7 @@ def test_test_tile_u8_equals_the_fp32_tile_path(cuda_device):
     net = G.build_net('x4', w, cuda_device)
     rng = np.random.default_rng(5)
     img = torch.from_numpy(rng.integers(0, 256, (2, 75, 100, 3), dtype=np.uint8)).to(cuda_device)
-    want = imgproc.output_to_u8(net.test_tile(imgproc.u8_to_input(img), 32, 8))
+    want = torch.stack([imgproc.output_to_u8(net.test_tile(imgproc.u8_to_input(img[i]), 32, 8)) for i in range(2)])
     got = net.test_tile_u8(img, 32, 8)
     assert got.dtype == torch.uint8 and got.shape == (2, 300, 400, 3) and torch.equal(got, want), int((got != want).sum())
     one = net.test_tile_u8(img[1], 32, 8)                               # (H,W,3) in -> (sH,sW,3) out
