@@ -38,11 +38,11 @@ class ConvArgs(ctypes.Structure):
         ('act', ctypes.c_int32),
         ('res1', vp), ('res2', vp), ('out', vp),
         ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32),
-        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp), ('w_wino', vp), ('fast_act', ctypes.c_int32), ('in_add', vp), ('w_bf16s', vp), ('in_bf16s', vp), ('out_bf16s', vp),
+        ('w_bf16x3', vp), ('gn_part', vp), ('w_up2', vp), ('w_wino', vp), ('fast_act', ctypes.c_int32), ('in_add', vp), ('w_bf16s', vp),
     ]
 
 
-ABI_VERSION = 102      # femasr_version(): femasr_conv_args ends with in_bf16s / out_bf16s
+ABI_VERSION = 102      # femasr_version(): debug hooks in their own header, uint8 tile kernels (femasr_conv_args ends with w_bf16s)
 PRO_NONE, PRO_GN_SILU, PRO_LN = 0, 1, 2
 ACT_NONE, ACT_GELU = 0, 1
 
@@ -109,10 +109,6 @@ SIGNATURES = {
     'femasr_set_linear_math': (c_int, [vp, c_int]),
     'femasr_packed_weight_bf16s_bytes': (szt, [c_int, c_int]),
     'femasr_repack_k1_bf16s': (c_int, [vp, vp, c_int, c_int, vp]),
-    'femasr_packed_rows_bf16s_bytes': (szt, [c_i64, c_int]),
-    'femasr_pack_rows_bf16s': (c_int, [vp, vp, c_i64, c_int, vp]),
-    'femasr_unpack_rows_bf16s': (c_int, [vp, vp, c_i64, c_int, vp]),
-    'femasr_layernorm_bf16s': (c_int, [vp, vp, c_i64, c_int, vp, vp, c_f32, vp]),
     'femasr_image_u8_to_f32': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_image_f32_to_u8': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_clock_probe': (c_int, [vp, c_int, vp]),

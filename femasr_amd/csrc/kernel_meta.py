@@ -119,13 +119,11 @@ def check(verbose=False):
 
 OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 VMEM_PREFIXES = ('global_', 'buffer_', 'scratch_', 'flat_', 'tbuffer_')
-# kernels_gemm_bf16.hip: what one trip of the MFMA loop may contain.  AIN = 1 (planes by LDS-DMA): one step = six copies, one counted wait
-# (the six copies of the next step stay in flight).  AIN = 0 (fp32 rows): two chunks = four steps = twelve W copies + two 4-load row fetches,
-# waits 14 / 10 / 10 per chunk.  The numbers are the source's (`s_waitcnt vmcnt(N)` in the inline asm); check_counted_waits() also reads them there.
-COUNTED = {
-    1: {'loops': 1, 'global_load_lds_dwordx4': 6, 'vmcnt': {6: 1}},
-    0: {'loops': 1, 'global_load_lds_dwordx4': 12, 'global_load_dwordx4': 8, 'vmcnt': {14: 2, 10: 4}},
-}
+# kernels_gemm_bf16.hip: what one trip of the MFMA loop may contain: two chunks = four steps = twelve W copies (LDS-DMA) + two 4-load row
+# fetches, waits 14 / 10 / 10 per chunk.  The numbers are the source's (`s_waitcnt vmcnt(N)` in the inline asm); check_counted_waits() also
+# reads them there.
+COUNTED = {'loops': 1, 'global_load_lds_dwordx4': 12, 'global_load_dwordx4': 8, 'vmcnt': {14: 2, 10: 4}}
+N_GEMM_BF16S = 6                # instantiations (activation x residual operands)
 
 
 def disassemble(obj_path):
@@ -180,16 +178,15 @@ def check_counted_waits(obj=None):
     problems = []
     src = open(os.path.join(HERE, 'kernels_gemm_bf16.hip')).read()
     src_counts = sorted({int(v) for v in re.findall(r's_waitcnt vmcnt\((\d+)\)', src)})
-    want_counts = sorted({0} | {n for c in COUNTED.values() for n in c['vmcnt']})
+    want_counts = sorted({0} | set(COUNTED['vmcnt']))
     if src_counts != want_counts:
         problems.append(f'kernels_gemm_bf16.hip waits for vmcnt {src_counts}, kernel_meta.COUNTED expects {want_counts}: update both together')
     seen = 0
     for name, insts in disassemble(obj).items():
-        m = re.search(r'gemm_bf16s_kernelILi(\d)E', name)
-        if not m:
+        if 'gemm_bf16s_kernel' not in name:
             continue
         seen += 1
-        want = COUNTED[int(m.group(1))]
+        want = COUNTED
         loops = mfma_loops(insts)
         if len(loops) != want['loops']:
             problems.append(f'{demangle_short(name)}: expected {want["loops"]} MFMA loop(s), found {len(loops)}')
@@ -210,7 +207,7 @@ def check_counted_waits(obj=None):
                 problems.append(f'{demangle_short(name)}: vmcnt waits in the MFMA loop {waits}, the source has {want["vmcnt"]}')
             if not any(op == 's_barrier' for _, op, _ in body):
                 problems.append(f'{demangle_short(name)}: no s_barrier in the MFMA loop')
-    if seen < 14:
+    if seen < N_GEMM_BF16S:
         problems.append(f'only {seen} gemm_bf16s_kernel instantiations found in {obj}')
     return problems
 

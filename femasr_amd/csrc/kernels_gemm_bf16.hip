@@ -6,11 +6,8 @@
 //
 // Arithmetic (restated bit for bit in oracle/femasr_oracle.c, orc_linear_bf16s):
 //   * every fp32 operand is split EXACTLY into three bf16 terms,  x = x1 + x2 + x3:  x1 = bf16_rne(x), x2 = bf16_rne(x - x1),
-//     x3 = (x - x1) - x2 (exactly a bf16 value: 8 + 8 + 8 significand bits); weights at pack time; activations EITHER while the A tile
-//     is staged (AIN = 0: fp32 rows in HBM, registers -> v_cvt_pk_bf16_f32 -> LDS) OR where they are produced (AIN = 1, round 6: the
-//     LayerNorm kernel / the fc1 epilogue write the three planes in the packed layout below, 6 bytes per value instead of 4, and the A
-//     side of the main loop is pure LDS-DMA like the W side - no registers, no conversions, no LDS stores).  The split is a pure
-//     function of the fp32 value, so both forms give the same bits;
+//     x3 = (x - x1) - x2 (exactly a bf16 value: 8 + 8 + 8 significand bits); weights at pack time, activations while the A tile
+//     is staged (fp32 rows in HBM, registers -> v_cvt_pk_bf16_f32 -> LDS);
 //   * of the nine bf16 x bf16 partial products (each exact in fp32) the six of relative size >= 2^-16 are kept:
 //         hi += a1 b1          lo += a3 b1, a1 b3, a2 b2, a2 b1, a1 b2  (in this order)
 //     per 16-deep k step, k ascending; the three dropped ones are <= 2^-25 |a b| together (RNE terms: |x2| <= 2^-9 |x|,
@@ -28,14 +25,17 @@
 // LDS -> two blocks per CU (one block's prologue / epilogue under the other's MFMAs).  The loop advances in 16-deep k STEPS:
 //   * W planes: packed [step][n/32][plane][lane][8 bf16] (femasr_repack_k1_bf16s), copied into an LDS ring by LDS-DMA, 3 pieces of
 //     1 KiB per wave and step;
-//   * A, AIN = 1: packed [m/128][step][plane][granule = 8 channels][row % 128][8 bf16] (femasr_pack_rows_bf16s / femasr_layernorm_bf16s /
-//     this kernel's OUTP = 1 epilogue): a step of a block is 12 contiguous KiB, 3 pieces of 1 KiB per wave - the main loop holds six
-//     LDS-DMA copies, twelve ds_read_b128 and 24 MFMAs per wave and step, nothing else; three-stage ring, one barrier per step;
-//   * A, AIN = 0 (producers that do not write planes: the attention kernel's output for proj, a conv's output for before_quant):
-//     fp32 rows from global into registers two 32-deep chunks ahead, split on the VALU between the MFMAs of the current step - the
-//     VALU work is ADDED to the bf16 MFMA issue, ~1.8 cycles per instruction (DESIGN.md 5 "Round 5" 5.) - and written as three
-//     16-byte LDS stores per 8 channels into the half of the A buffer the NEXT step reads; W ring of 4 stages; one barrier per step.
-// Every global access of both main loops is inline asm with hand-counted `s_waitcnt vmcnt(N)` waits (behind the LDS-DMA builtin the
+//   * A: fp32 rows from global into registers two 32-deep chunks ahead, split on the VALU between the MFMAs of the current step and
+//     written as three 16-byte LDS stores per 8 channels into the half of the A buffer the NEXT step reads; W ring of 4 stages; one
+//     barrier per step.
+// Round 6 built the other form the VERDICT asked for - the split done by the PRODUCERS (LayerNorm, the fc1 epilogue: three packed bf16
+// planes, 6 bytes per value), the A side of the main loop pure LDS-DMA like the W side: 8 VALU instructions per step instead of 42, every
+// output bit-identical - and measured it (profiles/r06_gemm_experiments.txt): -3 % / -5 % / -1 % per qkv / fc1 / fc2 launch stand-alone, the
+// planes' extra bytes (LayerNorm writes 1.5x, fc1's plane epilogue +9 %) eat that in the network: 65.8 - 66.6 ms per step against 64.9 - 65.6
+// with fp32 rows, alternating on two boxes.  The launch runs at the package power limit (constant operands instead of random ones: 15 %
+// faster on the same instruction stream), so removing instructions raises the clock the chip can hold, not the throughput.  Removed again;
+// git history (8a3f0b5) has the kernels, the packed-row layout and their tests.
+// Every global access of the main loop is inline asm with hand-counted `s_waitcnt vmcnt(N)` waits (behind the LDS-DMA builtin the
 // compiler waits for vmcnt(0) at the first LDS access and sinks the copies below the compute).  The counts are only right if the
 // compiler emits NO VMEM instruction of its own between them: csrc/kernel_meta.py check_counted_waits() disassembles these kernels
 // after every build and fails it otherwise (tests/test_host_logic.py::test_counted_waits_of_the_split_gemm).
@@ -51,23 +51,18 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 namespace {
 
 struct GemmSParams {
-    const float *A;          // AIN = 0: fp32 rows
-    const uint4 *Ap;         // AIN = 1: packed planes (femasr_pack_rows_bf16s layout)
+    const float *A;
     const uint4 *W;          // femasr_repack_k1_bf16s
     const float *bias, *res1, *res2;
-    float *out;              // OUTP = 0
-    uint4 *outp;             // OUTP = 1: packed planes of the output (N = the consumer's K)
+    float *out;
     int M, N, K, MB, NB, NT32;
 };
 
-constexpr int GS_A_HALF = 3 * 2 * 128;                // AIN = 0: uint4 per step: [plane][granule][row]
+constexpr int GS_A_HALF = 3 * 2 * 128;                // uint4 per step: [plane][granule][row]
 constexpr int GS_A_BYTES = 2 * GS_A_HALF * 16;        // two steps
 constexpr int GS_W_STAGE = 4 * 3 * 64;                // uint4 per step: [column tile][plane][lane]
 constexpr int GS_W_STAGES = 4;
 constexpr int GS_LDS_BYTES = GS_A_BYTES + GS_W_STAGES * GS_W_STAGE * 16;      // 24 576 + 49 152 = 73 728
-constexpr int GP_STAGE = GS_A_HALF + GS_W_STAGE;      // AIN = 1: uint4 per step: A [plane][granule][row] then W [column tile][plane][lane]
-constexpr int GP_STAGES = 3;
-static_assert(GP_STAGES * GP_STAGE * 16 == GS_LDS_BYTES, "both main loops use the same 72 KB");
 static_assert(4 * TSCRATCH * 4 <= GS_LDS_BYTES, "epilogue scratch overlays the main-loop buffers");
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
@@ -108,12 +103,9 @@ __device__ __forceinline__ void dma3(const uint4 *w, unsigned d0)
                  : "=&s"(m0_keep) : "s"(d0), "s"(d0 + 1024u), "s"(d0 + 2048u), "v"(w), "v"(w + 64), "v"(w + 128) : "memory");
 }
 
-// AIN: 0 fp32 rows split in the staging, 1 packed planes by LDS-DMA.  OUTP: 0 fp32 rows out, 1 the three planes of the output in the
-// packed A layout (what the next linear's AIN = 1 reads; no residual operands in that form).
-template <int AIN, int ACT, int NRES, int OUTP>
+template <int ACT, int NRES>
 __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
 {
-    static_assert(!OUTP || (NRES == 0 && AIN == 1), "plane output: planes in, no residual operands");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *S = reinterpret_cast<uint4 *>(smem_raw);
 
@@ -170,42 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
     };
     const int boff = (wn * 2) * 192 + lane;      // + ct*192 + plane*64
 
-    if constexpr (AIN == 1) {
-        // ================= A planes by LDS-DMA: stage s % 3 = [A: plane][granule][row] (12 KiB) | [W: column tile][plane][lane] (12 KiB)
-        // Wave w copies A pieces 3w .. 3w + 2 of the step (piece a = (plane, granule, row half) = (a / 4, (a / 2) & 1, a & 1): 64 rows of
-        // 16 bytes, contiguous in the pack AND in the stage) and its three W pieces: six copies per wave and step.
-        const uint4 *srcA = p.Ap + (size_t)mb * nsteps * GS_A_HALF + wave * 192 + lane;
-        int aoff[2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) aoff[rt] = h * 128 + wm * 64 + rt * 32 + c31;      // granule h of the step, row of the block
-        const unsigned ldsA = lds0 + (unsigned)wave * 3072u, ldsW = lds0 + (unsigned)(GS_A_HALF * 16) + (unsigned)wave * 3072u;
-        auto issue = [&](int s, int stage) {               // unconditional (steps past the end re-copy the last one into a dead stage): the wait counts stay static
-            const int sc = s < nsteps ? s : nsteps - 1;
-            const unsigned so = (unsigned)stage * (GP_STAGE * 16);
-            dma3(srcA + (size_t)sc * GS_A_HALF, ldsA + so);
-            dma3(srcW + (size_t)sc * wstep, ldsW + so);
-        };
-        // VMEM issue order (the vmcnt arithmetic depends on it): step s issues the six copies of step s + 2; the prologue plays steps -2, -1.
-        issue(0, 0);
-        issue(1, 1);
-        int st = 0, st2 = 2;                               // stage of step s, of step s + 2 (uniform)
-        // (Round 6 measured what does NOT bound this loop, profiles/r06_gemm_experiments.txt: the copies ahead of or behind the MFMAs, in a
-        // different order in the CU's two resident blocks (slot parity from HW_REG_LDS_ALLOC), the second block of a CU started 8k - 40k cycles
-        // late - every variant within +-1.5 % of this one; constant instead of random operands: 15 % FASTER.  The launch runs at the package
-        // power limit: its time is joules per output, not schedule.)
-#pragma unroll 1
-        for (int s = 0; s < nsteps; ++s) {
-            // the six copies of step s have landed (the six of step s + 1 may be in flight); every wave has read step s - 1's stage
-            asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            issue(s + 2, st2);
-            const uint4 *Sb = S + st * GP_STAGE;
-            compute(Sb, aoff, Sb + GS_A_HALF + boff);
-            st = st == GP_STAGES - 1 ? 0 : st + 1;
-            st2 = st2 == GP_STAGES - 1 ? 0 : st2 + 1;
-        }
-    } else {
+    {
         // ================= fp32 rows: thread -> row t >> 1, granule g2 = t & 1 of each step: item 0 = channels 8 g2 .. +7 of a chunk
         // (step 2c), item 1 = channels 16 + 8 g2 .. (step 2c + 1); two lanes cover 64 contiguous bytes of a row per load
         uint4 *Al = S;
@@ -283,48 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
     // are still being written and would reuse them for the addresses below)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float *T = reinterpret_cast<float *>(smem_raw) + wave * TSCRATCH;
-    if constexpr (OUTP == 1) {
-        // plane output: lane l owns row l & 31 of the tile and the 8-column granule (l >> 5) + 2 pass: GELU, split, three 16-byte stores;
-        // 32 lanes = 32 consecutive rows of one (step, plane, granule) record = 512 contiguous bytes.  (N % 16 == 0 is required by the launcher.)
-        const int nsteps_o = p.N >> 4;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-            const int i = tl >> 1, j = tl & 1;
-            const int rloc = (wm * 2 + i) * 32 + c31, cbase = n0 + (wn * 2 + j) * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TPITCH + c31] = hi[i][j][r] + lo[i][j][r];
-            // (same wave wrote and reads the scratch: LDS ops of one wave complete in order)
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int col = cbase + 8 * (h + 2 * pass);
-                const bool ok = col < p.N && m0 + rloc < p.M;
-                const f32x4_t a0 = *reinterpret_cast<const f32x4_t *>(T + c31 * TPITCH + 8 * (h + 2 * pass));
-                const f32x4_t a1 = *reinterpret_cast<const f32x4_t *>(T + c31 * TPITCH + 8 * (h + 2 * pass) + 4);
-                const f32x4_t b0 = *reinterpret_cast<const f32x4_t *>(p.bias + (col < p.N ? col : 0));
-                const f32x4_t b1 = *reinterpret_cast<const f32x4_t *>(p.bias + (col < p.N ? col : 0) + 4);
-                f32x4_t u = {a0[0] + b0[0], a0[1] + b0[1], a0[2] + b0[2], a0[3] + b0[3]};
-                f32x4_t v = {a1[0] + b1[0], a1[1] + b1[1], a1[2] + b1[2], a1[3] + b1[3]};
-                if (ACT == FEMASR_ACT_GELU) {
-                    const det_f32x2 g0 = det_gelu2(det_f32x2{u[0], u[1]}), g1 = det_gelu2(det_f32x2{u[2], u[3]});
-                    const det_f32x2 g2 = det_gelu2(det_f32x2{v[0], v[1]}), g3 = det_gelu2(det_f32x2{v[2], v[3]});
-                    u = f32x4_t{g0[0], g0[1], g1[0], g1[1]};
-                    v = f32x4_t{g2[0], g2[1], g3[0], g3[1]};
-                }
-                uint4 q1, q2, q3;
-                split3_x8(u, v, q1, q2, q3);
-                if (ok) {
-                    uint4 *d = p.outp + ((size_t)mb * nsteps_o + (col >> 4)) * GS_A_HALF + ((col >> 3) & 1) * 128 + rloc;
-                    d[0] = q1;
-                    d[256] = q2;
-                    d[512] = q3;
-                }
-            }
-        }
-        return;
-    } else {
+    {
         // fp32 output: lane l owns columns 4 (l & 7) .. +3 of tile rows (l >> 3) + 8 k: float4 loads / stores (the epilogue of kernels_gemm.hip).
         // Bias (two column tiles) and the residual rows of the first tile are requested BEFORE the last barrier, the residuals of tile t + 1 before
         // tile t is processed: one exposed round trip per block instead of one per tile (profiles/r05_gemm_bf16s_ubench.txt).
@@ -425,118 +341,6 @@ __global__ void repack_k1_bf16s_kernel(const float *__restrict__ in, int O, int 
     }
 }
 
-// fp32 rows (M, K) -> the packed A planes [m/128][k/16][plane][granule][m % 128] x 8 bf16 (rows past M: zeros).
-// thread = (row block, step, granule, row): consecutive threads = consecutive rows of one record (coalesced 16-byte stores; the loads are
-// 32-byte pieces of rows K floats apart - this kernel serves tests, tools and hosts that hold fp32 rows, the network's producers write planes).
-__global__ void pack_rows_bf16s_kernel(const float *__restrict__ x, long long M, int K, uint4 *__restrict__ out, size_t total)
-{
-    const int nsteps = K >> 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i & 127), g = (int)((i >> 7) & 1);
-        const size_t rest = i >> 8;
-        const int st = (int)(rest % nsteps);
-        const long long mb = (long long)(rest / nsteps), row = mb * 128 + r;
-        f32x4_t u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
-        if (row < M) {
-            u = *reinterpret_cast<const f32x4_t *>(x + (size_t)row * K + 16 * st + 8 * g);
-            v = *reinterpret_cast<const f32x4_t *>(x + (size_t)row * K + 16 * st + 8 * g + 4);
-        }
-        uint4 q1, q2, q3;
-        split3_x8(u, v, q1, q2, q3);
-        uint4 *o = out + ((size_t)mb * nsteps + st) * GS_A_HALF + g * 128 + r;
-        o[0] = q1;
-        o[256] = q2;
-        o[512] = q3;
-    }
-}
-
-// the inverse (tests: what a producer wrote, as fp32 rows): x = x1 + x2 + x3, exact
-__global__ void unpack_rows_bf16s_kernel(const uint4 *__restrict__ in, long long M, int K, float *__restrict__ x, size_t total)
-{
-    const int nsteps = K >> 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i & 127), g = (int)((i >> 7) & 1);
-        const size_t rest = i >> 8;
-        const int st = (int)(rest % nsteps);
-        const long long mb = (long long)(rest / nsteps), row = mb * 128 + r;
-        if (row >= M) continue;
-        const uint4 *o = in + ((size_t)mb * nsteps + st) * GS_A_HALF + g * 128 + r;
-        const uint4 q1 = o[0], q2 = o[256], q3 = o[512];
-        const unsigned a1[4] = {q1.x, q1.y, q1.z, q1.w}, a2[4] = {q2.x, q2.y, q2.z, q2.w}, a3[4] = {q3.x, q3.y, q3.z, q3.w};
-        float *d = x + (size_t)row * K + 16 * st + 8 * g;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            d[2 * e] = (__uint_as_float(a1[e] << 16) + __uint_as_float(a2[e] << 16)) + __uint_as_float(a3[e] << 16);
-            d[2 * e + 1] = (__uint_as_float(a1[e] & 0xffff0000u) + __uint_as_float(a2[e] & 0xffff0000u)) + __uint_as_float(a3[e] & 0xffff0000u);
-        }
-    }
-}
-
-// y = LayerNorm(x) over C = 256 (the arithmetic of layernorm_kernel, kernels_misc.hip: lane l sums elements 4l..4l+3, xor-butterfly
-// 32...1, two-pass, fmaf((x - mean) * rstd, gamma, beta)) written as the three bf16 planes in the packed A layout: norm1 / norm2 in
-// front of qkv / fc1 (network_swinir.py:243,277).  Block = 4 waves x 8 rows = 32 consecutive rows (inside one 128-row block); the
-// planes go through LDS ([plane][8-channel granule][row], pitch 33 rows) so that every global store instruction writes whole 512-byte
-// runs of one (step, plane, granule) record.
-constexpr int LNS_ROWS = 32, LNS_PITCH = 33;
-__global__ __launch_bounds__(256) void layernorm_bf16s_kernel(const float *__restrict__ x, long long rows, const float *__restrict__ gamma,
-                                                              const float *__restrict__ beta, float eps, uint4 *__restrict__ out)
-{
-    __shared__ __attribute__((aligned(16))) unsigned long long Ls[3 * 32 * LNS_PITCH * 2];      // [plane][granule slot][row] x 16 bytes
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long long row0 = (long long)blockIdx.x * LNS_ROWS;
-    const float4 g = ld4(gamma + lane * 4), b = ld4(beta + lane * 4);
-    float4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const long long row = row0 + wave * 8 + k;
-        v[k] = ld4(x + (row < rows ? row : rows - 1) * 256 + lane * 4);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float s = v[k].x;
-        s = s + v[k].y;
-        s = s + v[k].z;
-        s = s + v[k].w;
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) s = s + __shfl_xor(s, sh, 64);
-        const float mean = s * (1.0f / 256.0f);
-        float d = v[k].x - mean;
-        float q = d * d;
-        d = v[k].y - mean;
-        q = __builtin_fmaf(d, d, q);
-        d = v[k].z - mean;
-        q = __builtin_fmaf(d, d, q);
-        d = v[k].w - mean;
-        q = __builtin_fmaf(d, d, q);
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) q = q + __shfl_xor(q, sh, 64);
-        const float var = q * (1.0f / 256.0f);
-        const float rstd = 1.0f / sqrtf(var + eps);
-        const float o0 = __builtin_fmaf((v[k].x - mean) * rstd, g.x, b.x), o1 = __builtin_fmaf((v[k].y - mean) * rstd, g.y, b.y);
-        const float o2 = __builtin_fmaf((v[k].z - mean) * rstd, g.z, b.z), o3 = __builtin_fmaf((v[k].w - mean) * rstd, g.w, b.w);
-        unsigned p1[2], p2[2], p3[2];
-        split3_pair(o0, o1, p1[0], p2[0], p3[0]);
-        split3_pair(o2, o3, p1[1], p2[1], p3[1]);
-        // lane l holds channels 4l .. 4l+3 = half (l & 1) of granule slot l >> 1
-        const int slot = ((lane >> 1) * LNS_PITCH + wave * 8 + k) * 2 + (lane & 1);
-        Ls[slot] = ((unsigned long long)p1[1] << 32) | p1[0];
-        Ls[32 * LNS_PITCH * 2 + slot] = ((unsigned long long)p2[1] << 32) | p2[0];
-        Ls[2 * 32 * LNS_PITCH * 2 + slot] = ((unsigned long long)p3[1] << 32) | p3[0];
-    }
-    __syncthreads();
-    // copy out: record (plane, granule slot gs = 2 step + granule) = 32 rows x 16 bytes, contiguous in the pack
-    const long long mb = row0 >> 7;
-    const int r128 = (int)(row0 & 127);
-    const uint4 *L4 = reinterpret_cast<const uint4 *>(Ls);
-#pragma unroll
-    for (int pass = 0; pass < 12; ++pass) {
-        const int rec = pass * 8 + (t >> 5), r = t & 31;            // 96 records, 8 per pass
-        const int plane = rec >> 5, gs = rec & 31;
-        if (row0 + r < rows)
-            out[((size_t)mb * 16 + (gs >> 1)) * GS_A_HALF + (plane * 2 + (gs & 1)) * 128 + r128 + r] = L4[(plane * 32 + gs) * LNS_PITCH + r];
-    }
-}
-
 // test hook: case n = (a[n][16], b[n][16], c[n]) on the diagonal (n % 32, n % 32) of instruction n / 32; k slot s = 8 (lane / 32) + element
 __global__ void mfma_bf16_probe_kernel(const unsigned short *__restrict__ a, const unsigned short *__restrict__ b, const float *__restrict__ c,
                                        int N, float *__restrict__ d)
@@ -560,24 +364,13 @@ struct GSVariant {
     void (*kern)(const GemmSParams);
     unsigned long long attr_devs;       // bit d: MaxDynamicSharedMemorySize set on device d
 };
-#define GS_VARIANT(ACT, NRES) { "gemm_bf16s<act=" #ACT ",nres=" #NRES ">", gemm_bf16s_kernel<0, ACT, NRES, 0>, 0ull }
-#define GP_VARIANT(ACT, NRES) { "gemm_bf16s<A=planes,act=" #ACT ",nres=" #NRES ">", gemm_bf16s_kernel<1, ACT, NRES, 0>, 0ull }
-#define GPO_VARIANT(ACT) { "gemm_bf16s<A=planes,act=" #ACT ",out=planes>", gemm_bf16s_kernel<1, ACT, 0, 1>, 0ull }
-GSVariant g_gsv[] = {
-    GS_VARIANT(0, 0), GS_VARIANT(0, 1), GS_VARIANT(0, 2), GS_VARIANT(1, 0), GS_VARIANT(1, 1), GS_VARIANT(1, 2),      // fp32 rows in, fp32 rows out
-    GP_VARIANT(0, 0), GP_VARIANT(0, 1), GP_VARIANT(0, 2), GP_VARIANT(1, 0), GP_VARIANT(1, 1), GP_VARIANT(1, 2),      // planes in, fp32 rows out
-    GPO_VARIANT(0), GPO_VARIANT(1),                                                                                  // planes in, planes out: 12 + ACT
-};
+#define GS_VARIANT(ACT, NRES) { "gemm_bf16s<act=" #ACT ",nres=" #NRES ">", gemm_bf16s_kernel<ACT, NRES>, 0ull }
+GSVariant g_gsv[] = { GS_VARIANT(0, 0), GS_VARIANT(0, 1), GS_VARIANT(0, 2), GS_VARIANT(1, 0), GS_VARIANT(1, 1), GS_VARIANT(1, 2) };
 constexpr int kNumGS = sizeof(g_gsv) / sizeof(g_gsv[0]);
 
 }  // namespace
 
 extern "C" size_t femasr_packed_weight_bf16s_bytes(int O, int I) { return (size_t)(I / 16) * ((O + 31) / 32) * 192 * sizeof(uint4); }
-extern "C" size_t femasr_packed_rows_bf16s_bytes(int64_t rows, int C)
-{
-    return rows > 0 && C > 0 && (C % 16) == 0 ? (size_t)((rows + 127) / 128) * (size_t)(C / 16) * GS_A_HALF * sizeof(uint4) : 0;
-}
-
 bool femasr_gemm_bf16s_shape_ok(const femasr_conv_args *a)
 {
     return a->ksz == 1 && a->stride == 1 && a->pad == 0 && !a->up2 && (a->Cin % 64) == 0 && a->prologue == FEMASR_PRO_NONE;
@@ -597,38 +390,6 @@ extern "C" int femasr_repack_k1_bf16s(void *stream, const float *in, int O, int 
     return FEMASR_OK;
 }
 
-extern "C" int femasr_pack_rows_bf16s(void *stream, const float *x, int64_t rows, int C, void *out)
-{
-    FEMASR_REQUIRE(x && out && rows > 0 && C > 0 && (C % 16) == 0, "pack_rows_bf16s: needs rows > 0 and C %% 16 == 0");
-    const size_t total = (size_t)((rows + 127) / 128) * (size_t)(C / 16) * 256;
-    size_t g = (total + 255) / 256;
-    g = g > 65535 ? 65535 : g;
-    hipLaunchKernelGGL(pack_rows_bf16s_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, C, (uint4 *)out, total);
-    FEMASR_CHECK_HIP(hipGetLastError());
-    return FEMASR_OK;
-}
-
-extern "C" int femasr_unpack_rows_bf16s(void *stream, const void *in, int64_t rows, int C, float *x)
-{
-    FEMASR_REQUIRE(x && in && rows > 0 && C > 0 && (C % 16) == 0, "unpack_rows_bf16s: needs rows > 0 and C %% 16 == 0");
-    const size_t total = (size_t)((rows + 127) / 128) * (size_t)(C / 16) * 256;
-    size_t g = (total + 255) / 256;
-    g = g > 65535 ? 65535 : g;
-    hipLaunchKernelGGL(unpack_rows_bf16s_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const uint4 *)in, (long long)rows, C, x, total);
-    FEMASR_CHECK_HIP(hipGetLastError());
-    return FEMASR_OK;
-}
-
-extern "C" int femasr_layernorm_bf16s(void *stream, const float *x, int64_t rows, int C, const float *gamma, const float *beta, float eps, void *out)
-{
-    FEMASR_REQUIRE(x && gamma && beta && out && rows > 0, "layernorm_bf16s: bad args");
-    FEMASR_REQUIRE(C == 256, "layernorm_bf16s: C must be 256 (one wave per row), got %d", C);
-    hipLaunchKernelGGL(layernorm_bf16s_kernel, dim3((unsigned)((rows + LNS_ROWS - 1) / LNS_ROWS)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows,
-                       gamma, beta, eps, (uint4 *)out);
-    FEMASR_CHECK_HIP(hipGetLastError());
-    return FEMASR_OK;
-}
-
 extern "C" int femasr_debug_mfma_bf16(void *stream, const uint16_t *a, const uint16_t *b, const float *c, int n, float *d)
 {
     FEMASR_REQUIRE(a && b && c && d && n > 0, "debug_mfma_bf16: bad args");
@@ -639,22 +400,19 @@ extern "C" int femasr_debug_mfma_bf16(void *stream, const uint16_t *a, const uin
 
 int femasr_gemm_bf16s_launch(hipStream_t s, const femasr_conv_args *a, const void *w_bf16s, int *variant_out, double *flops_out)
 {
-    FEMASR_REQUIRE(a && (a->in || a->in_bf16s) && w_bf16s && femasr_gemm_bf16s_shape_ok(a), "gemm_bf16s: layer is not a 1x1 / linear layer with Cin %% 64 == 0");
-    FEMASR_REQUIRE(a->bias && (a->out || a->out_bf16s), "gemm_bf16s: bias/out must be set");
+    FEMASR_REQUIRE(a && a->in && w_bf16s && femasr_gemm_bf16s_shape_ok(a), "gemm_bf16s: layer is not a 1x1 / linear layer with Cin %% 64 == 0");
+    FEMASR_REQUIRE(a->bias && a->out, "gemm_bf16s: bias/out must be set");
     FEMASR_REQUIRE(a->act == FEMASR_ACT_NONE || a->act == FEMASR_ACT_GELU, "gemm_bf16s: bad activation %d", a->act);
     const long long M = (long long)a->B * a->H * a->W;
     FEMASR_REQUIRE(a->Ho == a->H && a->Wo == a->W, "gemm_bf16s: Ho/Wo mismatch");
     FEMASR_REQUIRE(M > 0 && M < (1ll << 31) - 256, "gemm_bf16s: bad row count");
-    const bool ain = a->in_bf16s != nullptr, outp = a->out_bf16s != nullptr;
-    FEMASR_REQUIRE(!outp || (ain && (a->Cout % 16) == 0 && !a->res1 && !a->res2), "gemm_bf16s: out_bf16s needs in_bf16s, Cout %% 16 == 0 and no residual operands");
     GemmSParams p{};
-    p.A = a->in; p.Ap = (const uint4 *)a->in_bf16s; p.W = (const uint4 *)w_bf16s; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2;
-    p.out = a->out; p.outp = (uint4 *)a->out_bf16s;
+    p.A = a->in; p.W = (const uint4 *)w_bf16s; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
     p.M = (int)M; p.N = a->Cout; p.K = a->Cin;
     p.NT32 = (p.N + 31) / 32;
     p.MB = (p.M + 127) / 128; p.NB = (p.N + 127) / 128;
     const int nres = (a->res1 ? 1 : 0) + (a->res2 ? 1 : 0), act = a->act == FEMASR_ACT_GELU ? 1 : 0;
-    const int vi = outp ? 12 + act : (ain ? 6 : 0) + 3 * act + nres;
+    const int vi = 3 * act + nres;
     GSVariant &v = g_gsv[vi];
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));

@@ -1143,7 +1143,6 @@ int femasr_conv2d(void *stream, const femasr_conv_args *a)
 {
     FEMASR_REQUIRE(!a || !a->in_add || (a->w_wino && a->up2 && !a->w_bf16x3 && !a->w_bf16s),
                    "conv2d: in_add is only taken by the x2 Winograd-type form (up2 = 1 with w_wino, no w_bf16x3 / w_bf16s)");
-    FEMASR_REQUIRE(!a || (!a->in_bf16s && !a->out_bf16s) || a->w_bf16s, "conv2d: in_bf16s / out_bf16s are taken by the w_bf16s path only");
     if (a && a->w_bf16s) {
         FEMASR_REQUIRE(femasr_gemm_bf16s_shape_ok(a), "conv2d: w_bf16s given but the layer is not a 1x1 stride-1 layer with Cin %% 64 == 0 and no prologue");
         return femasr_gemm_bf16s_launch((hipStream_t)stream, a, a->w_bf16s, nullptr, nullptr);

@@ -112,7 +112,6 @@ struct T {          // NHWC activation view
     int B = 0, H = 0, W = 0, C = 0;
     double *gn_part = nullptr;   // fused GroupNorm partial moments written by the producing bf16x3 conv (or null)
     int gn_tiles = 0;
-    void *planes = nullptr;      // instead of p: the tensor as three packed bf16 planes (femasr_pack_rows_bf16s layout; Swin tokens in linear_math 1)
     size_t numel() const { return (size_t)B * H * W * C; }
 };
 
@@ -378,23 +377,12 @@ struct Ctx {
         const float *in_add = nullptr;   // second input, added while staging: only when up2_wino_ok() said the x2 Winograd-type form will run
         bool lowp = false;       // behind the VQ lookup: may use the bf16x3 path when the handle opts in
         bool want_gn = false;    // the output feeds a GroupNorm: let a bf16x3 conv emit its partial moments
-        // linear_math 1 only (planes_ok()): the input is given as packed bf16 planes (x.p is then not read: x carries the shape) /
-        // the output is written as packed planes into the buffer the returned T carries in .planes (y.p stays null)
-        const void *in_planes = nullptr;
-        bool out_planes = false;
     };
     T conv(const T &x, const std::string &prefix, int cout, const ConvOpt &o)
     {
         const int Hv = o.up2 ? 2 * x.H : x.H, Wv = o.up2 ? 2 * x.W : x.W;
         const int Ho = (Hv + 2 * o.pad - o.ksz) / o.stride + 1, Wo = (Wv + 2 * o.pad - o.ksz) / o.stride + 1;
-        T y;
-        if (o.out_planes) {
-            y.B = x.B; y.H = Ho; y.W = Wo; y.C = cout;
-            y.planes = arena->alloc(femasr_packed_rows_bf16s_bytes((int64_t)x.B * Ho * Wo, cout));
-            if (!y.planes && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
-        } else {
-            y = alloc_t(x.B, Ho, Wo, cout);
-        }
+        T y = alloc_t(x.B, Ho, Wo, cout);
         // The args struct is populated (shapes; pointers may be null in the dry run) BEFORE the planning decisions, and the
         // same eligibility helpers decide in the dry and in the real run, so both plan identical buffers.
         femasr_conv_args a{};
@@ -403,7 +391,6 @@ struct Ctx {
         a.prologue = o.pro; a.pro_a = o.pa; a.pro_b = o.pb; a.pro_c = o.pc;
         a.act = o.act; a.res1 = o.res1; a.res2 = o.res2; a.out = y.p; a.Ho = Ho; a.Wo = Wo;
         a.in_add = o.in_add;
-        a.in_bf16s = o.in_planes; a.out_bf16s = y.planes;
         const void *split = nullptr;
         // (several codebooks: the decoder feeds the later lookups through before_quant_group[q > 0]: only the convs that follow the LAST
         // lookup may take the bf16x3 / Winograd forms - behind_every_lookup)
@@ -459,10 +446,6 @@ struct Ctx {
         if (h->linear_math == 1 && femasr_gemm_bf16s_shape_ok(&a)) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) lin3 = h->specs[it->second].lin3;
-        }
-        if ((o.in_planes || o.out_planes) && !lin3) {
-            rc = femasr_set_error(FEMASR_ERR_INVALID, "conv %s: bf16 planes were scheduled for a layer that does not run in the split arithmetic", prefix.c_str());
-            return y;
         }
         if (lin3) {
             r = femasr_gemm_bf16s_launch(s(), &a, lin3, &variant, &flops);
@@ -542,32 +525,18 @@ struct Ctx {
     T swin_block(const T &y, int B, int H, int W, const std::string &bp, int shift)
     {
         const int rows = B * H * W, C = 256;
-        // linear_math 1 (round 6): norm1 / norm2 write the three bf16 planes of their output in the packed layout the split GEMM copies
-        // straight into LDS (6 bytes per value instead of 4; the GEMM's A side does no conversion work), and fc1 hands its GELU output to fc2
-        // the same way.  The attention kernel still writes fp32 rows: proj splits them in its staging.
-        static const int planes_env = [] { const char *e = getenv("FEMASR_LINEAR_PLANES"); return e ? atoi(e) : 1; }();      // (A/B measurement of round 6: 0 off, 1 all, 2 LayerNorm outputs only)
-        const bool planes = h->linear_math == 1 && planes_env != 0;
         auto ln = [&](const T &t, const std::string &np) {       // normalised tokens, materialised once (read by DMA in the GEMM)
-            T o;
-            o.B = 1; o.H = rows; o.W = 1; o.C = C;
-            if (planes) {
-                o.planes = arena->alloc(femasr_packed_rows_bf16s_bytes(rows, C));
-                if (!o.planes && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
-            } else {
-                o.p = alloc_f(o.numel());
-            }
+            T o = alloc_t(1, rows, 1, C);
             if (rc || dry()) return o;
-            Scope sc(h, s(), dry(), SLOT_LN, 0.0, (double)t.numel() * (planes ? 10.0 : 8.0));
-            const int r = planes ? femasr_layernorm_bf16s(s(), t.p, rows, C, Wt(np + ".weight"), Wt(np + ".bias"), 1e-5f, o.planes)
-                                 : femasr_layernorm(s(), t.p, rows, C, Wt(np + ".weight"), Wt(np + ".bias"), 1e-5f, o.p);
+            Scope sc(h, s(), dry(), SLOT_LN, 0.0, (double)t.numel() * 8.0);
+            const int r = femasr_layernorm(s(), t.p, rows, C, Wt(np + ".weight"), Wt(np + ".bias"), 1e-5f, o.p);
             if (r && !rc) rc = r;
             return o;
         };
-        auto drop = [&](T &t) { if (t.planes) { release(t.planes); t.planes = nullptr; } else release(t); };
         T n1 = ln(y, bp + ".norm1");
-        ConvOpt oq; oq.ksz = 1; oq.pad = 0; oq.in_planes = n1.planes;
+        ConvOpt oq; oq.ksz = 1; oq.pad = 0;
         T qkv = conv(n1, bp + ".attn.qkv", 3 * C, oq);
-        drop(n1);
+        release(n1);
         T att = alloc_t(1, rows, 1, C);
         if (!rc && !dry()) {
             Scope sc(h, s(), dry(), SLOT_ATTN, 4.0 * (double)rows * 64.0 * C, (double)rows * C * 16.0);
@@ -579,12 +548,14 @@ struct Ctx {
         T y1 = conv(att, bp + ".attn.proj", C, op);
         release(att);
         T n2 = ln(y1, bp + ".norm2");
-        ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.act = FEMASR_ACT_GELU; o1.in_planes = n2.planes; o1.out_planes = planes && planes_env == 1;
+        // (one kernel for fc1 + GELU + fc2 + residual was built in round 4 - bit-identical, 18 % slower than the two launches,
+        // profiles/r04_mlp_fused.txt - and removed in round 6; producer-side bf16 planes for qkv / fc1 / fc2 likewise, kernels_gemm_bf16.hip)
+        ConvOpt o1; o1.ksz = 1; o1.pad = 0; o1.act = FEMASR_ACT_GELU;
         T hdn = conv(n2, bp + ".mlp.fc1", 4 * C, o1);
-        drop(n2);
-        ConvOpt o2; o2.ksz = 1; o2.pad = 0; o2.res1 = y1.p; o2.in_planes = hdn.planes;
+        release(n2);
+        ConvOpt o2; o2.ksz = 1; o2.pad = 0; o2.res1 = y1.p;
         T y2 = conv(hdn, bp + ".mlp.fc2", C, o2);
-        drop(hdn);
+        release(hdn);
         release(y1);
         return y2;
     }

@@ -59,8 +59,8 @@ typedef struct {
 } femasr_config;
 
 const char *femasr_last_error(void);
-/* 100 * major + minor.  102: femasr_conv_args ends with in_bf16s / out_bf16s; the debug hooks moved to femasr_hip_debug.h; femasr_mlp_fused and the
- * process-global femasr_debug_wino_* switches are gone (a caller built against 101 passes a shorter struct: rebuild). */
+/* 100 * major + minor.  102: the debug hooks moved to femasr_hip_debug.h; femasr_mlp_fused and the process-global femasr_debug_wino_* switches are gone;
+ * femasr_extract_tiles_u8 / femasr_paste_tiles_u8 are new (femasr_conv_args is unchanged since 101). */
 int femasr_version(void);
 
 /* ---- model handle ------------------------------------------------------------------ */
@@ -197,13 +197,6 @@ typedef struct {
                              partial products of relative size >= 2^-16 accumulated in fp32 (two accumulators), ~3x closer to the fp64
                              result than the fp32 fmaf chain and bit-identical to oracle/femasr_oracle.c orc_linear_bf16s, which restates
                              the instruction's accumulation arithmetic from hardware probes (kernels_gemm_bf16.hip).  `w` is not read. */
-    const void *in_bf16s; /* optional (struct version 102, with w_bf16s only): the INPUT as its three bf16 planes in the packed layout of
-                             femasr_pack_rows_bf16s - what femasr_layernorm_bf16s and a producing layer's out_bf16s write.  The kernel's A side is
-                             then pure LDS-DMA (no conversion work in its main loop); `in` is not read and may be NULL.  Same bits as with the
-                             fp32 input: the split is a pure function of the fp32 value. */
-    void *out_bf16s;      /* optional (struct version 102, with w_bf16s and in_bf16s only; Cout % 16 == 0, no residual operands): the OUTPUT is written as
-                             its three bf16 planes (packed layout, femasr_packed_rows_bf16s_bytes(rows, Cout) bytes) instead of fp32 rows - the
-                             next linear takes it as in_bf16s (fc1 -> fc2: network_swinir.py:25-29); `out` is not written and may be NULL. */
 } femasr_conv_args;
 int femasr_conv2d(void *stream, const femasr_conv_args *a);
 
@@ -222,10 +215,6 @@ int femasr_ln_stats(void *stream, const float *x, int64_t rows, int C, float eps
  * (network_swinir.py:243,277: norm1 / norm2 ahead of qkv / fc1). */
 int femasr_layernorm(void *stream, const float *x, int64_t rows, int C, const float *gamma, const float *beta,
                      float eps, float *y);
-/* The same LayerNorm (C = 256), written as the three bf16 planes of y in the packed layout above (femasr_packed_rows_bf16s_bytes(rows, 256)
- * bytes): norm1 / norm2 in front of qkv / fc1 when those run with in_bf16s (linear_math 1) - 6 bytes per value instead of 4, and the
- * consuming GEMM does no conversion work.  femasr_unpack_rows_bf16s of the result equals femasr_layernorm's output bit for bit. */
-int femasr_layernorm_bf16s(void *stream, const float *x, int64_t rows, int C, const float *gamma, const float *beta, float eps, void *out);
 /* 8x8 (shifted-)window multi-head attention incl. rel-pos bias and shift mask
  * (network_swinir.py:114-145, 216-237, 249-272).  qkv (B,H*W,3C) -> out (B,H*W,C), natural token order. */
 int femasr_window_attention(void *stream, const float *qkv, int B, int H, int W, int C, int heads, int shift,
@@ -305,13 +294,6 @@ int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *o
  * [Cin/16][ceil(Cout/32)][plane][lane][8 bf16] - the MFMA B fragments of one 16-channel step, 1 KiB per (column tile, plane). */
 size_t femasr_packed_weight_bf16s_bytes(int O, int I);
 int femasr_repack_k1_bf16s(void *stream, const float *w_oi, int O, int I, void *out);
-/* The same split for ACTIVATION rows (femasr_conv_args.in_bf16s / out_bf16s): fp32 (rows, C) row-major, C % 16 == 0 ->
- * [ceil(rows/128)][C/16][plane 3][granule 2][row % 128][8 bf16]: one 16-channel step of a 128-row block is 12 contiguous KiB, which
- * the GEMM copies into LDS as twelve 1-KiB LDS-DMA pieces; x = plane1 + plane2 + plane3 exactly.  Rows past `rows` in the last block
- * are zero (pack) / unspecified (a producer's output) and are never read into a stored result.  unpack is the exact inverse (tests). */
-size_t femasr_packed_rows_bf16s_bytes(int64_t rows, int C);
-int femasr_pack_rows_bf16s(void *stream, const float *x, int64_t rows, int C, void *out);
-int femasr_unpack_rows_bf16s(void *stream, const void *in, int64_t rows, int C, float *x);
 /* Arithmetic of the network's 1x1 convs / nn.Linear layers (the Swin qkv / proj / fc1 / fc2 and before_quant):
  * 1 (default, 'bf16_split'): the fp32-grade product on the bf16 matrix pipe described at femasr_conv_args.w_bf16s;
  * 0 ('fp32'): one fp32 fmaf chain per output on the fp32 MFMA (kernels_gemm.hip), bit-identical to OracleNet(linear_math='fp32'). */

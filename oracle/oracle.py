@@ -45,9 +45,8 @@ def lib():
         # against, NOT through os.environ: the environment variable would also change torch's CPU thread pool if torch initialises
         # afterwards.
         if 'OMP_NUM_THREADS' not in os.environ:
-            try:        # (under pytest-xdist the workers share the host: divide by their number)
-                workers = max(1, int(os.environ.get('PYTEST_XDIST_WORKER_COUNT', '1') or 1))
-                ctypes.CDLL('libgomp.so.1').omp_set_num_threads(max(1, (os.cpu_count() or 2) // 2 // workers))
+            try:
+                ctypes.CDLL('libgomp.so.1').omp_set_num_threads(max(1, (os.cpu_count() or 2) // 2))
             except OSError:
                 pass
         i, i64, f, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p

@@ -10,13 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    # the controlling process of an xdist run executes no test: load the native library here too, so that whoever inspects the pytest
-    # process for the in-tree .so sees it in the controller as well as in the workers
-    try:
-        from femasr_amd import _lib
-        _lib.load()
-    except Exception:
-        pass
 
 
 @pytest.fixture(scope='session')

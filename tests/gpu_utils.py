@@ -41,12 +41,9 @@ def lib_weight_layout(w_khwc):
 
 
 def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(None, None, None), act=0,
-           res1=None, res2=None, bf16x3=False, gn_part=False, wino=False, fast_act=False, in_add=None, bf16s=False,
-           planes_in=False, planes_out=False):
+           res1=None, res2=None, bf16x3=False, gn_part=False, wino=False, fast_act=False, in_add=None, bf16s=False):
     """x NHWC numpy -> numpy, through femasr_conv2d (weights given in the oracle's [kh][kw][Cin][Cout] layout).
-    bf16s: the 1x1 / Linear layer on the bf16 matrix pipe (femasr_conv_args.w_bf16s, three-term split); planes_in: the input handed over
-    as its three packed bf16 planes (femasr_pack_rows_bf16s -> in_bf16s, `in` NULL); planes_out: the output taken as packed planes
-    (out_bf16s, `out` NULL) and unpacked here (femasr_unpack_rows_bf16s, exact)."""
+    bf16s: the 1x1 / Linear layer on the bf16 matrix pipe (femasr_conv_args.w_bf16s, three-term split)."""
     lib = _lib.load()
     cout = np.asarray(w_khwc).shape[-1]
     wlin3 = None
@@ -99,15 +96,6 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     a.w_wino = None if wwino is None else wwino.data_ptr()
     a.fast_act = int(fast_act)      # 0 exact, 1 hardware SiLU
     a.w_bf16s = None if wlin3 is None else wlin3.data_ptr()
-    rows_in, rows_out = b * h * w, b * ho * wo
-    pin = pout = None
-    if planes_in:
-        pin = torch.empty(int(lib.femasr_packed_rows_bf16s_bytes(rows_in, cin)), dtype=torch.uint8, device='cuda')
-        _lib.check(lib.femasr_pack_rows_bf16s(None, _lib.ptr(tx), rows_in, cin, _lib.ptr(pin)))
-        a.in_, a.in_bf16s = None, pin.data_ptr()
-    if planes_out:
-        pout = torch.full((int(lib.femasr_packed_rows_bf16s_bytes(rows_out, cout)),), 0xff, dtype=torch.uint8, device='cuda')      # (NaN patterns)
-        a.out, a.out_bf16s = None, pout.data_ptr()
     tadd = None if in_add is None else dev(in_add)
     a.in_add = None if tadd is None else tadd.data_ptr()
     part = None
@@ -120,8 +108,6 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
         part = torch.full((b, tiles, 32, 2), float('nan'), dtype=torch.float64, device='cuda')
         a.gn_part = part.data_ptr()
     _lib.check(lib.femasr_conv2d(None, ctypes.byref(a)))
-    if planes_out:
-        _lib.check(lib.femasr_unpack_rows_bf16s(None, _lib.ptr(pout), rows_out, cout, _lib.ptr(out)))
     torch.cuda.synchronize()
     if gn_part:
         return out.cpu().numpy(), part

@@ -191,7 +191,7 @@ def _net_cases(seed, n):
     return out
 
 
-@pytest.mark.parametrize('c', _net_cases(4242, 8 * _MULT), ids=lambda c: 'n%(id)d_%(cfg)s_%(b)dx%(h)dx%(w)d_s%(streams)d_%(math)s' % c)
+@pytest.mark.parametrize('c', _net_cases(4242, 6 * _MULT), ids=lambda c: 'n%(id)d_%(cfg)s_%(b)dx%(h)dx%(w)d_s%(streams)d_%(math)s' % c)
 def test_fuzz_network_vs_oracle(cuda_device, c):
     """Whole network at random small sizes / batch / stream count / math mode: fp32_strict bit-exact against the oracle
     (output and VQ indices); the default fp32 mode (hardware exp2 / rcp SiLU in the Winograd convs) identical indices and
@@ -242,10 +242,10 @@ def test_fuzz_gn_and_ln_moments_bit_exact(cuda_device, seed):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
-@pytest.mark.parametrize('seed', range(4 * _MULT))
+@pytest.mark.parametrize('seed', range(2 * _MULT))       # (round 6: 2 cases instead of 4 by default - each costs ~25 s of CPU oracle; FEMASR_FUZZ_MULT widens)
 def test_fuzz_test_tile_vs_oracle(cuda_device, seed):
     """`test_tile` with random tile size / pad (ragged border tiles, several shape classes) == the oracle's test_tile.  The first case of
-    every four runs the product default arithmetic of the linears, the others the fp32 chain on both sides (this test is about the tiling
+    every two runs the product default arithmetic of the linears, the other the fp32 chain on both sides (this test is about the tiling
     logic; the restated matrix-instruction arithmetic costs ~30x on the CPU side and has its own tests)."""
     import gpu_utils as G
     import torch
@@ -253,7 +253,7 @@ def test_fuzz_test_tile_vs_oracle(cuda_device, seed):
     rng = np.random.RandomState(1500 + seed)
     w = synth_weights('x4', 31 + seed, 'trained')
     net = G.build_net('x4', w, cuda_device)
-    lm = 'bf16_split' if seed % 4 == 0 else 'fp32'
+    lm = 'bf16_split' if seed % 2 == 0 else 'fp32'
     net.linear_math = lm
     net.num_streams = int(rng.choice([1, 2]))
     ts, pad = int(rng.choice([24, 32, 40, 48])), int(rng.choice([0, 4, 8]))

@@ -163,13 +163,16 @@ def test_counted_waits_of_the_split_gemm():
     sys.path.insert(0, csrc)
     import kernel_meta
     assert kernel_meta.check_counted_waits() == []
-    keep = dict(kernel_meta.COUNTED[1])
+    keep = dict(kernel_meta.COUNTED)
     try:
-        kernel_meta.COUNTED[1] = dict(keep, global_load_lds_dwordx4=5)
+        kernel_meta.COUNTED = dict(keep, global_load_lds_dwordx4=11)
         probs = kernel_meta.check_counted_waits()
-        assert len(probs) == 8 and all('VMEM instructions in the MFMA loop' in p for p in probs), probs
+        assert len(probs) == 6 and all('VMEM instructions in the MFMA loop' in p for p in probs), probs
+        kernel_meta.COUNTED = dict(keep, vmcnt={14: 2, 10: 3, 9: 1})
+        probs = kernel_meta.check_counted_waits()
+        assert len(probs) == 7 and 'update both together' in probs[0], probs
     finally:
-        kernel_meta.COUNTED[1] = keep
+        kernel_meta.COUNTED = keep
 
 
 def test_default_schedule_kernels_use_no_scratch():
