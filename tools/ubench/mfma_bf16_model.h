@@ -1,3 +1,6 @@
+// NOTE (round 6): this stand-alone copy covers NORMAL-range operands only (what the stand-alone GEMM driver feeds it).  The authoritative
+// restatement - bf16 / fp32 subnormals, results below the normal range, signed zeros, Inf / NaN, overflow - is orc_dot8_core in
+// oracle/femasr_oracle.c, pinned on tests/golden/mfma_bf16_probe.npz and tests/golden/mfma_bf16_corners.npz.
 // mfma_bf16_model.h - host restatement of what one 8-product group of v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16 computes on gfx950
 // (fitted to tools/ubench/mfma_bf16_probe.hip's dump by fit_bf16_model.py: 0 of 95 232 cases differ; check_bf16_model.cpp re-checks THIS code).
 #pragma once
