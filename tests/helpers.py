@@ -115,8 +115,8 @@ def check_indices_near_tie(idx, g, max_ulp=None):
     """VQ index parity against the reference with the documented near-tie allowance (hard part 1):
     a mismatch is accepted only if the REFERENCE's own distances of its winner and its runner-up are
     within `max_ulp` ulp AND the candidate picked that runner-up.  Returns (n_mismatch, n_accepted)."""
-    from oracle.near_tie import NEAR_TIE_ULP
-    max_ulp = NEAR_TIE_ULP if max_ulp is None else max_ulp
+    max_ulp = 2.0 if max_ulp is None else max_ulp      # (single-call goldens: callers assert n_mismatch == 0, the allowance only labels; the tiled /
+                                                       # testset fixtures pass oracle.near_tie.NEAR_TIE_ULP = 4 themselves; ADVICE r5)
     ref = g['vq_indices'].reshape(-1)
     idx = np.asarray(idx).reshape(-1)
     assert idx.shape == ref.shape

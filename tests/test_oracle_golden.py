@@ -60,8 +60,10 @@ def test_decode_indices_matches_reference():
 
 
 def test_full_tile_128_matches_reference():
-    """One full-size x4 tile (128x128 -> 512x512, 964 GFLOP): ~12 s of CPU."""
-    g, net, x = _run('x4_tile128_trained', 'fp32')        # (the GPU suite checks the default arithmetic on this tile: tests/test_gpu_network.py)
+    """One full-size x4 tile (128x128 -> 512x512, 964 GFLOP) in the PRODUCT DEFAULT arithmetic (linear_math 'bf16_split': the restated
+    matrix instruction; ~2 min on 8 cores) - ADVICE r5: at least one large golden keeps pinning the shipped default on the CPU, not
+    only on a GPU box.  0 index mismatches, no near-tie allowance."""
+    g, net, x = _run('x4_tile128_trained', 'bf16_split')
     y, idx = net.test(x, return_indices=True)
     st = int(g['out_stride'])
     assert np.abs(y[:, :, ::st, ::st] - g['output']).max() < TOL

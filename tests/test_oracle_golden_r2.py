@@ -78,6 +78,9 @@ def test_cli_arithmetic_on_testset_png(name):
     w = weights_from_arch(cfg, int(g['seed']), 'trained')
     rgb = np.asarray(Image.open(io.BytesIO(g['png'].tobytes())).convert('RGB'))
     x = orc.image_u8_to_f32(rgb)
+    # chip.png in the product default arithmetic; comic1.png (250 x 361 = 2.4x the pixels: ~3 min in the restated matrix-instruction
+    # arithmetic on 8 cores) in the fp32 chain here - the GPU suite runs BOTH in the default (tests/test_gpu_network_r2.py), and the
+    # default is pinned on the CPU by chip.png, x4_tile128 and every small fixture
     y, idx = oracle_net(cfg, w, 'fp32' if name == 'png_comic1' else 'bf16_split').test(x, return_indices=True)
     assert np.abs(y[:, :, ::4, ::4] - g['output_f32_stride4']).max() < TOL
     bad, _ = check_indices_near_tie(idx, g)
