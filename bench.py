@@ -618,7 +618,7 @@ def main():
                     return 4.0 / 9.0             # nearest-x2 + 3x3 conv as four 2x2-tap phase filters
                 if name.startswith('conv3x3_halo_bf16x3'):
                     return 3.0                   # three bf16 MFMA passes per multiply-add
-                if name.startswith('gemm_bf16s'):
+                if name.startswith('gemm_bf16s') or name.startswith('conv3x3_bf16s'):
                     # six bf16 MFMA passes per multiply-add of the definition, on a pipe 15.9x as fast: in units of the fp32-MFMA peak (so that the
                     # sums below stay physical pipe-time fractions <= 1)
                     return 6.0 * PEAK_FP32_MFMA_TFLOPS / PEAK_BF16_MFMA_TFLOPS
@@ -691,7 +691,7 @@ def main():
             sclk = (power or {}).get('sclk_mhz_median')
 
             def bf16_pipe(k, v):
-                if not k.startswith('gemm_bf16s') or v[2] <= 0:
+                if not (k.startswith('gemm_bf16s') or k.startswith('conv3x3_bf16s')) or v[2] <= 0:
                     return {}
                 pf = 6.0 * v[2] / (v[0] * 1e-3) / 1e12
                 return {'bf16_pipe_tflops': round(pf, 1), 'bf16_pipe_frac_at_2.4GHz': round(pf / PEAK_BF16_MFMA_TFLOPS, 4),

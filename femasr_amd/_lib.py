@@ -109,6 +109,9 @@ SIGNATURES = {
     'femasr_set_linear_math': (c_int, [vp, c_int]),
     'femasr_packed_weight_bf16s_bytes': (szt, [c_int, c_int]),
     'femasr_repack_k1_bf16s': (c_int, [vp, vp, c_int, c_int, vp]),
+    'femasr_packed_weight_conv3x3_bf16s_bytes': (szt, [c_int, c_int]),
+    'femasr_repack_oihw_bf16s': (c_int, [vp, vp, c_int, c_int, vp]),
+    'femasr_gn_silu_apply': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp]),
     'femasr_image_u8_to_f32': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_image_f32_to_u8': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'femasr_clock_probe': (c_int, [vp, c_int, vp]),

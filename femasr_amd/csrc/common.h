@@ -53,6 +53,7 @@ int femasr_repack_k1(hipStream_t s, const float *in, int O, int I, float *out);
 
 // 1x1 convs / nn.Linear as an fp32-grade product on the bf16 matrix pipe (kernels_gemm_bf16.hip)
 bool femasr_gemm_bf16s_shape_ok(const femasr_conv_args *a);
+bool femasr_conv3x3_bf16s_shape_ok(const femasr_conv_args *a);      // the 3x3 stride-1 pad-1 form (K = 9 Cin) of the same kernel
 int femasr_gemm_bf16s_launch(hipStream_t s, const femasr_conv_args *a, const void *w_bf16s, int *variant_out, double *flops_out);
 int femasr_gemm_bf16s_variant_count();
 const char *femasr_gemm_bf16s_variant_name(int v);

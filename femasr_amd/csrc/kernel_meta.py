@@ -123,7 +123,7 @@ VMEM_PREFIXES = ('global_', 'buffer_', 'scratch_', 'flat_', 'tbuffer_')
 # fetches, waits 14 / 10 / 10 per chunk.  The numbers are the source's (`s_waitcnt vmcnt(N)` in the inline asm); check_counted_waits() also
 # reads them there.
 COUNTED = {'loops': 1, 'global_load_lds_dwordx4': 12, 'global_load_dwordx4': 8, 'vmcnt': {14: 2, 10: 4}}
-N_GEMM_BF16S = 6                # instantiations (activation x residual operands)
+N_GEMM_BF16S = 9                # instantiations (activation x residual operands, + the 3x3 conv form x residual operands)
 
 
 def disassemble(obj_path):

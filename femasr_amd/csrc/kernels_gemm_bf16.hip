@@ -56,7 +56,10 @@ struct GemmSParams {
     const float *bias, *res1, *res2;
     float *out;
     int M, N, K, MB, NB, NT32;
+    int imH, imW, Cin, tapmul;   // CONV form: image size, channels per tap, ceil(2^20 / (Cin / 32)) (chunk -> tap without a division)
 };
+
+__device__ float g_gs_zero_page[64];      // CONV form: what a tap outside the image reads (zero-initialised device memory)
 
 constexpr int GS_A_HALF = 3 * 2 * 128;                // uint4 per step: [plane][granule][row]
 constexpr int GS_A_BYTES = 2 * GS_A_HALF * 16;        // two steps
@@ -103,7 +106,13 @@ __device__ __forceinline__ void dma3(const uint4 *w, unsigned d0)
                  : "=&s"(m0_keep) : "s"(d0), "s"(d0 + 1024u), "s"(d0 + 2048u), "v"(w), "v"(w + 64), "v"(w + 128) : "memory");
 }
 
-template <int ACT, int NRES>
+// CONV = 1 (round 6): the same kernel as the implicit GEMM of a 3x3 stride-1 pad-1 conv (the convs in FRONT of the codebook lookup:
+// fema_utils.py:75,78 in the encoder's ResBlocks, network_swinir.py:465 behind every RSTB): row = output pixel (NHWC raster order),
+// K = 9 Cin with k = (3 ky + kx) Cin + c - a 32-channel chunk of the main loop is a chunk of ONE tap, read from the neighbouring
+// pixel's row, or from a page of zeros where the tap lies outside the image (the load is issued either way: the wait counts stay
+// static).  Everything else - the split, the six products, the epilogue - is the linear layer's; oracle: conv3x3_bf16s (im2col +
+// orc_linear_bf16s).
+template <int ACT, int NRES, int CONV>
 __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -170,13 +179,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
         const int g2 = t & 1, srow = t >> 1;
         int grow = m0 + srow;
         grow = grow < p.M ? grow : p.M - 1;                     // tail rows: clamp (computed, never stored)
-        const float *srcA = p.A + (size_t)grow * p.K + 8 * g2;
+        const float *srcA = p.A + (size_t)grow * (CONV ? p.Cin : p.K) + 8 * g2;
+        unsigned tapmask = 0;                                   // CONV: bit (3 ky + kx) = that neighbour of this thread's pixel lies inside the image
+        if (CONV) {
+            const int px = grow % p.imW, py = (grow / p.imW) % p.imH;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int yy = py + tp / 3 - 1, xx = px + tp % 3 - 1;
+                tapmask |= (yy >= 0 && yy < p.imH && xx >= 0 && xx < p.imW ? 1u : 0u) << tp;
+            }
+        }
+        const int cpc = p.Cin >> 5;                             // CONV: 32-channel chunks per tap
         const int dstA = g2 * 128 + ((srow + 4 * g2) & 127);    // uint4 index inside a plane of a half (plane stride 256); row rotated by 4 x granule:
                                                                 // the 8-lane store groups and the 16-lane read groups are both conflict-free
         f32x4_t ar[2][4] = {};          // [set = chunk parity][item 0: two float4, item 1: two float4]
         const int nch = p.K >> 5;
         auto loadA = [&](int c, f32x4_t (&r)[4]) {              // (inline asm: every wait on these registers is explicit)
-            const float *q = srcA + (c < nch ? c : nch - 1) * 32;
+            const int cl = c < nch ? c : nch - 1;
+            const float *q;
+            if (CONV) {
+                const int tap = (cl * p.tapmul) >> 20, cc = cl - tap * cpc;           // (uniform)
+                const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+                const int off = ((ky - 1) * p.imW + (kx - 1)) * p.Cin + cc * 32;
+                q = ((tapmask >> tap) & 1u) ? srcA + off : g_gs_zero_page + 8 * g2;
+            } else {
+                q = srcA + cl * 32;
+            }
             asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
                          "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:80"
                          : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(q) : "memory");
@@ -341,6 +369,29 @@ __global__ void repack_k1_bf16s_kernel(const float *__restrict__ in, int O, int 
     }
 }
 
+// the same pack for a 3x3 conv weight (O, I, 3, 3): K = 9 I with k = (3 ky + kx) I + c
+__global__ void repack_oihw_bf16s_kernel(const float *__restrict__ in, int O, int I, uint4 *__restrict__ out, size_t total)
+{
+    const int NT32 = (O + 31) / 32;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const size_t rest = i >> 6;
+        const int nt = (int)(rest % NT32), st = (int)(rest / NT32);
+        const int n = 32 * nt + (lane & 31), k0 = 16 * st + 8 * (lane >> 5);
+        const int tap = k0 / I, c0 = k0 - tap * I;                  // (8 consecutive channels of one tap: I % 16 == 0)
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (n < O)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = in[((size_t)n * I + c0 + j) * 9 + tap];
+        uint4 q1, q2, q3;
+        split3_x8(f32x4_t{v[0], v[1], v[2], v[3]}, f32x4_t{v[4], v[5], v[6], v[7]}, q1, q2, q3);
+        uint4 *o = out + ((size_t)st * NT32 + nt) * 192 + lane;
+        o[0] = q1;
+        o[64] = q2;
+        o[128] = q3;
+    }
+}
+
 // test hook: case n = (a[n][16], b[n][16], c[n]) on the diagonal (n % 32, n % 32) of instruction n / 32; k slot s = 8 (lane / 32) + element
 __global__ void mfma_bf16_probe_kernel(const unsigned short *__restrict__ a, const unsigned short *__restrict__ b, const float *__restrict__ c,
                                        int N, float *__restrict__ d)
@@ -364,8 +415,10 @@ struct GSVariant {
     void (*kern)(const GemmSParams);
     unsigned long long attr_devs;       // bit d: MaxDynamicSharedMemorySize set on device d
 };
-#define GS_VARIANT(ACT, NRES) { "gemm_bf16s<act=" #ACT ",nres=" #NRES ">", gemm_bf16s_kernel<ACT, NRES>, 0ull }
-GSVariant g_gsv[] = { GS_VARIANT(0, 0), GS_VARIANT(0, 1), GS_VARIANT(0, 2), GS_VARIANT(1, 0), GS_VARIANT(1, 1), GS_VARIANT(1, 2) };
+#define GS_VARIANT(ACT, NRES) { "gemm_bf16s<act=" #ACT ",nres=" #NRES ">", gemm_bf16s_kernel<ACT, NRES, 0>, 0ull }
+#define GC_VARIANT(NRES) { "conv3x3_bf16s<128px x128,9Cin split GEMM,nres=" #NRES ">", gemm_bf16s_kernel<0, NRES, 1>, 0ull }
+GSVariant g_gsv[] = { GS_VARIANT(0, 0), GS_VARIANT(0, 1), GS_VARIANT(0, 2), GS_VARIANT(1, 0), GS_VARIANT(1, 1), GS_VARIANT(1, 2),
+                      GC_VARIANT(0), GC_VARIANT(1), GC_VARIANT(2) };      // 6 + residual operands: the 3x3 conv form
 constexpr int kNumGS = sizeof(g_gsv) / sizeof(g_gsv[0]);
 
 }  // namespace
@@ -373,7 +426,14 @@ constexpr int kNumGS = sizeof(g_gsv) / sizeof(g_gsv[0]);
 extern "C" size_t femasr_packed_weight_bf16s_bytes(int O, int I) { return (size_t)(I / 16) * ((O + 31) / 32) * 192 * sizeof(uint4); }
 bool femasr_gemm_bf16s_shape_ok(const femasr_conv_args *a)
 {
-    return a->ksz == 1 && a->stride == 1 && a->pad == 0 && !a->up2 && (a->Cin % 64) == 0 && a->prologue == FEMASR_PRO_NONE;
+    if (a->stride != 1 || a->up2 || (a->Cin % 64) != 0 || a->prologue != FEMASR_PRO_NONE) return false;
+    return (a->ksz == 1 && a->pad == 0) || femasr_conv3x3_bf16s_shape_ok(a);
+}
+// the 3x3 form: stride 1, pad 1, no activation; the GroupNorm + SiLU of a ResBlock conv is applied by femasr_gn_silu_apply in front of it
+bool femasr_conv3x3_bf16s_shape_ok(const femasr_conv_args *a)
+{
+    return a->ksz == 3 && a->stride == 1 && a->pad == 1 && !a->up2 && (a->Cin % 64) == 0 && a->Cin <= 1024 && a->prologue == FEMASR_PRO_NONE &&
+           a->act == FEMASR_ACT_NONE && (long long)a->B * a->H * a->W * a->Cin < (1ll << 31);
 }
 int femasr_gemm_bf16s_variant_count() { return kNumGS; }
 const char *femasr_gemm_bf16s_variant_name(int v) { return (v >= 0 && v < kNumGS) ? g_gsv[v].name : "?"; }
@@ -390,6 +450,18 @@ extern "C" int femasr_repack_k1_bf16s(void *stream, const float *in, int O, int 
     return FEMASR_OK;
 }
 
+extern "C" size_t femasr_packed_weight_conv3x3_bf16s_bytes(int O, int I) { return femasr_packed_weight_bf16s_bytes(O, 9 * I); }
+extern "C" int femasr_repack_oihw_bf16s(void *stream, const float *in, int O, int I, void *out)
+{
+    FEMASR_REQUIRE(in && out && O > 0 && I > 0 && (I % 64) == 0, "repack_oihw_bf16s: needs a 3x3 OIHW weight with I %% 64 == 0");
+    const size_t total = (size_t)(9 * I / 16) * ((O + 31) / 32) * 64;
+    size_t g = (total + 255) / 256;
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    hipLaunchKernelGGL(repack_oihw_bf16s_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, in, O, I, (uint4 *)out, total);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
 extern "C" int femasr_debug_mfma_bf16(void *stream, const uint16_t *a, const uint16_t *b, const float *c, int n, float *d)
 {
     FEMASR_REQUIRE(a && b && c && d && n > 0, "debug_mfma_bf16: bad args");
@@ -400,7 +472,7 @@ extern "C" int femasr_debug_mfma_bf16(void *stream, const uint16_t *a, const uin
 
 int femasr_gemm_bf16s_launch(hipStream_t s, const femasr_conv_args *a, const void *w_bf16s, int *variant_out, double *flops_out)
 {
-    FEMASR_REQUIRE(a && a->in && w_bf16s && femasr_gemm_bf16s_shape_ok(a), "gemm_bf16s: layer is not a 1x1 / linear layer with Cin %% 64 == 0");
+    FEMASR_REQUIRE(a && a->in && w_bf16s && femasr_gemm_bf16s_shape_ok(a), "gemm_bf16s: layer is neither a 1x1 / linear layer nor a 3x3 stride-1 pad-1 conv with Cin %% 64 == 0");
     FEMASR_REQUIRE(a->bias && a->out, "gemm_bf16s: bias/out must be set");
     FEMASR_REQUIRE(a->act == FEMASR_ACT_NONE || a->act == FEMASR_ACT_GELU, "gemm_bf16s: bad activation %d", a->act);
     const long long M = (long long)a->B * a->H * a->W;
@@ -408,11 +480,13 @@ int femasr_gemm_bf16s_launch(hipStream_t s, const femasr_conv_args *a, const voi
     FEMASR_REQUIRE(M > 0 && M < (1ll << 31) - 256, "gemm_bf16s: bad row count");
     GemmSParams p{};
     p.A = a->in; p.W = (const uint4 *)w_bf16s; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
-    p.M = (int)M; p.N = a->Cout; p.K = a->Cin;
+    const bool conv = a->ksz == 3;
+    p.M = (int)M; p.N = a->Cout; p.K = conv ? 9 * a->Cin : a->Cin;
+    p.imH = a->H; p.imW = a->W; p.Cin = a->Cin; p.tapmul = ((1 << 20) + (a->Cin >> 5) - 1) / (a->Cin >> 5);
     p.NT32 = (p.N + 31) / 32;
     p.MB = (p.M + 127) / 128; p.NB = (p.N + 127) / 128;
     const int nres = (a->res1 ? 1 : 0) + (a->res2 ? 1 : 0), act = a->act == FEMASR_ACT_GELU ? 1 : 0;
-    const int vi = 3 * act + nres;
+    const int vi = conv ? 6 + nres : 3 * act + nres;
     GSVariant &v = g_gsv[vi];
     int dev = 0;
     FEMASR_CHECK_HIP(hipGetDevice(&dev));
@@ -423,6 +497,6 @@ int femasr_gemm_bf16s_launch(hipStream_t s, const femasr_conv_args *a, const voi
     hipLaunchKernelGGL(v.kern, dim3((unsigned)(p.MB * p.NB)), dim3(256), (size_t)GS_LDS_BYTES, s, p);
     FEMASR_CHECK_HIP(hipGetLastError());
     if (variant_out) *variant_out = vi;
-    if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)a->Cin;
+    if (flops_out) *flops_out = 2.0 * (double)M * (double)a->Cout * (double)p.K;
     return FEMASR_OK;
 }

@@ -268,6 +268,26 @@ __global__ __launch_bounds__(64) void gn_finalize_partials_kernel(const double *
     }
 }
 
+// y = silu(fmaf(x, a[n][c], b[n][c])): GroupNorm-apply + SiLU (fema_utils.py:22,54-55,73-74,76-77) as a pass of its own - the arithmetic of the
+// conv kernels' GN+SiLU prologue (det_silu: the IEEE-exact form), for convs that take their input without a prologue (round 6: the 3x3
+// convs in front of the codebook lookup run as the split-bf16 GEMM, kernels_gemm_bf16.hip).  Thread = one float4 of channels.
+__global__ void gn_silu_apply_kernel(const float *__restrict__ x, int C, long long hw, const float *__restrict__ a, const float *__restrict__ b,
+                                     float *__restrict__ y, size_t total4)
+{
+    const int c4n = C >> 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const size_t n = (i / c4n) / (size_t)hw;
+        const float4 v = ld4(x + 4 * i), ga = ld4(a + n * C + 4 * c4), gb = ld4(b + n * C + 4 * c4);
+        float4 o;
+        o.x = det_silu(__builtin_fmaf(v.x, ga.x, gb.x));
+        o.y = det_silu(__builtin_fmaf(v.y, ga.y, gb.y));
+        o.z = det_silu(__builtin_fmaf(v.z, ga.z, gb.z));
+        o.w = det_silu(__builtin_fmaf(v.w, ga.w, gb.w));
+        *reinterpret_cast<float4 *>(y + 4 * i) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // LayerNorm moments (network_swinir.py:199,205): one wave per row of C = 64*PER floats
 // ------------------------------------------------------------------------------------------
@@ -932,6 +952,15 @@ int femasr_gn_coeffs_from_partials(void *stream, const double *part, int B, int 
     FEMASR_REQUIRE(C / G <= 64, "gn_coeffs_from_partials: at most 64 channels per group");
     hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3((unsigned)(B * G)), dim3(64), 0, (hipStream_t)stream, part, tiles, H, W, C,
                        G, gamma, beta, eps, a, b);
+    FEMASR_CHECK_HIP(hipGetLastError());
+    return FEMASR_OK;
+}
+
+int femasr_gn_silu_apply(void *stream, const float *x, int B, int H, int W, int C, const float *a, const float *b, float *y)
+{
+    FEMASR_REQUIRE(x && a && b && y && B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "gn_silu_apply: bad args (C %% 4 == 0)");
+    const size_t total4 = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(gn_silu_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, C, (long long)H * W, a, b, y, total4);
     FEMASR_CHECK_HIP(hipGetLastError());
     return FEMASR_OK;
 }

@@ -406,7 +406,20 @@ struct Ctx {
         const bool wino_on = !lowp_on && behind && (h->decoder_math == 0 || h->decoder_math == 3) &&
                              (o.up2 ? femasr_conv_wino_up2_shape_ok_lim(&a, h->wino_log2_total, h->wino_log2_image)
                                     : femasr_conv_wino_shape_ok_lim(&a, h->wino_log2_total, h->wino_log2_image));
-        const bool gn_ok = lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
+        // linear_math 1 (round 6): a 3x3 stride-1 conv in FRONT of a lookup (encoder ResBlocks, the conv behind every RSTB) runs as the
+        // split-bf16 GEMM over K = 9 Cin - the arithmetic of the linear layers (oracle: conv3x3_bf16s).  Its GroupNorm + SiLU prologue
+        // becomes a pass of its own (the GEMM takes plain rows), and it emits no GroupNorm partials: the next GroupNorm runs the
+        // stand-alone moments kernel, which gives the same coefficients bit for bit.
+        bool split3 = false;
+        {
+            femasr_conv_args q = a;
+            q.prologue = FEMASR_PRO_NONE;
+            split3 = h->linear_math == 1 && !behind && o.ksz == 3 && !lowp_on && !wino_on && !o.in_add &&
+                     (o.pro == FEMASR_PRO_NONE || o.pro == FEMASR_PRO_GN_SILU) && femasr_conv3x3_bf16s_shape_ok(&q);
+        }
+        float *act_tmp = nullptr;
+        if (split3 && o.pro == FEMASR_PRO_GN_SILU) act_tmp = alloc_f(x.numel());
+        const bool gn_ok = split3 ? false : lowp_on ? (cout % 32 == 0 && cout / 32 <= 8 && ((cout / 32) & (cout / 32 - 1)) == 0)
                                    : (femasr_conv_halo_eligible(&a) && femasr_gn_fusable(cout));
         if (o.want_gn && gn_ok) {
             // exact x2 convs (phase filters) emit one partial per half-resolution tile and phase
@@ -416,14 +429,21 @@ struct Ctx {
             y.gn_part = (double *)arena->alloc((size_t)x.B * y.gn_tiles * 32 * 2 * sizeof(double));
             if (!y.gn_part && !rc) rc = femasr_set_error(FEMASR_ERR_WORKSPACE, "workspace too small");
         }
-        if (rc || dry()) return y;
+        if (rc || dry()) { release(act_tmp); return y; }
         a.w = Wt(prefix + ".weight"); a.bias = Wt(prefix + ".bias");
         a.gn_part = y.gn_part;
         if (o.up2) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) a.w_up2 = h->specs[it->second].up2w;
         }
-        if (rc) return y;
+        if (rc) { release(act_tmp); return y; }
+        if (split3 && act_tmp) {       // GroupNorm-apply + SiLU as its own pass (exact SiLU: these convs feed the lookup)
+            Scope sa(h, s(), dry(), SLOT_GN, 0.0, (double)x.numel() * 8.0);
+            const int ra = femasr_gn_silu_apply(s(), x.p, x.B, x.H, x.W, x.C, o.pa, o.pb, act_tmp);
+            if (ra && !rc) rc = ra;
+            a.in = act_tmp;
+            a.prologue = FEMASR_PRO_NONE; a.pro_a = nullptr; a.pro_b = nullptr;
+        }
         Scope sc(h, s(), dry(), 0, 0.0, 0.0);
         int variant = 0; double flops = 0;
         int r;
@@ -443,10 +463,16 @@ struct Ctx {
             return y;
         }
         const void *lin3 = nullptr;
-        if (h->linear_math == 1 && femasr_gemm_bf16s_shape_ok(&a)) {
+        if (h->linear_math == 1 && (split3 || (o.ksz == 1 && femasr_gemm_bf16s_shape_ok(&a)))) {
             auto it = h->index.find(prefix + ".weight");
             if (it != h->index.end()) lin3 = h->specs[it->second].lin3;
         }
+        if (split3 && !lin3) {
+            rc = femasr_set_error(FEMASR_ERR_WEIGHT, "conv %s: planned as the split-bf16 GEMM but its weight planes were not packed", prefix.c_str());
+            release(act_tmp);
+            return y;
+        }
+
         if (lin3) {
             r = femasr_gemm_bf16s_launch(s(), &a, lin3, &variant, &flops);
             variant += femasr_conv_variant_count() + femasr_conv_bf16x3_variant_count() + femasr_conv_wino_variant_count() + 1;
@@ -473,6 +499,7 @@ struct Ctx {
         sc.set_bytes(4.0 * ((double)x.numel() * (o.in_add ? 2 : 1) + (double)y.numel() * (1 + (o.res1 ? 1 : 0) + (o.res2 ? 1 : 0)) +
                             (double)cout * x.C * o.ksz * o.ksz + cout));
         if (r && !rc) rc = r;
+        release(act_tmp);
         return y;
     }
 
@@ -953,6 +980,13 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
         // 1x1 convs / nn.Linear: the three bf16 planes for the fp32-grade product on the bf16 matrix pipe (kernels_gemm_bf16.hip)
         if (!w.lin3) FEMASR_CHECK_HIP(hipMalloc(&w.lin3, femasr_packed_weight_bf16s_bytes((int)w.shape[0], (int)w.shape[1])));
         rc = femasr_repack_k1_bf16s(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.lin3);
+        if (rc) return rc;
+    }
+    if (w.kind == W_CONV && !dec_side && !w.up2 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 64) == 0) {
+        // a 3x3 conv in FRONT of a codebook lookup: the planes of its (9 Cin x Cout) implicit-GEMM matrix (round 6: linear_math 1 runs it as
+        // the split-bf16 GEMM; whether it is a stride-1 conv is decided where it is launched - a stride-2 conv keeps the fp32 form)
+        if (!w.lin3) FEMASR_CHECK_HIP(hipMalloc(&w.lin3, femasr_packed_weight_conv3x3_bf16s_bytes((int)w.shape[0], (int)w.shape[1])));
+        rc = femasr_repack_oihw_bf16s(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.lin3);
         if (rc) return rc;
     }
     if (w.kind == W_CONV && w.up2 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 32) == 0) {

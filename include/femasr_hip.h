@@ -192,7 +192,8 @@ typedef struct {
                              FeMaSRNet's decoder adds the encoder's skip feature to a stage's input (`x = x + enc_feats[i]`,
                              femasr_arch.py:361-362) right in front of that stage's x2 conv, so the sum never makes a pass of its own. */
     const void *w_bf16s;  /* optional (struct version 101): femasr_repack_k1_bf16s weights.  When non-NULL the layer - a 1x1 stride-1 conv /
-                             nn.Linear with Cin % 64 == 0, no prologue (network_swinir.py:19-21,105-107,121,143; femasr_arch.py:298) - runs on
+                             nn.Linear with Cin % 64 == 0, no prologue (network_swinir.py:19-21,105-107,121,143; femasr_arch.py:298), or (round 6, weights from
+                             femasr_repack_oihw_bf16s) a 3x3 stride-1 pad-1 conv with Cin % 64 == 0, no prologue, no activation - runs on
                              the bf16 matrix pipe as an fp32-GRADE product: both operands split exactly into three bf16 terms, the six
                              partial products of relative size >= 2^-16 accumulated in fp32 (two accumulators), ~3x closer to the fp64
                              result than the fp32 fmaf chain and bit-identical to oracle/femasr_oracle.c orc_linear_bf16s, which restates
@@ -209,6 +210,10 @@ int femasr_gn_coeffs(void *stream, const float *x, int B, int H, int W, int C, i
  * (tiles = ceil(H/8)*ceil(W/16) of the producing conv's output). */
 int femasr_gn_coeffs_from_partials(void *stream, const double *part, int B, int tiles, int H, int W, int C, int G,
                                    const float *gamma, const float *beta, float eps, float *a, float *b);
+/* y = silu(fmaf(x, a[n][c], b[n][c])) on an NHWC tensor: the GroupNorm-apply + SiLU of a ResBlock conv (fema_utils.py:73-74,76-77) as a
+ * pass of its own, in the arithmetic of the conv kernels' GN+SiLU prologue (IEEE-exact SiLU; oracle: orc_scale_shift_silu).  Used in
+ * front of the 3x3 convs that run as the split-bf16 GEMM (w_bf16s with ksz = 3), which take their input without a prologue. */
+int femasr_gn_silu_apply(void *stream, const float *x, int B, int H, int W, int C, const float *a, const float *b, float *y);
 /* LayerNorm(C=256) row moments -> stats[rows][2] = (mean, rstd) (network_swinir.py:199,205). */
 int femasr_ln_stats(void *stream, const float *x, int64_t rows, int C, float eps, float *stats);
 /* y = LayerNorm(x) over the last dim (C = 256): the same moments, then fmaf((x-mean)*rstd, gamma, beta)
@@ -294,6 +299,13 @@ int femasr_repack_oihw_up2(void *stream, const float *in, int O, int I, float *o
  * [Cin/16][ceil(Cout/32)][plane][lane][8 bf16] - the MFMA B fragments of one 16-channel step, 1 KiB per (column tile, plane). */
 size_t femasr_packed_weight_bf16s_bytes(int O, int I);
 int femasr_repack_k1_bf16s(void *stream, const float *w_oi, int O, int I, void *out);
+/* The same for a 3x3 conv weight (O, I, 3, 3), I % 64 == 0: the planes of the (9 I x O) matrix of the conv's implicit GEMM, k = (3 ky + kx) I + c.
+ * With such weights in w_bf16s a 3x3 stride-1 pad-1 conv (no prologue, no activation; bias and residual operands as usual) runs as the
+ * split-bf16 GEMM over K = 9 Cin: the same arithmetic as the linear layers (oracle: conv3x3_bf16s = im2col + orc_linear_bf16s).  FeMaSRNet
+ * (linear_math 'bf16_split') uses it for the 3x3 convs in FRONT of the codebook lookup - the encoder's ResBlocks (femasr_arch.py:150-164,
+ * fema_utils.py:65-84) and the conv behind every RSTB (network_swinir.py:465). */
+size_t femasr_packed_weight_conv3x3_bf16s_bytes(int O, int I);
+int femasr_repack_oihw_bf16s(void *stream, const float *w_oihw, int O, int I, void *out);
 /* Arithmetic of the network's 1x1 convs / nn.Linear layers (the Swin qkv / proj / fc1 / fc2 and before_quant):
  * 1 (default, 'bf16_split'): the fp32-grade product on the bf16 matrix pipe described at femasr_conv_args.w_bf16s;
  * 0 ('fp32'): one fp32 fmaf chain per output on the fp32 MFMA (kernels_gemm.hip), bit-identical to OracleNet(linear_math='fp32'). */

@@ -221,6 +221,33 @@ def linear_bf16s(x_rows, w_oi, bias, act=0, res1=None, res2=None, scalar=False):
     return out
 
 
+def conv3x3_split_ok(cin, ksz, stride, pad, up2):
+    """3x3 stride-1 pad-1 convs the library runs as the split-bf16 GEMM over K = 9 Cin (femasr_conv_args.w_bf16s with ksz = 3;
+    csrc/kernels_gemm_bf16.hip CONV form) - round 6: the convs that FEED the codebook lookup, in linear_math 'bf16_split'."""
+    return ksz == 3 and stride == 1 and pad == 1 and not up2 and cin % 64 == 0
+
+
+def conv3x3_bf16s(x, w_khwc, bias, res1=None, res2=None):
+    """3x3 stride-1 pad-1 conv (femasr_arch.py:150-164, fema_utils.py:75,78, network_swinir.py:465) in the split-bf16 arithmetic: the
+    implicit GEMM out[pixel][o] = sum_k A[pixel][k] W[k][o] with k = (3 ky + kx) Cin + c - tap-major, channels ascending inside a tap,
+    zeros outside the image - evaluated EXACTLY as orc_linear_bf16s evaluates a K = 9 Cin linear layer (16-deep steps, six partial
+    products, two accumulators, the instruction's restated arithmetic).  x (B,H,W,Cin) NHWC, w_khwc [3][3][Cin][Cout]."""
+    x = _c(x)
+    b, h, w, cin = x.shape
+    cout = w_khwc.shape[-1]
+    xp = np.zeros((b, h + 2, w + 2, cin), np.float32)
+    xp[:, 1:-1, 1:-1] = x
+    cols = np.empty((b, h, w, 9, cin), np.float32)
+    for ky in range(3):
+        for kx in range(3):
+            cols[:, :, :, 3 * ky + kx] = xp[:, ky:ky + h, kx:kx + w]
+    w_oi = _c(np.asarray(w_khwc, np.float32).reshape(9 * cin, cout).T)
+    rows = b * h * w
+    y = linear_bf16s(cols.reshape(rows, 9 * cin), w_oi, bias, 0,
+                     None if res1 is None else _c(res1).reshape(rows, cout), None if res2 is None else _c(res2).reshape(rows, cout))
+    return y.reshape(b, h, w, cout)
+
+
 def linear(x_tokens, w_io, bias, act=0, res=None, split=False):
     """x: (..., Cin) -> (..., Cout); w_io is [in][out].  split: the bf16-pipe arithmetic (linear_bf16s) where the shape allows."""
     shp = x_tokens.shape
@@ -336,6 +363,7 @@ class OracleNet:
         # 'fp32' (one fmaf chain per output on the fp32 MFMA: kernels_gemm.hip)
         assert linear_math in ('fp32', 'bf16_split')
         self.lin_split = linear_math == 'bf16_split'
+        self.conv_split = self.lin_split          # the 3x3 convs that feed the lookup follow the same switch (csrc/model.hip Ctx::conv)
         # the kernels' default exact-fp32 mode: 3x3 convs behind the codebook lookup of a single-codebook network run in
         # the Winograd F(4x4,3x3) form (model.hip Ctx::conv `wino`); winograd=False = decoder_math 'fp32_direct'
         self.wino = bool(winograd)
@@ -374,6 +402,9 @@ class OracleNet:
     def _conv(self, x, prefix, ksz, stride=1, pad=1, up2=False, res1=None, res2=None, dec=False):
         """dec: the conv sits behind the codebook lookup (decoder side)."""
         w, b = self._conv_w(prefix)
+        if self.conv_split and not dec and conv3x3_split_ok(x.shape[-1], ksz, stride, pad, up2):
+            # round 6: a 3x3 conv in front of the codebook lookup (encoder ResBlocks, RSTB tail convs) as the split-bf16 GEMM over K = 9 Cin
+            return conv3x3_bf16s(x, w, b, res1, res2)
         return conv2d(x, w, b, ksz, stride, pad, up2, 0, res1, res2, wino=dec and self.wino)
 
     def _wino_fused(self, c, dec, shape=None):

@@ -47,7 +47,11 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     lib = _lib.load()
     cout = np.asarray(w_khwc).shape[-1]
     wlin3 = None
-    if bf16s:
+    if bf16s and ksz == 3:       # the 3x3 conv as the split-bf16 GEMM over K = 9 Cin: planes packed on the GPU from OIHW
+        w_oihw = dev(np.ascontiguousarray(np.asarray(w_khwc).transpose(3, 2, 0, 1)))
+        wlin3 = torch.empty(int(lib.femasr_packed_weight_conv3x3_bf16s_bytes(cout, w_oihw.shape[1])), dtype=torch.uint8, device='cuda')
+        _lib.check(lib.femasr_repack_oihw_bf16s(None, _lib.ptr(w_oihw), cout, w_oihw.shape[1], _lib.ptr(wlin3)))
+    elif bf16s:
         w_oi = dev(np.ascontiguousarray(np.asarray(w_khwc).reshape(-1, cout).T))
         wlin3 = torch.empty(int(lib.femasr_packed_weight_bf16s_bytes(cout, w_oi.shape[1])), dtype=torch.uint8, device='cuda')
         _lib.check(lib.femasr_repack_k1_bf16s(None, _lib.ptr(w_oi), cout, w_oi.shape[1], _lib.ptr(wlin3)))
@@ -112,6 +116,17 @@ def conv2d(x, w_khwc, bias, ksz, stride=1, pad=0, up2=False, prologue=0, pro=(No
     if gn_part:
         return out.cpu().numpy(), part
     return out.cpu().numpy()
+
+
+def gn_silu_apply(x, a, b):
+    """silu(fmaf(x, a[n][c], b[n][c])) on an NHWC array through femasr_gn_silu_apply."""
+    lib = _lib.load()
+    bb, h, w, c = x.shape
+    tx, ta, tb = dev(x), dev(a), dev(b)
+    y = torch.full(x.shape, float('nan'), dtype=torch.float32, device='cuda')
+    _lib.check(lib.femasr_gn_silu_apply(None, _lib.ptr(tx), bb, h, w, c, _lib.ptr(ta), _lib.ptr(tb), _lib.ptr(y)))
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
 
 
 def gn_coeffs(x, gamma, beta, eps=1e-6, groups=32):

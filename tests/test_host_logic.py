@@ -167,10 +167,10 @@ def test_counted_waits_of_the_split_gemm():
     try:
         kernel_meta.COUNTED = dict(keep, global_load_lds_dwordx4=11)
         probs = kernel_meta.check_counted_waits()
-        assert len(probs) == 6 and all('VMEM instructions in the MFMA loop' in p for p in probs), probs
+        assert len(probs) == 9 and all('VMEM instructions in the MFMA loop' in p for p in probs), probs
         kernel_meta.COUNTED = dict(keep, vmcnt={14: 2, 10: 3, 9: 1})
         probs = kernel_meta.check_counted_waits()
-        assert len(probs) == 7 and 'update both together' in probs[0], probs
+        assert len(probs) == 10 and 'update both together' in probs[0], probs
     finally:
         kernel_meta.COUNTED = keep
 
