@@ -19,8 +19,9 @@ def test_full_size_units_match_reference(name):
     """~20 s of CPU each (1075 / 544 GFLOP through the C oracle)."""
     g = load_golden(name)
     cn = cfg_name_of(g)
-    # (x2: 'fp32' linears - 20 736 tokens through the restated matrix instruction would take minutes here; the GPU suite runs the default)
-    net = oracle_net(cn, synth_weights(cn, int(g['seed']), str(g['codebook'])), 'fp32' if cn != 'hq' else 'bf16_split')
+    # ('fp32' chains here - 20 736 tokens (x2) / the HQ encoder's 3x3 convs at 512^2 through the restated matrix instruction would take minutes on
+    # the CPU; the GPU suite runs both units in the product default, tests/test_gpu_network_r3.py)
+    net = oracle_net(cn, synth_weights(cn, int(g['seed']), str(g['codebook'])), 'fp32')
     x = synth.synth_input(int(g['input_seed']), tuple(g['in_shape']))
     net.probes = {}
     y, idx = net.test(x, return_indices=True) if str(g['mode']) == 'test' else net.forward(x)
