@@ -123,10 +123,9 @@ def main():
         args.gn_part = part.data_ptr(); keep.append(part)
     raw = ctypes.CDLL(_lib.SO_PATH) if os.environ.get('FEMASR_SO') else None
     tt_fn = None
-    # the 16x16-pixel x 128-channel block shape of kernels_wino_c128.hip (layers with Cout % 128 == 0 under FEMASR_WINO_C128=1)
-    c128 = a_.wino and not a_.up2 and cout % 128 == 0 and cin % 32 == 0 and os.environ.get('FEMASR_WINO_C128', '0') not in ('', '0')
+    c128 = False          # (the 16x16 x 128 block shape of round 4 was removed in round 6)
     if raw is not None and a_.wino:
-        tt_fn = getattr(raw, 'femasr_debug_wino_up2_ttbuf' if a_.up2 else ('femasr_debug_wino_c128_ttbuf' if c128 else 'femasr_debug_wino_ttbuf'), None)
+        tt_fn = getattr(raw, 'femasr_debug_wino_up2_ttbuf' if a_.up2 else 'femasr_debug_wino_ttbuf', None)
     tt = tt_fn is not None
     if tt:
         nsb = b * ((ho + 15) // 16) * ((wo + 15) // 16)

@@ -11,7 +11,6 @@ O=femasr_amd/csrc
 for tag in ${@:-tt}; do
   case $tag in tt) D="-DFEMASR_WINO_TT=1 $EXTRA_DEFS";; abl*) D="-DFEMASR_WINO_ABL=${tag#abl}";; deep*) D="-DFEMASR_WINO_DEEP=${tag#deep}";; nt*) D="-DFEMASR_WINO_NT=${tag#nt}";; *) D="$EXTRA_DEFS";; esac
   /opt/rocm/bin/hipcc $F $D -c $O/kernels_wino.hip -o tools/dbg/kernels_wino_$tag.o
-  /opt/rocm/bin/hipcc $F $D -c $O/kernels_wino_c128.hip -o tools/dbg/kernels_wino_c128_$tag.o
   /opt/rocm/bin/hipcc $F $D -c $O/kernels_wino_up2.hip -o tools/dbg/kernels_wino_up2_$tag.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/dbg/libfemasr_hip_$tag.so $O/kernels_conv.o $O/kernels_gemm.o $O/kernels_mlp.o $O/kernels_vq.o tools/dbg/kernels_wino_$tag.o tools/dbg/kernels_wino_c128_$tag.o tools/dbg/kernels_wino_up2_$tag.o $O/kernels_conv_bf16.o $O/kernels_misc.o $O/model.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/dbg/libfemasr_hip_$tag.so $O/kernels_conv.o $O/kernels_gemm.o $O/kernels_gemm_bf16.o $O/kernels_vq.o tools/dbg/kernels_wino_$tag.o tools/dbg/kernels_wino_up2_$tag.o $O/kernels_conv_bf16.o $O/kernels_misc.o $O/model.o
 done
