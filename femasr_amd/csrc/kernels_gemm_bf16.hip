@@ -56,7 +56,8 @@ struct GemmSParams {
     const float *bias, *res1, *res2;
     float *out;
     int M, N, K, MB, NB, NT32;
-    int imH, imW, Cin, tapmul;   // CONV form: image size, channels per tap, ceil(2^20 / (Cin / 32)) (chunk -> tap without a division)
+    int imH, imW, Cin, tapmul;   // CONV form: input image size, channels per tap, ceil(2^20 / (Cin / 32)) (chunk -> tap without a division)
+    int imHo, imWo, stride;      // ... output image size, stride (1 or 2)
 };
 
 __device__ float g_gs_zero_page[64];      // CONV form: what a tap outside the image reads (zero-initialised device memory)
@@ -106,8 +107,8 @@ __device__ __forceinline__ void dma3(const uint4 *w, unsigned d0)
                  : "=&s"(m0_keep) : "s"(d0), "s"(d0 + 1024u), "s"(d0 + 2048u), "v"(w), "v"(w + 64), "v"(w + 128) : "memory");
 }
 
-// CONV = 1 (round 6): the same kernel as the implicit GEMM of a 3x3 stride-1 pad-1 conv (the convs in FRONT of the codebook lookup:
-// fema_utils.py:75,78 in the encoder's ResBlocks, network_swinir.py:465 behind every RSTB): row = output pixel (NHWC raster order),
+// CONV = 1 (round 6): the same kernel as the implicit GEMM of a 3x3 pad-1 conv of stride 1 or 2 (the convs in FRONT of the codebook lookup:
+// fema_utils.py:75,78 in the encoder's ResBlocks, femasr_arch.py:159 its stride-2 stages, network_swinir.py:465 behind every RSTB): row = output pixel (NHWC raster order),
 // K = 9 Cin with k = (3 ky + kx) Cin + c - a 32-channel chunk of the main loop is a chunk of ONE tap, read from the neighbouring
 // pixel's row, or from a page of zeros where the tap lies outside the image (the load is issued either way: the wait counts stay
 // static).  Everything else - the split, the six products, the epilogue - is the linear layer's; oracle: conv3x3_bf16s (im2col +
@@ -179,10 +180,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const GemmSParams p)
         const int g2 = t & 1, srow = t >> 1;
         int grow = m0 + srow;
         grow = grow < p.M ? grow : p.M - 1;                     // tail rows: clamp (computed, never stored)
-        const float *srcA = p.A + (size_t)grow * (CONV ? p.Cin : p.K) + 8 * g2;
+        const float *srcA = p.A + (size_t)grow * p.K + 8 * g2;
         unsigned tapmask = 0;                                   // CONV: bit (3 ky + kx) = that neighbour of this thread's pixel lies inside the image
         if (CONV) {
-            const int px = grow % p.imW, py = (grow / p.imW) % p.imH;
+            // row = OUTPUT pixel (n, oy, ox); the centre tap reads input pixel (oy * stride, ox * stride)
+            const int ox = grow % p.imWo, oy = (grow / p.imWo) % p.imHo, n = grow / (p.imWo * p.imHo);
+            const int px = ox * p.stride, py = oy * p.stride;
+            srcA = p.A + (((size_t)n * p.imH + py) * p.imW + px) * p.Cin + 8 * g2;
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
                 const int yy = py + tp / 3 - 1, xx = px + tp % 3 - 1;
@@ -426,13 +430,13 @@ constexpr int kNumGS = sizeof(g_gsv) / sizeof(g_gsv[0]);
 extern "C" size_t femasr_packed_weight_bf16s_bytes(int O, int I) { return (size_t)(I / 16) * ((O + 31) / 32) * 192 * sizeof(uint4); }
 bool femasr_gemm_bf16s_shape_ok(const femasr_conv_args *a)
 {
-    if (a->stride != 1 || a->up2 || (a->Cin % 64) != 0 || a->prologue != FEMASR_PRO_NONE) return false;
-    return (a->ksz == 1 && a->pad == 0) || femasr_conv3x3_bf16s_shape_ok(a);
+    if (a->up2 || (a->Cin % 64) != 0 || a->prologue != FEMASR_PRO_NONE) return false;
+    return (a->ksz == 1 && a->pad == 0 && a->stride == 1) || femasr_conv3x3_bf16s_shape_ok(a);
 }
-// the 3x3 form: stride 1, pad 1, no activation; the GroupNorm + SiLU of a ResBlock conv is applied by femasr_gn_silu_apply in front of it
+// the 3x3 form: stride 1 or 2, pad 1, no activation; the GroupNorm + SiLU of a ResBlock conv is applied by femasr_gn_silu_apply in front of it
 bool femasr_conv3x3_bf16s_shape_ok(const femasr_conv_args *a)
 {
-    return a->ksz == 3 && a->stride == 1 && a->pad == 1 && !a->up2 && (a->Cin % 64) == 0 && a->Cin <= 1024 && a->prologue == FEMASR_PRO_NONE &&
+    return a->ksz == 3 && (a->stride == 1 || a->stride == 2) && a->pad == 1 && !a->up2 && (a->Cin % 64) == 0 && a->Cin <= 1024 && a->prologue == FEMASR_PRO_NONE &&
            a->act == FEMASR_ACT_NONE && (long long)a->B * a->H * a->W * a->Cin < (1ll << 31);
 }
 int femasr_gemm_bf16s_variant_count() { return kNumGS; }
@@ -475,14 +479,15 @@ int femasr_gemm_bf16s_launch(hipStream_t s, const femasr_conv_args *a, const voi
     FEMASR_REQUIRE(a && a->in && w_bf16s && femasr_gemm_bf16s_shape_ok(a), "gemm_bf16s: layer is neither a 1x1 / linear layer nor a 3x3 stride-1 pad-1 conv with Cin %% 64 == 0");
     FEMASR_REQUIRE(a->bias && a->out, "gemm_bf16s: bias/out must be set");
     FEMASR_REQUIRE(a->act == FEMASR_ACT_NONE || a->act == FEMASR_ACT_GELU, "gemm_bf16s: bad activation %d", a->act);
-    const long long M = (long long)a->B * a->H * a->W;
-    FEMASR_REQUIRE(a->Ho == a->H && a->Wo == a->W, "gemm_bf16s: Ho/Wo mismatch");
+    const bool conv = a->ksz == 3;
+    const int Ho = conv ? (a->H - 1) / a->stride + 1 : a->H, Wo = conv ? (a->W - 1) / a->stride + 1 : a->W;      // (H + 2 - 3) / stride + 1
+    const long long M = (long long)a->B * Ho * Wo;
+    FEMASR_REQUIRE(a->Ho == Ho && a->Wo == Wo, "gemm_bf16s: Ho/Wo mismatch");
     FEMASR_REQUIRE(M > 0 && M < (1ll << 31) - 256, "gemm_bf16s: bad row count");
     GemmSParams p{};
     p.A = a->in; p.W = (const uint4 *)w_bf16s; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
-    const bool conv = a->ksz == 3;
     p.M = (int)M; p.N = a->Cout; p.K = conv ? 9 * a->Cin : a->Cin;
-    p.imH = a->H; p.imW = a->W; p.Cin = a->Cin; p.tapmul = ((1 << 20) + (a->Cin >> 5) - 1) / (a->Cin >> 5);
+    p.imH = a->H; p.imW = a->W; p.imHo = Ho; p.imWo = Wo; p.stride = a->stride; p.Cin = a->Cin; p.tapmul = ((1 << 20) + (a->Cin >> 5) - 1) / (a->Cin >> 5);
     p.NT32 = (p.N + 31) / 32;
     p.MB = (p.M + 127) / 128; p.NB = (p.N + 127) / 128;
     const int nres = (a->res1 ? 1 : 0) + (a->res2 ? 1 : 0), act = a->act == FEMASR_ACT_GELU ? 1 : 0;

@@ -983,8 +983,8 @@ int femasr_set_weight(femasr_handle *h, const char *key, const float *dev_ptr, c
         if (rc) return rc;
     }
     if (w.kind == W_CONV && !dec_side && !w.up2 && w.shape[2] == 3 && w.shape[3] == 3 && (w.shape[1] % 64) == 0) {
-        // a 3x3 conv in FRONT of a codebook lookup: the planes of its (9 Cin x Cout) implicit-GEMM matrix (round 6: linear_math 1 runs it as
-        // the split-bf16 GEMM; whether it is a stride-1 conv is decided where it is launched - a stride-2 conv keeps the fp32 form)
+        // a 3x3 conv in FRONT of a codebook lookup (stride 1 or 2): the planes of its (9 Cin x Cout) implicit-GEMM matrix (round 6: linear_math 1
+        // runs it as the split-bf16 GEMM)
         if (!w.lin3) FEMASR_CHECK_HIP(hipMalloc(&w.lin3, femasr_packed_weight_conv3x3_bf16s_bytes((int)w.shape[0], (int)w.shape[1])));
         rc = femasr_repack_oihw_bf16s(nullptr, dev_ptr, (int)w.shape[0], (int)w.shape[1], w.lin3);
         if (rc) return rc;

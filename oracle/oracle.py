@@ -222,12 +222,12 @@ def linear_bf16s(x_rows, w_oi, bias, act=0, res1=None, res2=None, scalar=False):
 
 
 def conv3x3_split_ok(cin, ksz, stride, pad, up2):
-    """3x3 stride-1 pad-1 convs the library runs as the split-bf16 GEMM over K = 9 Cin (femasr_conv_args.w_bf16s with ksz = 3;
+    """3x3 pad-1 convs of stride 1 or 2 the library runs as the split-bf16 GEMM over K = 9 Cin (femasr_conv_args.w_bf16s with ksz = 3;
     csrc/kernels_gemm_bf16.hip CONV form) - round 6: the convs that FEED the codebook lookup, in linear_math 'bf16_split'."""
-    return ksz == 3 and stride == 1 and pad == 1 and not up2 and cin % 64 == 0
+    return ksz == 3 and stride in (1, 2) and pad == 1 and not up2 and cin % 64 == 0
 
 
-def conv3x3_bf16s(x, w_khwc, bias, res1=None, res2=None):
+def conv3x3_bf16s(x, w_khwc, bias, res1=None, res2=None, stride=1):
     """3x3 stride-1 pad-1 conv (femasr_arch.py:150-164, fema_utils.py:75,78, network_swinir.py:465) in the split-bf16 arithmetic: the
     implicit GEMM out[pixel][o] = sum_k A[pixel][k] W[k][o] with k = (3 ky + kx) Cin + c - tap-major, channels ascending inside a tap,
     zeros outside the image - evaluated EXACTLY as orc_linear_bf16s evaluates a K = 9 Cin linear layer (16-deep steps, six partial
@@ -237,15 +237,16 @@ def conv3x3_bf16s(x, w_khwc, bias, res1=None, res2=None):
     cout = w_khwc.shape[-1]
     xp = np.zeros((b, h + 2, w + 2, cin), np.float32)
     xp[:, 1:-1, 1:-1] = x
-    cols = np.empty((b, h, w, 9, cin), np.float32)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1            # (h + 2 - 3) // stride + 1
+    cols = np.empty((b, ho, wo, 9, cin), np.float32)
     for ky in range(3):
         for kx in range(3):
-            cols[:, :, :, 3 * ky + kx] = xp[:, ky:ky + h, kx:kx + w]
+            cols[:, :, :, 3 * ky + kx] = xp[:, ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (wo - 1) + 1:stride]
     w_oi = _c(np.asarray(w_khwc, np.float32).reshape(9 * cin, cout).T)
-    rows = b * h * w
+    rows = b * ho * wo
     y = linear_bf16s(cols.reshape(rows, 9 * cin), w_oi, bias, 0,
                      None if res1 is None else _c(res1).reshape(rows, cout), None if res2 is None else _c(res2).reshape(rows, cout))
-    return y.reshape(b, h, w, cout)
+    return y.reshape(b, ho, wo, cout)
 
 
 def linear(x_tokens, w_io, bias, act=0, res=None, split=False):
@@ -404,7 +405,7 @@ class OracleNet:
         w, b = self._conv_w(prefix)
         if self.conv_split and not dec and conv3x3_split_ok(x.shape[-1], ksz, stride, pad, up2):
             # round 6: a 3x3 conv in front of the codebook lookup (encoder ResBlocks, RSTB tail convs) as the split-bf16 GEMM over K = 9 Cin
-            return conv3x3_bf16s(x, w, b, res1, res2)
+            return conv3x3_bf16s(x, w, b, res1, res2, stride)
         return conv2d(x, w, b, ksz, stride, pad, up2, 0, res1, res2, wino=dec and self.wino)
 
     def _wino_fused(self, c, dec, shape=None):

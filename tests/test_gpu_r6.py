@@ -67,33 +67,37 @@ def test_test_tile_u8_equals_the_fp32_tile_path(cuda_device):
         net.test_u8(img[:1, :40, :48], out=buf[1:2, :, :100])
 
 
-CONV_SHAPES = [('rb128', 2, 24, 40, 128, 128, 0), ('rstb256', 1, 36, 36, 256, 256, 1), ('ragged', 3, 7, 13, 64, 96, 2), ('one_px_rows', 1, 1, 150, 64, 64, 0),
+CONV_SHAPES = [('s2_even', 2, 24, 40, 128, 256, 0, 2), ('s2_odd', 1, 23, 37, 64, 128, 1, 2), ('s2_256', 1, 36, 36, 256, 256, 0, 2), ('rb128', 2, 24, 40, 128, 128, 0), ('rstb256', 1, 36, 36, 256, 256, 1), ('ragged', 3, 7, 13, 64, 96, 2), ('one_px_rows', 1, 1, 150, 64, 64, 0),
                ('one_px_cols', 2, 130, 1, 128, 48, 1), ('cin192', 1, 16, 24, 192, 200, 1), ('tail_block', 1, 11, 12, 512, 130, 0)]
 
 
-@pytest.mark.parametrize('name,b,h,w,cin,cout,nres', CONV_SHAPES, ids=[c[0] for c in CONV_SHAPES])
-def test_conv3x3_bf16s_bit_exact_vs_oracle(cuda_device, name, b, h, w, cin, cout, nres):
+@pytest.mark.parametrize('case', CONV_SHAPES, ids=[c[0] for c in CONV_SHAPES])
+def test_conv3x3_bf16s_bit_exact_vs_oracle(cuda_device, case):
     """The 3x3 stride-1 pad-1 conv as the split-bf16 GEMM over K = 9 Cin (femasr_conv_args.w_bf16s with ksz = 3; the convs in FRONT of the
     codebook lookup in linear_math 'bf16_split') against the oracle's conv3x3_bf16s = im2col + orc_linear_bf16s, bit for bit: image borders
     (zero taps), rows that straddle images / batch entries, ragged pixel and channel tiles, residual operands - and closer to the fp64
     convolution than the fp32 fmaf chain of the direct form."""
     import gpu_utils as G
     from oracle import oracle as orc
+    name, b, h, w, cin, cout, nres = case[:7]
+    st = case[7] if len(case) > 7 else 1                     # stride 2: the encoder's down-sampling convs (femasr_arch.py:159)
+    ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
     rng = np.random.default_rng(len(name) + h * w)
     x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
     wt = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
     bias = (rng.standard_normal(cout) * 0.1).astype(np.float32)
-    r1 = rng.standard_normal((b, h, w, cout)).astype(np.float32) if nres >= 1 else None
-    r2 = rng.standard_normal((b, h, w, cout)).astype(np.float32) if nres >= 2 else None
-    yo = orc.conv3x3_bf16s(x, wt, bias, r1, r2)
-    y = G.conv2d(x, wt, bias, 3, 1, 1, res1=r1, res2=r2, bf16s=True)
+    r1 = rng.standard_normal((b, ho, wo, cout)).astype(np.float32) if nres >= 1 else None
+    r2 = rng.standard_normal((b, ho, wo, cout)).astype(np.float32) if nres >= 2 else None
+    yo = orc.conv3x3_bf16s(x, wt, bias, r1, r2, stride=st)
+    y = G.conv2d(x, wt, bias, 3, st, 1, res1=r1, res2=r2, bf16s=True)
+    assert y.shape == (b, ho, wo, cout)
     assert np.array_equal(y.view(np.uint32), yo.view(np.uint32)), f'{name}: {(y != yo).sum()} of {y.size} differ, max-abs {np.abs(y - yo).max():.3e}'
     ref = torch.nn.functional.conv2d(torch.from_numpy(x.astype(np.float64)).permute(0, 3, 1, 2), torch.from_numpy(wt.astype(np.float64)).permute(3, 2, 0, 1),
-                                     torch.from_numpy(bias.astype(np.float64)), padding=1).permute(0, 2, 3, 1).numpy()
+                                     torch.from_numpy(bias.astype(np.float64)), padding=1, stride=st).permute(0, 2, 3, 1).numpy()
     for r in (r1, r2):
         if r is not None:
             ref = ref + r
-    ych = G.conv2d(x, wt, bias, 3, 1, 1, res1=r1, res2=r2)          # the direct fp32 form (one fmaf chain per output)
+    ych = G.conv2d(x, wt, bias, 3, st, 1, res1=r1, res2=r2)         # the direct fp32 form (one fmaf chain per output)
     e_split, e_chain = float(np.abs(y - ref).max()), float(np.abs(ych - ref).max())
     print(f'{name}: max-abs vs fp64: split {e_split:.3e}, fp32 chain {e_chain:.3e}')
     assert e_split <= 1.5 * e_chain + 1e-7
@@ -106,8 +110,8 @@ def test_conv3x3_bf16s_refusals_and_gn_silu_apply(cuda_device):
     with pytest.raises(_lib.FemasrError):          # Cin % 64 != 0
         G.conv2d(x, np.zeros((3, 3, 96, 64), np.float32), np.zeros(64, np.float32), 3, 1, 1, bf16s=True)
     x = np.zeros((1, 8, 8, 64), np.float32)
-    with pytest.raises(_lib.FemasrError):          # stride 2
-        G.conv2d(x, np.zeros((3, 3, 64, 64), np.float32), np.zeros(64, np.float32), 3, 2, 1, bf16s=True)
+    with pytest.raises(_lib.FemasrError):          # no padding
+        G.conv2d(x, np.zeros((3, 3, 64, 64), np.float32), np.zeros(64, np.float32), 3, 1, 0, bf16s=True)
     with pytest.raises(_lib.FemasrError):          # a GN prologue is not taken by this form (femasr_gn_silu_apply runs in front of it)
         G.conv2d(x, np.zeros((3, 3, 64, 64), np.float32), np.zeros(64, np.float32), 3, 1, 1, bf16s=True, prologue=_lib.PRO_GN_SILU,
                  pro=(np.ones((1, 64), np.float32), np.zeros((1, 64), np.float32), None))
