@@ -221,10 +221,10 @@ def linear_bf16s(x_rows, w_oi, bias, act=0, res1=None, res2=None, scalar=False):
     return out
 
 
-def conv3x3_split_ok(cin, ksz, stride, pad, up2):
+def conv3x3_split_ok(cin, ksz, stride, pad, up2, numel=0):
     """3x3 pad-1 convs of stride 1 or 2 the library runs as the split-bf16 GEMM over K = 9 Cin (femasr_conv_args.w_bf16s with ksz = 3;
     csrc/kernels_gemm_bf16.hip CONV form) - round 6: the convs that FEED the codebook lookup, in linear_math 'bf16_split'."""
-    return ksz == 3 and stride in (1, 2) and pad == 1 and not up2 and cin % 64 == 0
+    return ksz == 3 and stride in (1, 2) and pad == 1 and not up2 and cin % 64 == 0 and cin <= 1024 and numel < 2 ** 31      # (femasr_conv3x3_bf16s_shape_ok)
 
 
 def conv3x3_bf16s(x, w_khwc, bias, res1=None, res2=None, stride=1):
@@ -403,7 +403,7 @@ class OracleNet:
     def _conv(self, x, prefix, ksz, stride=1, pad=1, up2=False, res1=None, res2=None, dec=False):
         """dec: the conv sits behind the codebook lookup (decoder side)."""
         w, b = self._conv_w(prefix)
-        if self.conv_split and not dec and conv3x3_split_ok(x.shape[-1], ksz, stride, pad, up2):
+        if self.conv_split and not dec and conv3x3_split_ok(x.shape[-1], ksz, stride, pad, up2, x.size):
             # round 6: a 3x3 conv in front of the codebook lookup (encoder ResBlocks, RSTB tail convs) as the split-bf16 GEMM over K = 9 Cin
             return conv3x3_bf16s(x, w, b, res1, res2, stride)
         return conv2d(x, w, b, ksz, stride, pad, up2, 0, res1, res2, wino=dec and self.wino)
